@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Benchmark of the north-star metric: queries/s of exact brute-force inner-product top-k.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json, configs[2], the configuration `metric` is quoted on; it fits one GPU):
+10 M sections x 768 fp16, batch = 1024 queries, top-100, corpus resident in HBM, row-sharded over the N
+ranks (strong scaling: the corpus is fixed, each rank holds N_total / N rows).  One "step" = one batch of
+1024 queries answered end to end: local fused score + top-k on every rank, RCCL all-gather of the
+per-shard top-k, merge.  Inputs are synthetic N(0,1) embeddings generated on the device (corpus seed 1234,
+query seed 4321); queries are resident in HBM when the timed region starts.
+
+Prints ONE JSON line on rank 0 (see the keys below); `roofline` is for the dominant kernel
+(`mips_filter_kernel`, MFMA-bound at nq = 1024), `cpu_baseline` is the oracle-side faiss-CPU restatement
+timed on the host cores of this box (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GEN_CHUNK = 250_000  # rows per generation chunk; shard boundaries are multiples of it so the corpus is the same for every N
+
+
+def parse_args() -> argparse.Namespace:
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=10_000_000)
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--nq", type=int, default=1024)
+    p.add_argument("--k", type=int, default=100)
+    p.add_argument("--dtype", choices=["f16", "bf16"], default="f16")
+    p.add_argument("--tile", type=int, default=0)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=15.0)
+    return p.parse_args()
+
+
+def main() -> None:
+    args = parse_args()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: PLC0415
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vod_amd.index import HipFlatIndex, merge_topk
+
+    tdt = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    n_total, d, nq, k = args.rows, args.dim, args.nq, args.k
+    # contiguous row sharding on generation-chunk boundaries
+    n_chunks = (n_total + GEN_CHUNK - 1) // GEN_CHUNK
+    c_lo = (n_chunks * rank) // world
+    c_hi = (n_chunks * (rank + 1)) // world
+    row_lo = min(n_total, c_lo * GEN_CHUNK)
+    row_hi = min(n_total, c_hi * GEN_CHUNK)
+    n_local = row_hi - row_lo
+
+    index = HipFlatIndex(d, max(n_local, 1), dtype=tdt, device=local_rank)
+    if args.tile:
+        index.set_param("tile", args.tile)
+    t_build0 = time.perf_counter()
+    for c in range(c_lo, c_hi):
+        g = torch.Generator(device=dev).manual_seed(1234 + c)
+        rows = min(GEN_CHUNK, n_total - c * GEN_CHUNK)
+        index.add(torch.randn((rows, d), generator=g, device=dev, dtype=torch.float32).to(tdt))
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build0
+    assert index.ntotal == n_local
+    gq = torch.Generator(device=dev).manual_seed(4321)
+    queries = torch.randn((nq, d), generator=gq, device=dev, dtype=torch.float32).to(tdt)
+
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    if world > 1:
+        gat_s = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
+        gat_i = torch.empty((world, nq, k), dtype=torch.int64, device=dev)
+
+    def step():
+        index.search(queries, k, id_base=row_lo, out=(out_s, out_i))
+        if world > 1:
+            dist.all_gather_into_tensor(gat_s, out_s)
+            dist.all_gather_into_tensor(gat_i, out_i)
+            return merge_topk(gat_s, gat_i)
+        return out_s, out_i
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    index.set_param("profile", 1)
+    filter_ns = 0
+    filter_launches = 0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        filter_ns += index.get_stat("last_filter_ns")
+        filter_launches += index.get_stat("last_filter_launches")
+    fence()
+    elapsed = time.perf_counter() - t0
+    index.set_param("profile", 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- post-run verification (outside the timed region): exactness on a query sample ----
+    verify = None
+    if not args.no_verify:
+        fs, fi = res
+        sample = list(range(0, nq, max(1, nq // 8)))[:8]
+        # local brute force on this rank's shard with torch (fp32 matmul on the stored rows), merged over ranks
+        full = torch.empty((len(sample), n_local), dtype=torch.float32, device=dev)
+        qs = queries[sample].float()
+        for lo in range(0, n_local, 1_000_000):
+            blk = index.stored_rows(lo, min(1_000_000, n_local - lo))
+            full[:, lo : lo + blk.shape[0]] = qs @ blk.float().T
+            del blk
+        ls, li = torch.topk(full, min(k, n_local), dim=1)
+        li = li + row_lo
+        del full
+        if world > 1:
+            pad_s = torch.full((len(sample), k), float("-inf"), device=dev)
+            pad_i = torch.full((len(sample), k), -1, dtype=torch.int64, device=dev)
+            pad_s[:, : ls.shape[1]] = ls
+            pad_i[:, : li.shape[1]] = li
+            as_ = torch.empty((world,) + pad_s.shape, device=dev)
+            ai_ = torch.empty((world,) + pad_i.shape, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(as_, pad_s)
+            dist.all_gather_into_tensor(ai_, pad_i)
+            ls, li = merge_topk(as_, ai_)
+        got_i = fi[sample].cpu()
+        ref_i = li.cpu()
+        hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got_i, ref_i))
+        verify = {
+            "recall_at_k_vs_torch_fp32": hits / float(ref_i.numel()),
+            "max_abs_score_diff": float((fs[sample].cpu() - ls.cpu()).abs().max()),
+            "queries_checked": len(sample),
+        }
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        qps = nq * args.steps / elapsed
+        flops_per_step = 2.0 * nq * n_local * d          # algorithmic flops of this rank's filter launches per step
+        bytes_per_step = n_local * d * 2.0 + nq * d * 2.0 + nq * k * 12.0
+        filt_s = filter_ns * 1e-9
+        achieved_tf = flops_per_step * args.steps / filt_s / 1e12 if filt_s > 0 else None
+        traffic = None
+        tfile = ROOT / "profiles" / "hbm_traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get(f"{n_total}x{d}x{nq}@{world}")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "queries/sec brute-force top-k (10Mx768 fp16)",
+            "value": qps,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n_total} sections x {d} {args.dtype}, batch {nq} queries, top-{k}, exact brute force",
+                "rows_per_gpu": n_local,
+                "parallelism": f"row-sharded x{world} + RCCL all-gather of per-shard top-k" if world > 1 else "single GPU",
+                "index_build_s": round(t_build, 3),
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "mips_filter_kernel",
+                "achieved": achieved_tf,
+                "peak": 2500.0,
+                "unit": "TFLOP/s",
+                "frac": (achieved_tf / 2500.0) if achieved_tf else None,
+                "traffic": traffic,
+                "launches_per_step": filter_launches / args.steps,
+                "kernel_ms_per_step": filt_s / args.steps * 1e3,
+                "algorithmic_flops_per_step": flops_per_step,
+                "algorithmic_bytes_per_step": bytes_per_step,
+                "hbm_frac_at_8TBps": (bytes_per_step * args.steps / filt_s / 8e12) if filt_s > 0 else None,
+            },
+        }
+        if verify is not None:
+            line["verify"] = verify
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.cpu_baseline import time_cpu_baseline  # the reported CPU baseline, never the product path
+
+            line["cpu_baseline"] = time_cpu_baseline(d, nq, k, n_total, target_seconds=args.cpu_seconds)
+            line["speedup_vs_cpu_baseline"] = qps / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+
+    index.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+/*
+ * vodhip.h -- C-ABI of the MI355X-native dense-retrieval scoring library (libvodhip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of VodLM/vod that this project replaces:
+ * the corpus vector store + batched query x section inner-product top-k that the reference
+ * reaches through a faiss server process, plus the hybrid score merge and the in-batch
+ * retrieval scoring glued to it.  Plain pointers and sizes only; no torch / C++ types.
+ * Reference citations are relative to /root/reference/.
+ *
+ * Conventions
+ *   - every function returns 0 on success, < 0 on error; `vodhip_last_error()` returns a
+ *     thread-local, NUL-terminated description of the last failure on the calling thread;
+ *   - no exception crosses the boundary; the caller owns every buffer it passes in;
+ *   - `stream` is a `hipStream_t` passed as `void*` (NULL = the null stream).  Kernels are
+ *     enqueued on it; functions documented "async" return before the GPU work is done;
+ *   - device pointers must belong to the device the handle was created on;
+ *   - result layout everywhere: scores float32 [nq,k] sorted descending, ids int64 [nq,k],
+ *     ties -> smaller id first, missing entries padded with score -inf / id -1
+ *     (the repo-wide padding convention, src/vod_types/retrieval.py:284-285).
+ */
+#ifndef VODHIP_H
+#define VODHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VODHIP_VERSION 1
+
+/* element types of vectors handed to / stored by the library */
+enum { VODHIP_F16 = 0, VODHIP_BF16 = 1, VODHIP_F32 = 2 };
+/* where a caller buffer lives */
+enum { VODHIP_HOST = 0, VODHIP_DEVICE = 1 };
+
+typedef struct vodhip_index vodhip_index_t;
+
+const char* vodhip_last_error(void);
+int vodhip_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * H1  corpus vector store.
+ * Replaces: faiss.index_factory(D, "Flat", METRIC_INNER_PRODUCT) + index.add(float32 batch)
+ *           (src/vod_search/faiss_search/build.py:51-81) and the faiss.write_index/read_index
+ *           round trip (src/vod_search/factory.py:167, src/vod_search/faiss_search/server.py:42).
+ * The store is a row-major [capacity, dim_padded] fp16/bf16 matrix in HBM on `device`
+ * (dim padded with zeros to a multiple of 64).  Rows get ids 0,1,2,... in insertion order.
+ * ------------------------------------------------------------------------------------------- */
+int vodhip_index_create(int device, int64_t dim, int store_dtype /* VODHIP_F16 | VODHIP_BF16 */,
+                        int64_t capacity_rows, vodhip_index_t** out);
+int vodhip_index_destroy(vodhip_index_t* index);
+
+/* Append `n_rows` row-major [n_rows, dim] vectors of `src_dtype` living in host or device memory.
+ * Values are rounded to the store dtype (round-to-nearest-even).  Synchronous for host sources
+ * (the call returns when the rows are resident); async on `stream` for device sources. */
+int vodhip_index_add(vodhip_index_t* index, const void* rows, int64_t n_rows, int src_dtype,
+                     int src_location, void* stream);
+int vodhip_index_reset(vodhip_index_t* index);               /* ntotal := 0 (capacity kept) */
+int vodhip_index_ntotal(const vodhip_index_t* index, int64_t* out);
+int vodhip_index_dim(const vodhip_index_t* index, int64_t* out);
+int vodhip_index_capacity(const vodhip_index_t* index, int64_t* out);
+/* raw view of the store (device pointer, row stride in elements) for persistence / tests */
+int vodhip_index_data(const vodhip_index_t* index, void** dev_ptr, int64_t* row_stride_elems, int* store_dtype);
+/* copy rows [row_begin, row_begin + n_rows) of the store, as stored (fp16/bf16, unpadded [n_rows, dim]),
+ * to `dst` in host or device memory; async on `stream` for device destinations. */
+int vodhip_index_get_rows(const vodhip_index_t* index, int64_t row_begin, int64_t n_rows, void* dst,
+                          int dst_location, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * H2  exact brute-force inner-product top-k over the store.
+ * Replaces: faiss_index.search(query_vec, k)
+ *           (src/vod_search/faiss_search/server.py:72 and :84).
+ * `queries` is a DEVICE pointer to row-major [nq, dim] values of `q_dtype`; they are rounded to the
+ * store dtype.  Scores are fp32-accumulated dot products of the stored (rounded) values.
+ * `id_base` is added to every valid id (row offset of this shard inside a sharded corpus,
+ * the reference's `indices += offset` at src/vod_search/sharded_search.py:103,155 -- pads stay -1).
+ * out_scores / out_ids are DEVICE pointers [nq, k].  1 <= k <= VODHIP_MAX_K.
+ *
+ * vodhip_index_search        enqueue + wait + exactness check (re-runs in the exhaustive-safe
+ *                            schedule if a candidate buffer overflowed); results are final on return.
+ * vodhip_index_search_async  enqueue only.  Must be followed by vodhip_index_search_finish on the
+ *                            same index before the outputs are trusted.
+ * ------------------------------------------------------------------------------------------- */
+#define VODHIP_MAX_K 2048
+int vodhip_index_search(vodhip_index_t* index, const void* queries, int q_dtype, int64_t nq, int k,
+                        int64_t id_base, float* out_scores, int64_t* out_ids, void* stream);
+int vodhip_index_search_async(vodhip_index_t* index, const void* queries, int q_dtype, int64_t nq, int k,
+                              int64_t id_base, float* out_scores, int64_t* out_ids, void* stream);
+int vodhip_index_search_finish(vodhip_index_t* index, void* stream);
+
+/* Tunables / introspection (tests and bench).  key: "cand_cap", "dense_rows", "growth", "force_safe",
+ * "tile" (0 = auto, 1 = 128x128, 2 = 256x256); stats: "last_overflow", "last_chunks", "last_safe_reruns". */
+int vodhip_index_set_param(vodhip_index_t* index, const char* key, int64_t value);
+int vodhip_index_get_stat(const vodhip_index_t* index, const char* key, int64_t* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * H3  merge of per-shard top-k lists (multi-GPU exchange step, after the RCCL all-gather).
+ * Replaces: the row-offset + stack of ShardedSearchClient (src/vod_search/sharded_search.py:92-106,
+ *           198-203) and faiss IndexShards' host merge (src/vod_search/faiss_search/server.py:51-54).
+ * scores/ids: DEVICE [n_shards, nq, k] (ids already global, pads -1).  Output [nq, k_out].
+ * ------------------------------------------------------------------------------------------- */
+int vodhip_merge_topk(const float* scores, const int64_t* ids, int n_shards, int64_t nq, int k,
+                      int k_out, float* out_scores, int64_t* out_ids, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * H4  hybrid score merge (lookup + up to VODHIP_MAX_ENGINES scored engines), one query row per wavefront.
+ * Replaces: _merge_search_results (src/vod_dataloaders/core/search.py:79-125) =
+ *           normalize_search_scores_ (core/normalize.py:6-20) + merge_search_results
+ *           (core/merge.py:8-164) + gather_values_by_indices (core/numpy_ops.py:126-143).
+ * All pointers are DEVICE pointers.  lookup_idx/lookup_lbl [nq, k_lookup] (lookup scores are discarded
+ * by the reference, search.py:92).  engine e: idx[e] int64 [nq, k_e], scr[e] float32 [nq, k_e].
+ * Outputs have `out_stride` = k_lookup + sum(k_e) + 1 columns allocated; the reference's width
+ * (max cursor + 1, merge.py:160-162) is written to *out_width (device int32).
+ *   out_idx  int64  : union of ids in first-seen order, -1 padded
+ *   out_scr  float32: sum_e w_e * (s_e - rowmin_e), -inf padded
+ *   out_lbl  int64  : lookup label of the id, -1 if absent (pad column: see SURVEY quirk Q3)
+ *   out_raw[e] float32: min-subtracted score of the id in engine e, NaN if absent
+ * ------------------------------------------------------------------------------------------- */
+#define VODHIP_MAX_ENGINES 4
+int vodhip_merge_hybrid(const int64_t* lookup_idx, const int64_t* lookup_lbl, int k_lookup,
+                        int n_engines, const int64_t* const* engine_idx, const float* const* engine_scr,
+                        const int* engine_k, const float* engine_weight, int64_t nq,
+                        int64_t* out_idx, float* out_scr, int64_t* out_lbl, float* const* out_raw,
+                        int out_stride, int32_t* out_width, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * H5  in-batch retrieval scoring + log-prob / loss combination, forward and backward fused.
+ * Replaces: RetrievalGradients.__call__ (src/vod_models/vod_gradients/retrieval.py:30-92) with
+ *           _compute_retriever_scores (:186-203), _cast_data_targets (:206-215), _compute_loss
+ *           (:153-177), _compute_kld (:225-243) and the autograd backward of those.
+ * q [B,H], s [D,H] (sections_3d = 0) or [B,D,H] (sections_3d = 1), of `enc_dtype` (F32 | F16 | BF16).
+ * score/sparse/dense float32 [B,D] (sparse/dense may be NULL), relevance int64 [B,D].
+ * Outputs (DEVICE): retriever_scores float32 [B,D]; d_scores float32 [B,D] (= dLoss/dScores);
+ * loss float32 [1]; kl float32 [3] (score, sparse, dense; NaN where the input is NULL).
+ * vodhip_retrieval_backward turns d_scores into dq [B,H] and ds ([D,H] | [B,D,H]) in float32,
+ * scaled by *grad_out (device float32 scalar).
+ * ------------------------------------------------------------------------------------------- */
+int vodhip_retrieval_forward(const void* q, const void* s, int enc_dtype, int sections_3d,
+                             int64_t B, int64_t D, int64_t H,
+                             const float* score, const int64_t* relevance, const float* sparse, const float* dense,
+                             float* retriever_scores, float* d_scores, float* loss, float* kl,
+                             float* workspace /* DEVICE scratch, >= 8*B floats */, void* stream);
+int vodhip_retrieval_backward(const void* q, const void* s, int enc_dtype, int sections_3d,
+                              int64_t B, int64_t D, int64_t H, const float* d_scores, const float* grad_out,
+                              float* dq, float* ds, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VODHIP_H */

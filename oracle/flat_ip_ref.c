@@ -10,7 +10,7 @@
  * in this image; this file follows the published IndexFlatIP contract (exhaustive scan + heap
  * for small batches) with two stated choices: ties -> smaller id first, pad = (-inf, -1).
  *
- * Build: gcc -O3 -march=native -fopenmp -shared -fPIC flat_ip_ref.c -o _build/liboracle_flat_ip.so
+ * Build: gcc -O3 -fopenmp -shared -fPIC flat_ip_ref.c -o _build/liboracle_flat_ip.so
  */
 #include <math.h>
 #include <stdint.h>

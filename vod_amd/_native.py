@@ -1,0 +1,121 @@
+"""ctypes binding of libvodhip.so (the C-ABI declared in include/vodhip.h).
+
+The library is built in-tree (`vod_amd/csrc/libvodhip.so`, see `vod_amd/build.py`) so that it travels
+with the repository snapshot.  Loading fails loudly: there is no Python/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import pathlib
+import threading
+
+_LIB_NAME = "libvodhip.so"
+_lock = threading.Lock()
+_lib: ctypes.CDLL | None = None
+
+F16, BF16, F32 = 0, 1, 2
+HOST, DEVICE = 0, 1
+MAX_K = 2048
+MAX_ENGINES = 4
+
+
+class NativeLibraryError(RuntimeError):
+    """The HIP extension is missing or a native call failed."""
+
+
+def lib_path() -> pathlib.Path:
+    return pathlib.Path(__file__).resolve().parent / "csrc" / _LIB_NAME
+
+
+_c = ctypes
+_vp, _i64, _i32, _f32p = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p
+
+# name -> (restype, argtypes): every symbol include/vodhip.h declares
+SIGNATURES: dict[str, tuple] = {
+    "vodhip_last_error": (_c.c_char_p, []),
+    "vodhip_version": (_i32, []),
+    "vodhip_index_create": (_i32, [_i32, _i64, _i32, _i64, _c.POINTER(_vp)]),
+    "vodhip_index_destroy": (_i32, [_vp]),
+    "vodhip_index_add": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "vodhip_index_reset": (_i32, [_vp]),
+    "vodhip_index_ntotal": (_i32, [_vp, _c.POINTER(_i64)]),
+    "vodhip_index_dim": (_i32, [_vp, _c.POINTER(_i64)]),
+    "vodhip_index_capacity": (_i32, [_vp, _c.POINTER(_i64)]),
+    "vodhip_index_data": (_i32, [_vp, _c.POINTER(_vp), _c.POINTER(_i64), _c.POINTER(_i32)]),
+    "vodhip_index_get_rows": (_i32, [_vp, _i64, _i64, _vp, _i32, _vp]),
+    "vodhip_index_search": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]),
+    "vodhip_index_search_async": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]),
+    "vodhip_index_search_finish": (_i32, [_vp, _vp]),
+    "vodhip_index_set_param": (_i32, [_vp, _c.c_char_p, _i64]),
+    "vodhip_index_get_stat": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i64)]),
+    "vodhip_merge_topk": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "vodhip_merge_hybrid": (
+        _i32,
+        [_vp, _vp, _i32, _i32, _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_i32), _c.POINTER(_c.c_float), _i64,
+         _vp, _vp, _vp, _c.POINTER(_vp), _i32, _vp, _vp],
+    ),
+    "vodhip_retrieval_forward": (
+        _i32, [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    ),
+    "vodhip_retrieval_backward": (_i32, [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+def load_library() -> ctypes.CDLL:
+    """Load libvodhip.so once; raise NativeLibraryError if it is absent or lacks a declared symbol."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not path.exists():
+            raise NativeLibraryError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C vod_amd/csrc`.  vod_amd has no CPU fallback."
+            )
+        try:
+            lib = ctypes.CDLL(str(path))
+        except OSError as exc:  # pragma: no cover - depends on the machine
+            raise NativeLibraryError(f"cannot load {path}: {exc}") from exc
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as exc:
+                raise NativeLibraryError(f"{path} does not export `{name}` (stale build?)") from exc
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(status: int) -> None:
+    """Raise with the library's thread-local message when a call returned an error."""
+    if status != 0:
+        msg = load_library().vodhip_last_error()
+        raise NativeLibraryError(msg.decode("utf-8", "replace") if msg else f"native call failed with status {status}")
+
+
+def torch_dtype_code(dtype) -> int:
+    import torch
+
+    try:
+        return {torch.float16: F16, torch.bfloat16: BF16, torch.float32: F32}[dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {dtype}; expected float16, bfloat16 or float32") from None
+
+
+def numpy_dtype_code(dtype) -> int:
+    import numpy as np
+
+    dt = np.dtype(dtype)
+    if dt == np.float16:
+        return F16
+    if dt == np.float32:
+        return F32
+    raise TypeError(f"unsupported numpy dtype {dt}; expected float16 or float32")
+
+
+def current_stream_ptr(device=None) -> int:
+    import torch
+
+    return int(torch.cuda.current_stream(device).cuda_stream)

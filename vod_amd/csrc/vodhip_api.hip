@@ -1,0 +1,495 @@
+// C-ABI layer of libvodhip.so: handle management, ingest, the chunk schedule of the fused
+// score + top-k search, and thin wrappers for the merge / hybrid / retrieval kernels.
+// See include/vodhip.h for the contract and the reference call sites each entry point replaces.
+#include "../../include/vodhip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vodhip_internal.h"
+
+using namespace vodhip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return -1;
+}
+
+#define HIP_OK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+constexpr int64_t ROW_ALIGN = 256;       // largest tile height; chunk boundaries and capacity padding
+constexpr int64_t MAX_NQ_PER_PASS = 2048;
+constexpr int64_t STAGE_BYTES = 64ll << 20;
+
+struct PendingSearch {
+    bool active = false;
+    const void* queries = nullptr;
+    int q_dtype = 0;
+    int64_t nq = 0;
+    int k = 0;
+    int64_t id_base = 0;
+    float* out_scores = nullptr;
+    int64_t* out_ids = nullptr;
+};
+
+}  // namespace
+
+struct vodhip_index {
+    int device = 0;
+    int64_t dim = 0, dim_pad = 0;
+    int64_t capacity = 0, capacity_pad = 0;
+    int64_t ntotal = 0;
+    int dtype = VODHIP_F16;
+    uint16_t* data = nullptr;
+    void* stage_dev = nullptr;  // raw-dtype staging for host ingest
+    SearchWorkspace ws;
+    unsigned int* overflow_host = nullptr;  // pinned
+    PendingSearch pending;
+    // tunables
+    int64_t cand_cap = 4096;
+    int64_t dense_rows = 2048;
+    int64_t growth_x100 = 0;  // 0 = derive from k
+    int64_t force_safe = 0;
+    int64_t tile = 0;
+    int64_t profile = 0;  // 1: bracket every filter launch with HIP events (bench / roofline accounting)
+    // stats
+    int64_t last_overflow = 0, last_chunks = 0, last_safe_reruns = 0;
+    int64_t last_filter_launches = 0, last_filter_ns = 0;
+    std::vector<hipEvent_t> ev_pool;  // pairs (start, stop), reused across searches
+    size_t ev_used = 0;
+};
+
+namespace {
+
+int elem_size(int dtype) { return dtype == VODHIP_F32 ? 4 : 2; }
+
+int free_workspace(vodhip_index* ix) {
+    SearchWorkspace& w = ix->ws;
+    (void)hipFree(w.q_pad);
+    (void)hipFree(w.topk);
+    (void)hipFree(w.cand);
+    (void)hipFree(w.cnt);
+    (void)hipFree(w.thr_s);
+    (void)hipFree(w.thr_key);
+    (void)hipFree(w.overflow);
+    w = SearchWorkspace();
+    return 0;
+}
+
+int ensure_workspace(vodhip_index* ix, int64_t nq_pad, int64_t cap, int64_t kp) {
+    SearchWorkspace& w = ix->ws;
+    if (w.nq_cap >= nq_pad && w.cap == cap && w.kp == kp && w.q_pad) return 0;
+    const int64_t nq_cap = std::max(nq_pad, w.nq_cap);
+    free_workspace(ix);
+    HIP_OK(hipMalloc((void**)&w.q_pad, (size_t)nq_cap * ix->dim_pad * 2));
+    HIP_OK(hipMalloc((void**)&w.topk, (size_t)nq_cap * kp * sizeof(key_t64)));
+    HIP_OK(hipMalloc((void**)&w.cand, (size_t)nq_cap * cap * sizeof(key_t64)));
+    HIP_OK(hipMalloc((void**)&w.cnt, (size_t)nq_cap * sizeof(unsigned int)));
+    HIP_OK(hipMalloc((void**)&w.thr_s, (size_t)nq_cap * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&w.thr_key, (size_t)nq_cap * sizeof(key_t64)));
+    HIP_OK(hipMalloc((void**)&w.overflow, sizeof(unsigned int)));
+    w.nq_cap = nq_cap;
+    w.cap = cap;
+    w.kp = kp;
+    return 0;
+}
+
+// chunk schedule: [0, c0) scored densely (every score becomes a candidate: the threshold is still
+// -inf), then geometrically growing chunks filtered against the threshold of everything before them.
+void make_schedule(int64_t n, int64_t dense_rows, double growth, bool safe, int64_t cap,
+                   std::vector<std::pair<int64_t, int64_t>>& chunks, std::vector<bool>& dense) {
+    chunks.clear();
+    dense.clear();
+    if (n <= 0) return;
+    if (safe) {
+        const int64_t step = std::max<int64_t>(ROW_ALIGN, cap / ROW_ALIGN * ROW_ALIGN);
+        for (int64_t b = 0; b < n; b += step) {
+            chunks.emplace_back(b, std::min(n, b + step));
+            dense.push_back(true);
+        }
+        return;
+    }
+    int64_t b = std::min(n, dense_rows);
+    chunks.emplace_back(0, b);
+    dense.push_back(true);
+    while (b < n) {
+        int64_t e = (int64_t)((double)b * growth);
+        e = std::max(e, b + ROW_ALIGN);
+        e = round_up(e, ROW_ALIGN);
+        e = std::min(e, n);
+        chunks.emplace_back(b, e);
+        dense.push_back(false);
+        b = e;
+    }
+}
+
+int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStream_t stream) {
+    const int k = ps.k;
+    int64_t kp = 64;
+    while (kp < k) kp <<= 1;
+    const int64_t cap = ix->cand_cap;
+    int64_t dense_rows = std::max(ix->dense_rows, round_up(k, ROW_ALIGN));
+    dense_rows = std::min(dense_rows, cap / ROW_ALIGN * ROW_ALIGN);
+    if (dense_rows < k) return fail("cand_cap=%lld is too small for k=%d", (long long)cap, k);
+    double growth = ix->growth_x100 > 0 ? ix->growth_x100 / 100.0 : 1.0 + (double)cap / (4.0 * k);
+    growth = std::min(8.0, std::max(1.25, growth));
+
+    std::vector<std::pair<int64_t, int64_t>> chunks;
+    std::vector<bool> dense;
+    make_schedule(ix->ntotal, dense_rows, growth, safe, cap, chunks, dense);
+    ix->last_chunks = (int64_t)chunks.size();
+
+    const int q_es = elem_size(ps.q_dtype);
+    int tile = (int)ix->tile;
+    if (tile == 0) tile = ps.nq > 128 ? 2 : 1;
+    const int64_t bn = filter_tile_cols(tile);
+    if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
+    const SearchWorkspace& ws = ix->ws;
+    HIP_OK(hipMemsetAsync(ws.overflow, 0, sizeof(unsigned int), stream));
+    for (int64_t qb = 0; qb < ps.nq; qb += MAX_NQ_PER_PASS) {
+        const int64_t nq = std::min(MAX_NQ_PER_PASS, ps.nq - qb);
+        const int64_t nq_pad = round_up(nq, bn);
+        // queries -> store dtype, zero padded rows/cols
+        HIP_OK(hipMemsetAsync(ws.q_pad, 0, (size_t)nq_pad * ix->dim_pad * 2, stream));
+        HIP_OK(launch_convert_rows((const char*)ps.queries + (size_t)qb * ix->dim * q_es, ps.q_dtype, nq, ix->dim,
+                                   ws.q_pad, ix->dtype, ix->dim_pad, stream));
+        HIP_OK(launch_search_init(ws, nq_pad, stream));
+        for (size_t c = 0; c < chunks.size(); ++c) {
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if (ix->profile) {
+                while (ix->ev_pool.size() < ix->ev_used + 2) {
+                    hipEvent_t e;
+                    HIP_OK(hipEventCreate(&e));
+                    ix->ev_pool.push_back(e);
+                }
+                ev0 = ix->ev_pool[ix->ev_used++];
+                ev1 = ix->ev_pool[ix->ev_used++];
+                HIP_OK(hipEventRecord(ev0, stream));
+            }
+            HIP_OK(launch_filter(ix->dtype, tile, dense[c], ix->data, ws.q_pad, ix->dim_pad, chunks[c].first,
+                                 chunks[c].second, nq, nq_pad, ws, stream));
+            if (ix->profile) HIP_OK(hipEventRecord(ev1, stream));
+            HIP_OK(launch_select(ws, nq, k, dense[c] ? chunks[c].second - chunks[c].first : -1, stream));
+        }
+        HIP_OK(launch_output(ws, nq, k, ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k, stream));
+    }
+    HIP_OK(hipMemcpyAsync(ix->overflow_host, ws.overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vodhip_last_error(void) { return g_last_error.c_str(); }
+int vodhip_version(void) { return VODHIP_VERSION; }
+
+int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capacity_rows, vodhip_index_t** out) {
+    if (!out) return fail("out is NULL");
+    if (dim <= 0 || capacity_rows < 0) return fail("invalid dim=%lld / capacity=%lld", (long long)dim, (long long)capacity_rows);
+    if (store_dtype != VODHIP_F16 && store_dtype != VODHIP_BF16) return fail("store dtype must be F16 or BF16");
+    if (capacity_rows >= (1ll << 31) - 2 * ROW_ALIGN) return fail("capacity must be < 2^31 rows per device");
+    HIP_OK(hipSetDevice(device));
+    vodhip_index* ix = new vodhip_index();
+    ix->device = device;
+    ix->dim = dim;
+    ix->dim_pad = round_up(dim, 64);
+    ix->capacity = capacity_rows;
+    ix->capacity_pad = round_up(capacity_rows, ROW_ALIGN) + ROW_ALIGN;
+    ix->dtype = store_dtype;
+    const size_t bytes = (size_t)ix->capacity_pad * ix->dim_pad * 2;
+    hipError_t e = hipMalloc((void**)&ix->data, bytes);
+    if (e != hipSuccess) {
+        delete ix;
+        return fail("hipMalloc of the %zu-byte vector store failed: %s", bytes, hipGetErrorString(e));
+    }
+    e = hipMemset(ix->data, 0, bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ix->overflow_host, sizeof(unsigned int), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipFree(ix->data);
+        delete ix;
+        return fail("store initialisation failed: %s", hipGetErrorString(e));
+    }
+    *ix->overflow_host = 0;
+    *out = ix;
+    return 0;
+}
+
+int vodhip_index_destroy(vodhip_index_t* ix) {
+    if (!ix) return 0;
+    (void)hipSetDevice(ix->device);
+    free_workspace(ix);
+    for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
+    (void)hipFree(ix->data);
+    (void)hipFree(ix->stage_dev);
+    (void)hipHostFree(ix->overflow_host);
+    delete ix;
+    return 0;
+}
+
+int vodhip_index_add(vodhip_index_t* ix, const void* rows, int64_t n_rows, int src_dtype, int src_location, void* stream_) {
+    if (!ix) return fail("index is NULL");
+    if (n_rows < 0 || (n_rows > 0 && !rows)) return fail("invalid rows");
+    if (src_dtype < 0 || src_dtype > 2) return fail("invalid src_dtype %d", src_dtype);
+    if (ix->ntotal + n_rows > ix->capacity)
+        return fail("index full: ntotal=%lld + %lld > capacity=%lld", (long long)ix->ntotal, (long long)n_rows, (long long)ix->capacity);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_OK(hipSetDevice(ix->device));
+    const int es = elem_size(src_dtype);
+    if (src_location == VODHIP_DEVICE) {
+        HIP_OK(launch_convert_rows(rows, src_dtype, n_rows, ix->dim, ix->data + (size_t)ix->ntotal * ix->dim_pad, ix->dtype,
+                                   ix->dim_pad, stream));
+        ix->ntotal += n_rows;
+        return 0;
+    }
+    if (src_location != VODHIP_HOST) return fail("invalid src_location %d", src_location);
+    if (!ix->stage_dev) HIP_OK(hipMalloc(&ix->stage_dev, STAGE_BYTES));
+    const int64_t rows_per_stage = std::max<int64_t>(1, STAGE_BYTES / (ix->dim * es));
+    for (int64_t r = 0; r < n_rows; r += rows_per_stage) {
+        const int64_t n = std::min(rows_per_stage, n_rows - r);
+        HIP_OK(hipMemcpyAsync(ix->stage_dev, (const char*)rows + (size_t)r * ix->dim * es, (size_t)n * ix->dim * es,
+                              hipMemcpyHostToDevice, stream));
+        HIP_OK(launch_convert_rows(ix->stage_dev, src_dtype, n, ix->dim, ix->data + (size_t)(ix->ntotal + r) * ix->dim_pad,
+                                   ix->dtype, ix->dim_pad, stream));
+        HIP_OK(hipStreamSynchronize(stream));  // the staging buffer is reused by the next slice
+    }
+    ix->ntotal += n_rows;
+    return 0;
+}
+
+int vodhip_index_reset(vodhip_index_t* ix) {
+    if (!ix) return fail("index is NULL");
+    ix->ntotal = 0;
+    return 0;
+}
+
+int vodhip_index_ntotal(const vodhip_index_t* ix, int64_t* out) {
+    if (!ix || !out) return fail("NULL argument");
+    *out = ix->ntotal;
+    return 0;
+}
+int vodhip_index_dim(const vodhip_index_t* ix, int64_t* out) {
+    if (!ix || !out) return fail("NULL argument");
+    *out = ix->dim;
+    return 0;
+}
+int vodhip_index_capacity(const vodhip_index_t* ix, int64_t* out) {
+    if (!ix || !out) return fail("NULL argument");
+    *out = ix->capacity;
+    return 0;
+}
+int vodhip_index_data(const vodhip_index_t* ix, void** dev_ptr, int64_t* row_stride_elems, int* store_dtype) {
+    if (!ix) return fail("index is NULL");
+    if (dev_ptr) *dev_ptr = ix->data;
+    if (row_stride_elems) *row_stride_elems = ix->dim_pad;
+    if (store_dtype) *store_dtype = ix->dtype;
+    return 0;
+}
+
+int vodhip_index_get_rows(const vodhip_index_t* ix, int64_t row_begin, int64_t n_rows, void* dst, int dst_location,
+                          void* stream_) {
+    if (!ix) return fail("index is NULL");
+    if (row_begin < 0 || n_rows < 0 || row_begin + n_rows > ix->ntotal) return fail("row range out of bounds");
+    if (n_rows == 0) return 0;
+    if (!dst) return fail("dst is NULL");
+    HIP_OK(hipSetDevice(ix->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const hipMemcpyKind kind = dst_location == VODHIP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    HIP_OK(hipMemcpy2DAsync(dst, (size_t)ix->dim * 2, ix->data + (size_t)row_begin * ix->dim_pad, (size_t)ix->dim_pad * 2,
+                            (size_t)ix->dim * 2, (size_t)n_rows, kind, stream));
+    if (dst_location != VODHIP_DEVICE) HIP_OK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dtype, int64_t nq, int k, int64_t id_base,
+                              float* out_scores, int64_t* out_ids, void* stream_) {
+    if (!ix) return fail("index is NULL");
+    if (nq < 0 || (nq > 0 && (!queries || !out_scores || !out_ids))) return fail("invalid query / output pointers");
+    if (k < 1 || k > VODHIP_MAX_K) return fail("k=%d out of range [1, %d]", k, VODHIP_MAX_K);
+    if (q_dtype < 0 || q_dtype > 2) return fail("invalid q_dtype %d", q_dtype);
+    if (ix->cand_cap < ROW_ALIGN || ix->cand_cap < k) return fail("cand_cap too small");
+    HIP_OK(hipSetDevice(ix->device));
+    PendingSearch ps;
+    ps.active = true;
+    ps.queries = queries;
+    ps.q_dtype = q_dtype;
+    ps.nq = nq;
+    ps.k = k;
+    ps.id_base = id_base;
+    ps.out_scores = out_scores;
+    ps.out_ids = out_ids;
+    ix->pending = ps;
+    ix->last_overflow = 0;
+    ix->last_safe_reruns = 0;
+    ix->ev_used = 0;
+    if (nq == 0) return 0;
+    return enqueue_search(ix, ps, ix->force_safe != 0, (hipStream_t)stream_);
+}
+
+int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
+    if (!ix) return fail("index is NULL");
+    if (!ix->pending.active) return fail("no search is pending on this index");
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_OK(hipSetDevice(ix->device));
+    if (ix->pending.nq > 0) {
+        HIP_OK(hipStreamSynchronize(stream));
+        if (*ix->overflow_host) {
+            // A candidate list overflowed (scores that keep rising along the row order defeat the
+            // geometric schedule).  Redo the batch with the exhaustive schedule, which cannot overflow.
+            ix->last_overflow = 1;
+            ix->last_safe_reruns = 1;
+            if (enqueue_search(ix, ix->pending, true, stream)) return -1;
+            HIP_OK(hipStreamSynchronize(stream));
+            if (*ix->overflow_host) return fail("internal error: exhaustive schedule overflowed");
+        }
+    }
+    ix->last_filter_launches = (int64_t)(ix->ev_used / 2);
+    ix->last_filter_ns = 0;
+    for (size_t e = 0; e + 1 < ix->ev_used; e += 2) {
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, ix->ev_pool[e], ix->ev_pool[e + 1]));
+        ix->last_filter_ns += (int64_t)((double)ms * 1e6);
+    }
+    ix->pending.active = false;
+    return 0;
+}
+
+int vodhip_index_search(vodhip_index_t* ix, const void* queries, int q_dtype, int64_t nq, int k, int64_t id_base,
+                        float* out_scores, int64_t* out_ids, void* stream) {
+    if (vodhip_index_search_async(ix, queries, q_dtype, nq, k, id_base, out_scores, out_ids, stream)) return -1;
+    return vodhip_index_search_finish(ix, stream);
+}
+
+int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
+    if (!ix || !key) return fail("NULL argument");
+    if (!strcmp(key, "cand_cap")) {
+        if (value < ROW_ALIGN || value > (1 << 15)) return fail("cand_cap must be in [256, 32768]");
+        ix->cand_cap = value;
+    } else if (!strcmp(key, "dense_rows")) {
+        if (value < ROW_ALIGN) return fail("dense_rows must be >= 256");
+        ix->dense_rows = round_up(value, ROW_ALIGN);
+    } else if (!strcmp(key, "growth")) {
+        ix->growth_x100 = value;  // growth factor * 100; 0 = derive from k
+    } else if (!strcmp(key, "force_safe")) {
+        ix->force_safe = value;
+    } else if (!strcmp(key, "profile")) {
+        ix->profile = value;
+    } else if (!strcmp(key, "tile")) {
+        if (value < 0 || value > 2) return fail("tile must be 0 (auto), 1 (128x128) or 2 (256x256)");
+        ix->tile = value;
+    } else {
+        return fail("unknown parameter '%s'", key);
+    }
+    return 0;
+}
+
+int vodhip_index_get_stat(const vodhip_index_t* ix, const char* key, int64_t* out) {
+    if (!ix || !key || !out) return fail("NULL argument");
+    if (!strcmp(key, "last_overflow"))
+        *out = ix->last_overflow;
+    else if (!strcmp(key, "last_chunks"))
+        *out = ix->last_chunks;
+    else if (!strcmp(key, "last_safe_reruns"))
+        *out = ix->last_safe_reruns;
+    else if (!strcmp(key, "last_filter_launches"))
+        *out = ix->last_filter_launches;
+    else if (!strcmp(key, "last_filter_ns"))
+        *out = ix->last_filter_ns;
+    else if (!strcmp(key, "cand_cap"))
+        *out = ix->cand_cap;
+    else if (!strcmp(key, "dense_rows"))
+        *out = ix->dense_rows;
+    else if (!strcmp(key, "dim_pad"))
+        *out = ix->dim_pad;
+    else
+        return fail("unknown stat '%s'", key);
+    return 0;
+}
+
+int vodhip_merge_topk(const float* scores, const int64_t* ids, int n_shards, int64_t nq, int k, int k_out,
+                      float* out_scores, int64_t* out_ids, void* stream) {
+    if (n_shards < 1 || k < 1 || k_out < 1 || nq < 0) return fail("invalid sizes");
+    if ((int64_t)n_shards * k > 8192) return fail("n_shards * k = %lld exceeds 8192", (long long)n_shards * k);
+    if (nq > 0 && (!scores || !ids || !out_scores || !out_ids)) return fail("NULL argument");
+    HIP_OK(launch_merge_topk(scores, ids, n_shards, nq, k, k_out, out_scores, out_ids, (hipStream_t)stream));
+    return 0;
+}
+
+int vodhip_merge_hybrid(const int64_t* lookup_idx, const int64_t* lookup_lbl, int k_lookup, int n_engines,
+                        const int64_t* const* engine_idx, const float* const* engine_scr, const int* engine_k,
+                        const float* engine_weight, int64_t nq, int64_t* out_idx, float* out_scr, int64_t* out_lbl,
+                        float* const* out_raw, int out_stride, int32_t* out_width, void* stream) {
+    if (n_engines < 0 || n_engines > VODHIP_MAX_ENGINES) return fail("n_engines=%d out of range", n_engines);
+    if (k_lookup < 0 || nq < 0) return fail("invalid sizes");
+    HybridArgs a;
+    memset(&a, 0, sizeof(a));
+    a.lookup_idx = lookup_idx;
+    a.lookup_lbl = lookup_lbl;
+    a.k_lookup = k_lookup;
+    a.n_engines = n_engines;
+    int64_t width = k_lookup;
+    for (int e = 0; e < n_engines; ++e) {
+        if (!engine_idx[e] || !engine_scr[e] || engine_k[e] < 0) return fail("engine %d: invalid arguments", e);
+        a.engine_idx[e] = engine_idx[e];
+        a.engine_scr[e] = engine_scr[e];
+        a.engine_k[e] = engine_k[e];
+        a.engine_w[e] = engine_weight[e];
+        a.out_raw[e] = out_raw ? out_raw[e] : nullptr;
+        width += engine_k[e];
+    }
+    if (out_stride < width + 1) return fail("out_stride=%d < %lld", out_stride, (long long)width + 1);
+    if (width > 4096) return fail("total width %lld exceeds 4096", (long long)width);
+    a.nq = nq;
+    a.out_idx = out_idx;
+    a.out_scr = out_scr;
+    a.out_lbl = out_lbl;
+    a.out_stride = out_stride;
+    a.out_width = out_width;
+    if (!out_idx || !out_scr || !out_width) return fail("NULL output");
+    HIP_OK(launch_merge_hybrid(a, (hipStream_t)stream));
+    return 0;
+}
+
+int vodhip_retrieval_forward(const void* q, const void* s, int enc_dtype, int sections_3d, int64_t B, int64_t D, int64_t H,
+                             const float* score, const int64_t* relevance, const float* sparse, const float* dense,
+                             float* retriever_scores, float* d_scores, float* loss, float* kl, float* workspace,
+                             void* stream) {
+    if (!q || !s || !score || !relevance || !retriever_scores || !d_scores || !loss || !kl || !workspace)
+        return fail("NULL argument");
+    if (B <= 0 || D <= 0 || H <= 0) return fail("invalid sizes");
+    if (D > 16384) return fail("D=%lld exceeds 16384 sections per row", (long long)D);
+    if (enc_dtype < 0 || enc_dtype > 2) return fail("invalid enc_dtype");
+    HIP_OK(launch_retrieval_forward(q, s, enc_dtype, sections_3d, B, D, H, score, relevance, sparse, dense,
+                                    retriever_scores, d_scores, loss, kl, workspace, (hipStream_t)stream));
+    return 0;
+}
+
+int vodhip_retrieval_backward(const void* q, const void* s, int enc_dtype, int sections_3d, int64_t B, int64_t D, int64_t H,
+                              const float* d_scores, const float* grad_out, float* dq, float* ds, void* stream) {
+    if (!q || !s || !d_scores || !grad_out || !dq || !ds) return fail("NULL argument");
+    if (B <= 0 || D <= 0 || H <= 0) return fail("invalid sizes");
+    if (enc_dtype < 0 || enc_dtype > 2) return fail("invalid enc_dtype");
+    HIP_OK(launch_retrieval_backward(q, s, enc_dtype, sections_3d, B, D, H, d_scores, grad_out, dq, ds, (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

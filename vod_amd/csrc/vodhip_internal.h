@@ -1,0 +1,71 @@
+// Internal declarations shared by the kernel translation units and the C-ABI layer of libvodhip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vodhip {
+
+// 64-bit order-preserving result key: high 32 bits = monotone image of the fp32 score, low 32 bits =
+// 0xFFFFFFFF - local row id.  Larger key == better hit (higher score; on equal score the smaller id).
+// Key 0 is reserved for "no entry" and sorts below every real key.
+typedef unsigned long long key_t64;
+
+struct SearchWorkspace {
+    uint16_t* q_pad = nullptr;       // [nq_pad][dim_pad] queries rounded to the store dtype, zero padded
+    key_t64* topk = nullptr;         // [nq_pad][kp] running top-k keys, sorted descending
+    key_t64* cand = nullptr;         // [nq_pad][cap] candidate keys appended by the filter kernel
+    unsigned int* cnt = nullptr;     // [nq_pad] candidates appended in the current chunk
+    float* thr_s = nullptr;          // [nq_pad] score of the current k-th best (-inf until k hits exist)
+    key_t64* thr_key = nullptr;      // [nq_pad] key of the current k-th best (0 until k hits exist)
+    unsigned int* overflow = nullptr;  // [1] set when a candidate buffer overflowed
+    int64_t nq_cap = 0;
+    int64_t cap = 0;
+    int64_t kp = 0;
+};
+
+// ---- launchers (kernels_mips.hip) -------------------------------------------------------------
+// store_dtype: 0 = f16, 1 = bf16.  tile: 1 = 128x128 (256 threads), 2 = 256x256 (512 threads).
+hipError_t launch_convert_rows(const void* src, int src_dtype, int64_t n_rows, int64_t dim, void* dst, int dst_dtype,
+                               int64_t dst_stride, hipStream_t stream);
+hipError_t launch_search_init(const SearchWorkspace& ws, int64_t nq_pad, hipStream_t stream);
+hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* store, const void* q_pad, int64_t dim_pad,
+                         int64_t row_begin, int64_t row_end, int64_t nq, int64_t nq_pad, const SearchWorkspace& ws,
+                         hipStream_t stream);
+hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, hipStream_t stream);
+hipError_t launch_output(const SearchWorkspace& ws, int64_t nq, int k, int64_t id_base, float* out_scores,
+                         int64_t* out_ids, hipStream_t stream);
+hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_shards, int64_t nq, int k, int k_out,
+                             float* out_scores, int64_t* out_ids, hipStream_t stream);
+int filter_tile_rows(int tile);  // BM of the tile config
+int filter_tile_cols(int tile);  // BN of the tile config
+
+// ---- launchers (kernels_hybrid.hip) -----------------------------------------------------------
+struct HybridArgs {
+    const int64_t* lookup_idx;
+    const int64_t* lookup_lbl;
+    int k_lookup;
+    int n_engines;
+    const int64_t* engine_idx[4];
+    const float* engine_scr[4];
+    int engine_k[4];
+    float engine_w[4];
+    int64_t nq;
+    int64_t* out_idx;
+    float* out_scr;
+    int64_t* out_lbl;
+    float* out_raw[4];
+    int out_stride;
+    int32_t* out_width;
+};
+hipError_t launch_merge_hybrid(const HybridArgs& a, hipStream_t stream);
+
+// ---- launchers (kernels_retrieval.hip) --------------------------------------------------------
+hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype, int sections_3d, int64_t B, int64_t D,
+                                    int64_t H, const float* score, const int64_t* relevance, const float* sparse,
+                                    const float* dense, float* retriever_scores, float* d_scores, float* loss,
+                                    float* kl, float* workspace, hipStream_t stream);
+hipError_t launch_retrieval_backward(const void* q, const void* s, int enc_dtype, int sections_3d, int64_t B, int64_t D,
+                                     int64_t H, const float* d_scores, const float* grad_out, float* dq, float* ds,
+                                     hipStream_t stream);
+
+}  // namespace vodhip

@@ -1,0 +1,181 @@
+"""HBM-resident corpus vector store + exact inner-product top-k (host wrapper over the C-ABI).
+
+Mirrors what the reference gets from a faiss `IndexFlat` with METRIC_INNER_PRODUCT:
+`index.add(float32 batch)` (/root/reference/src/vod_search/faiss_search/build.py:65-73) and
+`index.search(query_vec, k)` (/root/reference/src/vod_search/faiss_search/server.py:72,84).
+PyTorch is used only to own the query / result buffers and the stream; the store itself is owned by
+libvodhip.so.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from vod_amd import _native
+
+
+class HipFlatIndex:
+    """Exact MIPS index: row-major fp16/bf16 rows in HBM, searched by the fused MFMA + top-k kernels."""
+
+    def __init__(self, dim: int, capacity: int, dtype: torch.dtype = torch.float16, device: int | torch.device = 0):
+        self._lib = _native.load_library()
+        if not torch.cuda.is_available():
+            raise _native.NativeLibraryError("HipFlatIndex needs a ROCm device (torch.cuda.is_available() is False)")
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise TypeError("store dtype must be torch.float16 or torch.bfloat16")
+        self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        self.dim = int(dim)
+        self.capacity = int(capacity)
+        self.dtype = dtype
+        handle = ctypes.c_void_p()
+        _native.check(
+            self._lib.vodhip_index_create(
+                self.device.index or 0, self.dim, _native.torch_dtype_code(dtype), self.capacity, ctypes.byref(handle)
+            )
+        )
+        self._h = handle
+
+    # -- lifecycle ---------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.vodhip_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self) -> "HipFlatIndex":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
+    # -- store -------------------------------------------------------------------------------------
+    @property
+    def ntotal(self) -> int:
+        out = ctypes.c_int64()
+        _native.check(self._lib.vodhip_index_ntotal(self._h, ctypes.byref(out)))
+        return out.value
+
+    def reset(self) -> None:
+        _native.check(self._lib.vodhip_index_reset(self._h))
+
+    def add(self, vectors: np.ndarray | torch.Tensor) -> None:
+        """Append rows (float32/float16 NumPy on the host, or float32/float16/bfloat16 tensors on this device)."""
+        if isinstance(vectors, torch.Tensor) and vectors.is_cuda:
+            if vectors.device != self.device:
+                raise ValueError(f"vectors live on {vectors.device}, the index on {self.device}")
+            v = vectors.contiguous()
+            if v.ndim != 2 or v.shape[1] != self.dim:
+                raise ValueError(f"expected [n, {self.dim}] vectors, got {tuple(v.shape)}")
+            _native.check(
+                self._lib.vodhip_index_add(
+                    self._h, v.data_ptr(), v.shape[0], _native.torch_dtype_code(v.dtype), _native.DEVICE,
+                    _native.current_stream_ptr(self.device),
+                )
+            )
+            torch.cuda.current_stream(self.device).synchronize()  # `v` may be freed by the caller right after
+            return
+        if isinstance(vectors, torch.Tensor):
+            vectors = vectors.numpy() if vectors.dtype != torch.bfloat16 else vectors.float().numpy()
+        v = np.ascontiguousarray(vectors)
+        if v.dtype not in (np.float16, np.float32):
+            v = v.astype(np.float32)
+        if v.ndim != 2 or v.shape[1] != self.dim:
+            raise ValueError(f"expected [n, {self.dim}] vectors, got {v.shape}")
+        with torch.cuda.device(self.device):
+            _native.check(
+                self._lib.vodhip_index_add(
+                    self._h, v.ctypes.data, v.shape[0], _native.numpy_dtype_code(v.dtype), _native.HOST,
+                    _native.current_stream_ptr(self.device),
+                )
+            )
+
+    def stored_rows(self, begin: int = 0, n: int | None = None) -> torch.Tensor:
+        """Copy of the stored (rounded) rows [begin, begin+n) as a device tensor -- tests / persistence."""
+        n = self.ntotal - begin if n is None else int(n)
+        out = torch.empty((n, self.dim), dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(
+                self._lib.vodhip_index_get_rows(self._h, int(begin), n, out.data_ptr(), _native.DEVICE,
+                                                _native.current_stream_ptr(self.device))
+            )
+        return out
+
+    # -- search ------------------------------------------------------------------------------------
+    def set_param(self, key: str, value: int) -> None:
+        _native.check(self._lib.vodhip_index_set_param(self._h, key.encode(), int(value)))
+
+    def get_stat(self, key: str) -> int:
+        out = ctypes.c_int64()
+        _native.check(self._lib.vodhip_index_get_stat(self._h, key.encode(), ctypes.byref(out)))
+        return out.value
+
+    def _prep_queries(self, queries) -> torch.Tensor:
+        if isinstance(queries, np.ndarray):
+            q = np.ascontiguousarray(queries)
+            if q.dtype not in (np.float16, np.float32):
+                q = q.astype(np.float32)
+            queries = torch.from_numpy(q).to(self.device, non_blocking=False)
+        q = queries
+        if q.device != self.device:
+            q = q.to(self.device)
+        if q.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+            q = q.float()
+        q = q.contiguous()
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"expected [nq, {self.dim}] queries, got {tuple(q.shape)}")
+        return q
+
+    def search_async(self, queries, k: int, id_base: int = 0, out: tuple[torch.Tensor, torch.Tensor] | None = None):
+        """Enqueue a search on the current stream; call `finish()` before trusting the outputs."""
+        q = self._prep_queries(queries)
+        nq = q.shape[0]
+        if out is None:
+            scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+            ids = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        else:
+            scores, ids = out
+        self._keep = q  # keep the query buffer alive until finish()
+        _native.check(
+            self._lib.vodhip_index_search_async(
+                self._h, q.data_ptr(), _native.torch_dtype_code(q.dtype), nq, int(k), int(id_base),
+                scores.data_ptr(), ids.data_ptr(), _native.current_stream_ptr(self.device),
+            )
+        )
+        return scores, ids
+
+    def finish(self) -> None:
+        _native.check(self._lib.vodhip_index_search_finish(self._h, _native.current_stream_ptr(self.device)))
+        self._keep = None
+
+    def search(self, queries, k: int, id_base: int = 0, out=None) -> tuple[torch.Tensor, torch.Tensor]:
+        """Exact top-k by inner product: (scores f32 [nq,k] desc, ids i64 [nq,k]); ties -> smaller id; pad -inf/-1."""
+        with torch.cuda.device(self.device):
+            res = self.search_async(queries, k, id_base, out)
+            self.finish()
+        return res
+
+
+def merge_topk(scores: torch.Tensor, ids: torch.Tensor, k_out: int | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """Merge per-shard top-k lists [n_shards, nq, k] (global ids, pads -1) into [nq, k_out] on the GPU."""
+    lib = _native.load_library()
+    if scores.ndim != 3 or ids.shape != scores.shape:
+        raise ValueError("expected scores/ids of shape [n_shards, nq, k]")
+    n_shards, nq, k = scores.shape
+    k_out = k if k_out is None else int(k_out)
+    scores = scores.contiguous().float()
+    ids = ids.contiguous().long()
+    out_s = torch.empty((nq, k_out), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((nq, k_out), dtype=torch.int64, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _native.check(
+            lib.vodhip_merge_topk(scores.data_ptr(), ids.data_ptr(), n_shards, nq, k, k_out, out_s.data_ptr(),
+                                  out_i.data_ptr(), _native.current_stream_ptr(scores.device))
+        )
+    return out_s, out_i
