@@ -98,15 +98,15 @@ def main() -> None:
     out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
     if world > 1:
-        gat_s = torch.empty((world, nq, k), dtype=torch.float32, device=dev)
-        gat_i = torch.empty((world, nq, k), dtype=torch.int64, device=dev)
+        gat_s = torch.empty((world * nq, k), dtype=torch.float32, device=dev)  # rank-major concatenation
+        gat_i = torch.empty((world * nq, k), dtype=torch.int64, device=dev)
 
     def step():
         index.search(queries, k, id_base=row_lo, out=(out_s, out_i))
         if world > 1:
             dist.all_gather_into_tensor(gat_s, out_s)
             dist.all_gather_into_tensor(gat_i, out_i)
-            return merge_topk(gat_s, gat_i)
+            return merge_topk(gat_s.view(world, nq, k), gat_i.view(world, nq, k))
         return out_s, out_i
 
     def fence():
@@ -153,11 +153,11 @@ def main() -> None:
             pad_i = torch.full((len(sample), k), -1, dtype=torch.int64, device=dev)
             pad_s[:, : ls.shape[1]] = ls
             pad_i[:, : li.shape[1]] = li
-            as_ = torch.empty((world,) + pad_s.shape, device=dev)
-            ai_ = torch.empty((world,) + pad_i.shape, dtype=torch.int64, device=dev)
+            as_ = torch.empty((world * len(sample), k), device=dev)
+            ai_ = torch.empty((world * len(sample), k), dtype=torch.int64, device=dev)
             dist.all_gather_into_tensor(as_, pad_s)
             dist.all_gather_into_tensor(ai_, pad_i)
-            ls, li = merge_topk(as_, ai_)
+            ls, li = merge_topk(as_.view(world, len(sample), k), ai_.view(world, len(sample), k))
         got_i = fi[sample].cpu()
         ref_i = li.cpu()
         hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got_i, ref_i))

@@ -1,0 +1,99 @@
+"""GPU parity tests for the fused in-batch retrieval loss (H5), through the C-ABI.
+
+Floating point: tolerance rtol 2e-4 / atol 2e-5 against the golden vectors (reference ran fp32 torch on CPU)
+and against the fp64 oracle; the contraction is an fp32 dot product in a different summation order."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=2e-4, atol=2e-5)
+NAMES = ["retrieval_grad_2d", "retrieval_grad_3d", "retrieval_grad_nopos", "retrieval_grad_padded", "retrieval_grad_inbatch"]
+
+
+def _run(q, s, score, rel, sparse, dense, dtype=torch.float32, upstream=1.0):
+    from vod_amd.gradients import RetrievalGradients
+
+    qt = torch.tensor(q, device="cuda", dtype=dtype, requires_grad=True)
+    st = torch.tensor(s, device="cuda", dtype=dtype, requires_grad=True)
+    batch = {
+        "section__score": torch.tensor(score, device="cuda"),
+        "section__relevance": torch.tensor(rel, device="cuda"),
+        "section__sparse": None if sparse is None else torch.tensor(sparse, device="cuda"),
+        "section__dense": None if dense is None else torch.tensor(dense, device="cuda"),
+    }
+    out = RetrievalGradients()(batch=batch, query_encoding=qt, section_encoding=st)
+    (out.loss * upstream).backward()
+    return out, qt.grad, st.grad
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_matches_reference_golden(name):
+    g = np.load(GOLDEN / f"{name}.npz")
+    out, dq, ds = _run(g["q"], g["s"], g["score"], g["relevance"], g["sparse"], g["dense"])
+    np.testing.assert_allclose(out.loss.item(), g["loss"], **TOL)
+    np.testing.assert_allclose(out.retriever_scores.cpu().numpy(), g["retriever_scores"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(dq.cpu().numpy(), g["dq"], **TOL)
+    np.testing.assert_allclose(ds.cpu().numpy(), g["ds"], **TOL)
+    for k in ("kl_score", "kl_sparse", "kl_dense"):
+        np.testing.assert_allclose(out.diagnostics[k].item(), g[k], **TOL)
+    assert out.retriever_scores.requires_grad is False and out.loss.dtype == torch.float32
+
+
+@pytest.mark.parametrize("three_d", [False, True])
+@pytest.mark.parametrize("B,D,H", [(64, 32, 768), (64, 2048, 768), (3, 5, 17), (16, 300, 1024)])
+def test_matches_fp64_oracle(B, D, H, three_d):
+    from oracle.gradients import retrieval_gradients
+
+    if three_d and D > 512:
+        pytest.skip("3-D section encodings are per-query sets (D = n_sections), never the flattened in-batch set")
+    rng = np.random.default_rng(B + D + H)
+    q = (rng.normal(size=(B, H)) / np.sqrt(H) * 3).astype(np.float32)
+    s = rng.normal(size=((B, D, H) if three_d else (D, H))).astype(np.float32)
+    score = rng.normal(size=(B, D)).astype(np.float32)
+    pad = rng.uniform(size=(B, D)) < 0.1
+    pad[:, 0] = False
+    score[pad] = -np.inf
+    rel = (rng.uniform(size=(B, D)) < 0.05).astype(np.int64)
+    rel[:, 0] = 1
+    rel[B // 2] = 0  # a row without positives -> n_positives falls back to the non-pad count
+    sparse = rng.normal(size=(B, D)).astype(np.float32)
+    sparse[rng.uniform(size=(B, D)) < 0.2] = np.nan
+    out, dq, ds = _run(q, s, score, rel, sparse, None, upstream=2.5)
+    ref = retrieval_gradients(q, s, score, rel, sparse, None)
+    np.testing.assert_allclose(out.loss.item(), ref["loss"], **TOL)
+    np.testing.assert_allclose(out.retriever_scores.cpu().numpy(), ref["retriever_scores"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(dq.cpu().numpy(), 2.5 * ref["dq"], **TOL)
+    np.testing.assert_allclose(ds.cpu().numpy(), 2.5 * ref["ds"], **TOL)
+    np.testing.assert_allclose(out.diagnostics["kl_score"].item(), ref["kl_score"], **TOL)
+    np.testing.assert_allclose(out.diagnostics["kl_sparse"].item(), ref["kl_sparse"], **TOL)
+    assert "kl_dense" not in out.diagnostics
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_half_precision_encodings(dtype):
+    from oracle.gradients import retrieval_gradients
+
+    rng = np.random.default_rng(3)
+    B, D, H = 8, 64, 256
+    q = torch.tensor(rng.normal(size=(B, H)) / np.sqrt(H) * 3).to(dtype)
+    s = torch.tensor(rng.normal(size=(D, H))).to(dtype)
+    score = rng.normal(size=(B, D)).astype(np.float32)
+    rel = (rng.uniform(size=(B, D)) < 0.2).astype(np.int64)
+    rel[:, 0] = 1
+    out, dq, ds = _run(q.float().numpy(), s.float().numpy(), score, rel, None, None, dtype=dtype)
+    ref = retrieval_gradients(q.float().numpy(), s.float().numpy(), score, rel)  # oracle on the rounded inputs
+    np.testing.assert_allclose(out.loss.item(), ref["loss"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(dq.float().cpu().numpy(), ref["dq"], rtol=2e-2, atol=2e-3)  # grads are cast back to 16 bit
+    np.testing.assert_allclose(ds.float().cpu().numpy(), ref["ds"], rtol=2e-2, atol=2e-3)
+    assert dq.dtype == dtype and ds.dtype == dtype
+
+
+def test_auxiliary_losses_are_rejected():
+    from vod_amd.gradients import RetrievalGradients
+
+    with pytest.raises(NotImplementedError):
+        RetrievalGradients(guidance_weight=0.1)

@@ -1,0 +1,234 @@
+"""CPU tests: host-side mirror of the reference interface (containers, codec, routing, server contract),
+and the C-ABI library's exported symbols.  No compute call touches a GPU here."""
+import json
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+from vod_amd import io as vio
+from vod_amd import types as vt
+from vod_amd.search import base, client as vclient, sharded
+
+
+def _load(name):
+    return np.load(GOLDEN / f"{name}.npz")
+
+
+# ---- C-ABI ------------------------------------------------------------------------------------------
+def test_library_loads_and_exports_every_declared_symbol():
+    from vod_amd import _native
+    from vod_amd.build import build_native
+
+    build_native()
+    lib = _native.load_library()
+    header = (ROOT / "include" / "vodhip.h").read_text()
+    declared = set(re.findall(r"\b(vodhip_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/vodhip.h but not exported"
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    assert lib.vodhip_version() == 1
+
+
+def test_native_errors_are_reported_not_swallowed():
+    import ctypes
+
+    from vod_amd import _native
+
+    lib = _native.load_library()
+    out = ctypes.c_int64()
+    assert lib.vodhip_index_ntotal(None, ctypes.byref(out)) != 0
+    with pytest.raises(_native.NativeLibraryError, match="NULL"):
+        _native.check(lib.vodhip_index_ntotal(None, ctypes.byref(out)))
+
+
+def test_product_has_no_cpu_fallback_and_never_imports_the_oracle():
+    for path in (ROOT / "vod_amd").rglob("*.py"):
+        text = path.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{path} imports the oracle"
+    import torch
+
+    if not torch.cuda.is_available():
+        from vod_amd import _native
+        from vod_amd.index import HipFlatIndex
+
+        with pytest.raises(_native.NativeLibraryError):
+            HipFlatIndex(8, 8)
+
+
+# ---- containers -------------------------------------------------------------------------------------
+def test_stack_samples_matches_reference_padding():
+    g = _load("stack_samples_ragged")
+    rows = [
+        vt.RetrievalSample(scores=g["r0_s"], indices=g["r0_i"]),
+        vt.RetrievalSample(scores=g["r1_s"], indices=g["r1_i"]),
+        vt.RetrievalSample(scores=np.array([], dtype=np.float32), indices=np.array([], dtype=np.int64)),
+    ]
+    out = vt.RetrievalBatch.stack_samples(rows)
+    np.testing.assert_array_equal(out.scores, g["out_scr"])
+    np.testing.assert_array_equal(out.indices, g["out_idx"])
+    assert out.scores.dtype == np.float32 and out.indices.dtype == np.int64
+
+
+def test_retrieval_batch_contract():
+    b = vt.RetrievalBatch.cast(scores=[[1.0, 3.0], [2.0, -np.inf]], indices=[[5, 6], [7, -1]])
+    assert b.shape == (2, 2) and len(b) == 2
+    assert isinstance(b[0], vt.RetrievalSample) and isinstance(b[0][1], vt.RetrievalTuple)
+    s = b.sorted()
+    assert s.indices.tolist() == [[6, 5], [7, -1]]
+    w = b * 0.0
+    assert np.isnan(w.scores[1, 1]) and w.scores[0, 0] == 0.0  # 0 * -inf -> NaN (reference quirk Q5)
+    both = b + b
+    assert both.shape == (4, 2)
+    with pytest.raises(ValueError):
+        vt.RetrievalBatch(scores=np.zeros((2, 2)), indices=np.zeros((2, 3), dtype=np.int64))
+    with pytest.raises(ValueError):
+        vt.RetrievalBatch(scores=np.zeros((2,)), indices=np.zeros((2,), dtype=np.int64))
+    with pytest.raises(TypeError):
+        b * "x"  # noqa: B018
+    assert b.to_dict()["indices"] == [[5, 6], [7, -1]]
+
+
+# ---- wire codec -------------------------------------------------------------------------------------
+def test_codec_is_string_identical_to_the_reference():
+    g = _load("io_codec")
+    strings = json.loads((GOLDEN / "io_codec.json").read_text())
+    for key in ("f32", "i64", "f16"):
+        assert vio.serialize_np_array(g[key]) == strings[key]
+        back = vio.deserialize_np_array(strings[key])
+        np.testing.assert_array_equal(back, g[key])
+        assert back.dtype == g[key].dtype
+
+
+def test_codec_refuses_pickled_payloads():
+    import base64
+    import io
+
+    buf = io.BytesIO()
+    np.save(buf, np.array([{"a": 1}], dtype=object), allow_pickle=True)
+    with pytest.raises(ValueError):
+        vio.deserialize_np_array(base64.urlsafe_b64encode(buf.getvalue()).decode())
+
+
+# ---- logical shard routing --------------------------------------------------------------------------
+class _TableClient(base.SearchClient):
+    def __init__(self, scr, idx):
+        self.scr, self.idx = scr, idx
+
+    def ping(self):
+        return True
+
+    def search(self, *, text, vector=None, subset_ids=None, ids=None, shard=None, top_k=3):  # noqa: ARG002
+        n = len(text)
+        return vt.RetrievalBatch(scores=self.scr[:n, :top_k].copy(), indices=self.idx[:n, :top_k].copy())
+
+
+def test_sharded_scatter_gather_matches_reference_except_pad_offset_quirk():
+    g = _load("shard_scatter_gather")
+    p = json.loads((GOLDEN / "manifest.json").read_text())["shard_scatter_gather"]["params"]
+    c = sharded.ShardedSearchClient(
+        shards={"a": _TableClient(g["a_scr"], g["a_idx"]), "b": _TableClient(g["b_scr"], g["b_idx"])}, offsets=p["offsets"]
+    )
+    out = c.search(text=[""] * 5, vector=np.zeros((5, 4), dtype=np.float32), shard=p["shard"], top_k=p["top_k"])
+    np.testing.assert_array_equal(out.scores, g["out_scr"])
+    ref = g["out_idx"]
+    pad = np.isneginf(g["out_scr"])
+    np.testing.assert_array_equal(out.indices[~pad], ref[~pad])
+    assert np.all(out.indices[pad] == -1)        # ours: pads stay -1
+    assert set(ref[pad].tolist()) <= {-1, 99}    # reference: pad of shard "b" became offset-1 (quirk Q1)
+    import asyncio
+
+    out2 = asyncio.run(c.async_search(text=[""] * 5, vector=np.zeros((5, 4), dtype=np.float32), shard=p["shard"], top_k=p["top_k"]))
+    np.testing.assert_array_equal(out2.indices, out.indices)
+    with pytest.raises(ValueError):
+        c.search(text=[""], shard=None)
+    with pytest.raises(ValueError):
+        c.search(text=[""], shard=["nope"])
+
+
+# ---- master / client --------------------------------------------------------------------------------
+def test_master_refuses_pickling_and_client_is_picklable(tmp_path):
+    m = vclient.HipMipsMaster(tmp_path / "v.npy", port=12345, skip_setup=True)
+    with pytest.raises(base.DoNotPickleError):
+        pickle.dumps(m)
+    c = pickle.loads(pickle.dumps(m.get_client()))
+    assert c.url == "http://localhost:12345" and c.requires_vectors
+    assert m.service_name == "hip_mips_master-12345"
+    with m as mm:  # skip_setup: no server is spawned
+        assert mm._server_proc is None
+    assert vclient.HipMipsMaster(tmp_path / "v.npy", port=-1, skip_setup=True).port > 0
+    cmd = m._make_cmd()
+    assert "-m" in cmd and "vod_amd.search.server" in cmd and "--vectors-path" in cmd
+
+
+def test_client_ping_false_when_no_server():
+    from vod_amd.search.socket import find_available_port
+
+    assert vclient.HipMipsClient(port=find_available_port()).ping() is False
+
+
+# ---- server contract, with a test double engine (the oracle) -----------------------------------------
+class _OracleEngine:
+    def __init__(self, x):
+        self.x = x
+
+    @property
+    def ntotal(self):
+        return len(self.x)
+
+    def search(self, q, k):
+        from oracle.flat_ip import flat_ip_topk
+
+        if q.shape[1] != self.x.shape[1]:
+            raise ValueError("dimension mismatch")
+        return flat_ip_topk(q, self.x, k)
+
+
+def test_server_routes_and_wire_format():
+    from fastapi.testclient import TestClient
+
+    from vod_amd.search.server import create_app
+
+    rng = np.random.default_rng(0)
+    x = rng.integers(-4, 5, size=(50, 8)).astype(np.float32)
+    q = rng.integers(-4, 5, size=(3, 8)).astype(np.float32)
+    http = TestClient(create_app(_OracleEngine(x)))
+    assert "OK" in http.get("/").text
+    assert "ERROR" in TestClient(create_app(_OracleEngine(x[:0]))).get("/").text  # empty index is not healthy (Q12)
+    r = http.post("/fast-search", json={"vectors": vio.serialize_np_array(q), "top_k": 60})
+    assert r.status_code == 200
+    scores = vio.deserialize_np_array(r.json()["scores"])
+    ids = vio.deserialize_np_array(r.json()["indices"])
+    assert scores.dtype == np.float32 and ids.dtype == np.int64 and scores.shape == (3, 60)
+    assert np.all(ids[:, 50:] == -1) and np.all(np.isneginf(scores[:, 50:]))
+    r2 = http.post("/search", json={"vectors": q.tolist(), "top_k": 5})
+    assert r2.status_code == 200 and np.array(r2.json()["indices"]).tolist() == ids[:, :5].tolist()
+    # contract errors
+    assert http.post("/fast-search", json={"vectors": vio.serialize_np_array(q), "top_k": 3, "extra": 1}).status_code == 422
+    bad = http.post("/fast-search", json={"vectors": vio.serialize_np_array(q[0]), "top_k": 3})
+    assert bad.status_code == 500 and "Expected 2D array" in bad.json()["detail"]
+    assert http.post("/fast-search", json={"vectors": vio.serialize_np_array(q[:, :4]), "top_k": 3}).status_code == 500
+
+
+def test_store_roundtrip_and_factory_protocol(tmp_path):
+    from vod_amd import factory, store
+
+    x = np.random.default_rng(1).normal(size=(1000, 16)).astype(np.float32)
+    p = store.save_vectors(tmp_path / "v.npy", x, dtype=np.float16, chunk=300)
+    back = store.open_vectors(p)
+    np.testing.assert_array_equal(np.asarray(back), x.astype(np.float16))
+    assert store.fingerprint_vectors(x) == store.fingerprint_vectors(x.copy())
+    assert store.fingerprint_vectors(x) != store.fingerprint_vectors(x + 1)
+    calls = []
+    m0 = factory.build_hip_mips_index(x, config={"port": 23456}, cache_dir=tmp_path, barrier_fn=calls.append, skip_setup=False)
+    m1 = factory.build_hip_mips_index(x, config={"port": 23456}, cache_dir=tmp_path, barrier_fn=calls.append, skip_setup=True)
+    assert m0.vectors_path == m1.vectors_path and m0.vectors_path.exists() and len(calls) == 2
+    assert m1.skip_setup and m0.get_client().url == m1.get_client().url
+    with pytest.raises(FileNotFoundError):
+        factory.build_hip_mips_index(x + 2, config={"port": 23456}, cache_dir=tmp_path / "other", skip_setup=True)
+    with pytest.raises(ValueError):
+        factory.build_hip_mips_index(x, config={"factory": "IVF100,Flat"}, cache_dir=tmp_path)

@@ -1,0 +1,44 @@
+"""End to end on the GPU box: HipMipsMaster spawns the real server process (owner of the GPU index), the
+picklable HTTP client queries it -- the counterpart of /root/reference/examples/search/faiss.py
+(config 1: 100k x 384 fp32 vectors, batch 32, top-10) -- and the result must equal the CPU oracle."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def test_master_client_roundtrip_config1(tmp_path, monkeypatch):
+    from oracle.flat_ip import flat_ip_topk
+    from vod_amd import factory
+    from vod_amd.search import ShardedSearchMaster
+
+    monkeypatch.chdir(tmp_path)  # the master writes <service>-<port>.std{out,err}.log into the cwd
+    rng = np.random.default_rng(0)
+    n, d, nq, k = 100_000, 384, 32, 10
+    x = rng.integers(-8, 9, size=(n, d)).astype(np.float32)
+    q = rng.integers(-8, 9, size=(nq, d)).astype(np.float32)
+    master = factory.build_hip_mips_index(x, config={"port": -1, "logging_level": "warning"}, cache_dir=tmp_path)
+    sharded = ShardedSearchMaster(shards={"corpus": master}, offsets={"corpus": 1000})
+    with sharded:
+        client = pickle.loads(pickle.dumps(sharded.get_client()))  # what a DataLoader worker receives
+        assert client.ping()
+        res = client.search(text=[""] * nq, vector=q, shard=["corpus"] * nq, top_k=k)
+        rs, ri = flat_ip_topk(q, x, k, id_base=1000)
+        np.testing.assert_array_equal(res.indices, ri)
+        np.testing.assert_array_equal(res.scores, rs)
+        assert res.scores.dtype == np.float32 and res.indices.dtype == np.int64
+        direct = master.get_client()
+        r2 = direct.search(vector=q[:3], top_k=5)
+        assert r2.meta["time"] > 0 and r2.indices.shape == (3, 5)
+        r3 = direct.search_py(q[:3], top_k=5)
+        np.testing.assert_array_equal(r3.indices, r2.indices)
+        import requests
+
+        with pytest.raises(requests.exceptions.HTTPError):
+            direct.search(vector=q[0], top_k=5)  # 1-D query -> HTTP 500 with the trace in `detail`
+    assert not master.get_client().ping()  # server terminated on exit
+    assert os.path.exists(f"{master.service_name}.stderr.log")

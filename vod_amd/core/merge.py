@@ -1,0 +1,94 @@
+"""Hybrid score merge on the GPU (host wrapper over `vodhip_merge_hybrid`).
+
+Replaces the numba path `_merge_search_results` -> `normalize_search_scores_` -> `merge_search_results`
+-> `gather_values_by_indices` (/root/reference/src/vod_dataloaders/core/search.py:79-125,
+normalize.py:6-20, merge.py:8-164, numpy_ops.py:24-143) with one kernel launch; output layout is the
+reference's, bit for bit: ids in first-seen order (lookup, then each engine), scores
+`sum_e w_e * (s_e - rowmin_e)` in float32, one trailing pad column, labels from the lookup (-1 when
+absent), raw per-engine scores min-subtracted with NaN for "not returned by this engine".
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from vod_amd import _native
+
+
+def merge_hybrid_tensors(
+    lookup_idx: torch.Tensor,
+    lookup_lbl: torch.Tensor | None,
+    engines: dict[str, tuple[torch.Tensor, torch.Tensor]],
+    weights: dict[str, float],
+) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None, dict[str, torch.Tensor]]:
+    """Device-tensor API.  lookup_idx int64 [nq, kl]; engines[name] = (idx int64 [nq, k], scores f32 [nq, k]).
+
+    Returns (indices, scores, labels, raw_scores) already cut to the reference's width.
+    """
+    lib = _native.load_library()
+    dev = lookup_idx.device
+    if dev.type != "cuda":
+        raise _native.NativeLibraryError("merge_hybrid_tensors needs device tensors (there is no CPU path)")
+    names = list(engines)
+    if len(names) > _native.MAX_ENGINES:
+        raise ValueError(f"at most {_native.MAX_ENGINES} scored engines are supported, got {len(names)}")
+    nq, kl = lookup_idx.shape
+    lookup_idx = lookup_idx.contiguous().long()
+    if lookup_lbl is not None:
+        lookup_lbl = lookup_lbl.contiguous().long()
+    e_idx = [engines[n][0].contiguous().long() for n in names]
+    e_scr = [engines[n][1].contiguous().float() for n in names]
+    for n, i, s in zip(names, e_idx, e_scr):
+        if i.shape != s.shape or i.shape[0] != nq:
+            raise ValueError(f"engine `{n}`: indices {tuple(i.shape)} / scores {tuple(s.shape)} do not match nq={nq}")
+    ks = [int(i.shape[1]) for i in e_idx]
+    stride = kl + sum(ks) + 1
+    out_idx = torch.empty((nq, stride), dtype=torch.int64, device=dev)
+    out_scr = torch.empty((nq, stride), dtype=torch.float32, device=dev)
+    out_lbl = torch.empty((nq, stride), dtype=torch.int64, device=dev) if lookup_lbl is not None else None
+    out_raw = [torch.empty((nq, stride), dtype=torch.float32, device=dev) for _ in names]
+    width = torch.zeros((1,), dtype=torch.int32, device=dev)
+
+    n_e = len(names)
+    VP = ctypes.c_void_p
+    arr_idx = (VP * max(n_e, 1))(*[t.data_ptr() for t in e_idx])
+    arr_scr = (VP * max(n_e, 1))(*[t.data_ptr() for t in e_scr])
+    arr_raw = (VP * max(n_e, 1))(*[t.data_ptr() for t in out_raw])
+    arr_k = (ctypes.c_int * max(n_e, 1))(*ks)
+    arr_w = (ctypes.c_float * max(n_e, 1))(*[float(weights[n]) for n in names])
+    with torch.cuda.device(dev):
+        _native.check(
+            lib.vodhip_merge_hybrid(
+                lookup_idx.data_ptr(), lookup_lbl.data_ptr() if lookup_lbl is not None else None, kl, n_e,
+                arr_idx, arr_scr, arr_k, arr_w, nq,
+                out_idx.data_ptr(), out_scr.data_ptr(), out_lbl.data_ptr() if out_lbl is not None else None,
+                arr_raw, stride, width.data_ptr(), _native.current_stream_ptr(dev),
+            )
+        )
+    w = int(width.item()) if nq else 1
+    w = max(w, 1)
+    raw = {n: t[:, :w] for n, t in zip(names, out_raw)}
+    return out_idx[:, :w], out_scr[:, :w], (out_lbl[:, :w] if out_lbl is not None else None), raw
+
+
+def merge_hybrid(
+    lookup_idx: np.ndarray,
+    lookup_lbl: np.ndarray | None,
+    engines: dict[str, tuple[np.ndarray, np.ndarray]],
+    weights: dict[str, float],
+    device: int | torch.device = 0,
+) -> tuple[np.ndarray, np.ndarray, np.ndarray | None, dict[str, np.ndarray]]:
+    """NumPy API (what the collate sees): copies the small inputs to the GPU, merges, copies back."""
+    dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    lbl_dtype = None if lookup_lbl is None else lookup_lbl.dtype
+    idx, scr, lbl, raw = merge_hybrid_tensors(
+        t(lookup_idx.astype(np.int64, copy=False)),
+        None if lookup_lbl is None else t(lookup_lbl.astype(np.int64)),
+        {n: (t(i.astype(np.int64, copy=False)), t(s.astype(np.float32, copy=False))) for n, (i, s) in engines.items()},
+        weights,
+    )
+    out_lbl = None if lbl is None else lbl.cpu().numpy().astype(lbl_dtype, copy=False)
+    return idx.cpu().numpy(), scr.cpu().numpy(), out_lbl, {n: r.cpu().numpy() for n, r in raw.items()}

@@ -1,0 +1,72 @@
+"""`build_hip_mips_index`: counterpart of `vod_search.factory.build_faiss_index`
+(/root/reference/src/vod_search/factory.py:131-190).
+
+Same protocol: the store is content-addressed under `<cache_dir>/indices/<fingerprint>.npy`; only the
+process with `skip_setup=False` (rank 0) writes it, every rank then passes `barrier_fn` and gets a
+master bound to the same host/port (non-zero ranks construct it with `skip_setup=True` and only call
+`get_client()`, src/vod_ops/workflows/train.py:67).
+"""
+from __future__ import annotations
+
+import dataclasses
+import pathlib
+import typing as typ
+
+import numpy as np
+
+from vod_amd import store
+from vod_amd.search.client import HipMipsMaster
+
+
+@dataclasses.dataclass(frozen=True)
+class HipMipsFactoryConfig:
+    """The few fields of the reference's `FaissFactoryConfig` (src/vod_configs/search.py:124-154) this path needs."""
+
+    factory: str = "Flat"           # only the exact index exists here
+    metric: str = "inner_product"   # src/vod_configs/search.py:130
+    dtype: str = "float16"          # HBM storage type (float16 | bfloat16)
+    host: str = "http://localhost"
+    port: int = -1                  # < 0: pick a free port
+    logging_level: str = "CRITICAL"
+    device: int = 0
+
+    def fingerprint(self) -> dict:
+        return {"factory": self.factory, "metric": self.metric, "dtype": self.dtype}
+
+
+def build_hip_mips_index(
+    vectors: typ.Sequence[np.ndarray],
+    *,
+    config: HipMipsFactoryConfig | dict | None = None,
+    cache_dir: str | pathlib.Path,
+    skip_setup: bool = False,
+    barrier_fn: None | typ.Callable[[str], None] = None,
+    free_resources: bool = False,
+) -> HipMipsMaster:
+    if config is None:
+        config = HipMipsFactoryConfig()
+    elif isinstance(config, dict):
+        config = HipMipsFactoryConfig(**config)
+    if config.factory != "Flat" or config.metric != "inner_product":
+        raise ValueError("the HIP MIPS engine is an exact inner-product index (factory='Flat', metric='inner_product')")
+    fp = store.fingerprint_vectors(vectors, config.fingerprint())
+    path = pathlib.Path(cache_dir, "indices", f"{fp}.npy")
+    path.parent.mkdir(parents=True, exist_ok=True)
+    if not skip_setup and not path.exists():
+        tmp = path.with_suffix(".tmp.npy")
+        store.save_vectors(tmp, vectors, dtype=np.float16 if config.dtype == "float16" else np.float32)
+        tmp.rename(path)
+    if barrier_fn is not None:
+        barrier_fn(f"hip mips store: `{path.name}`")
+    if not path.exists():
+        raise FileNotFoundError(f"Could not find the vector store at `{path}`.")
+    return HipMipsMaster(
+        vectors_path=path,
+        logging_level=config.logging_level,
+        host=config.host,
+        port=config.port,
+        skip_setup=skip_setup,
+        free_resources=free_resources,
+        dtype=config.dtype,
+        device=config.device,
+    )

@@ -1,0 +1,115 @@
+"""In-batch retrieval scoring + loss on the GPU (host wrapper over `vodhip_retrieval_forward/backward`).
+
+Mirror of `RetrievalGradients` (/root/reference/src/vod_models/vod_gradients/retrieval.py:14-92): same
+constructor, same keyword-only call `(batch, query_encoding, section_encoding)`, same outputs (`loss`,
+`retriever_scores`, `diagnostics` with kl_score / kl_sparse / kl_dense).  The ~15 torch kernels of the
+reference's forward (einsum, masked_fill, log_softmax, targets, loss, three KLs) and the autograd backward
+become one fused forward launch (+ finalize) and two backward launches, wrapped in a
+`torch.autograd.Function` so `loss.backward()` keeps working.  Auxiliary losses (guidance,
+self-supervision, score decay; all weight 0 in the shipped config) are not implemented: a non-zero weight
+raises.
+"""
+from __future__ import annotations
+
+import dataclasses
+import typing as typ
+
+import torch
+
+from vod_amd import _native
+
+
+@dataclasses.dataclass
+class RealmOutput:
+    """`loss`, `retriever_scores [B, D]`, `diagnostics` -- fields of the reference's RealmOutput (vod_types/batch.py:106-114)."""
+
+    loss: torch.Tensor
+    retriever_scores: torch.Tensor
+    diagnostics: dict[str, typ.Any] = dataclasses.field(default_factory=dict)
+
+
+class _RetrievalLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, s, score, relevance, sparse, dense):  # noqa: ANN001
+        lib = _native.load_library()
+        if not q.is_cuda:
+            raise _native.NativeLibraryError("RetrievalGradients needs device tensors (there is no CPU path)")
+        enc = q.dtype if q.dtype in (torch.float16, torch.bfloat16, torch.float32) else torch.float32
+        qc = q.detach().to(enc).contiguous()
+        sc = s.detach().to(enc).contiguous()
+        three_d = sc.dim() == 3
+        if sc.dim() not in (2, 3):
+            raise ValueError(f"Invalid dimension for `section_encoding`: {tuple(sc.shape)}")
+        B, H = qc.shape
+        D = sc.shape[1] if three_d else sc.shape[0]
+        score_c = score.detach().float().contiguous()
+        rel_c = relevance.detach().long().contiguous()
+        if score_c.shape != (B, D) or rel_c.shape != (B, D):
+            raise ValueError(f"section__score / section__relevance must be [{B}, {D}]")
+        sparse_c = None if sparse is None else sparse.detach().float().contiguous()
+        dense_c = None if dense is None else dense.detach().float().contiguous()
+        dev = q.device
+        scores = torch.empty((B, D), dtype=torch.float32, device=dev)
+        d_scores = torch.empty((B, D), dtype=torch.float32, device=dev)
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        kl = torch.empty((3,), dtype=torch.float32, device=dev)
+        work = torch.empty((8 * B,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _native.check(
+                lib.vodhip_retrieval_forward(
+                    qc.data_ptr(), sc.data_ptr(), _native.torch_dtype_code(enc), int(three_d), B, D, H,
+                    score_c.data_ptr(), rel_c.data_ptr(),
+                    None if sparse_c is None else sparse_c.data_ptr(), None if dense_c is None else dense_c.data_ptr(),
+                    scores.data_ptr(), d_scores.data_ptr(), loss.data_ptr(), kl.data_ptr(), work.data_ptr(),
+                    _native.current_stream_ptr(dev),
+                )
+            )
+        ctx.save_for_backward(qc, sc, d_scores)
+        ctx.meta = (enc, three_d, B, D, H, q.dtype, s.dtype)
+        ctx.mark_non_differentiable(scores, kl)
+        return loss.reshape(()), scores, kl
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_scores, _g_kl):  # noqa: ANN001
+        lib = _native.load_library()
+        qc, sc, d_scores = ctx.saved_tensors
+        enc, three_d, B, D, H, q_dt, s_dt = ctx.meta
+        dev = qc.device
+        go = g_loss.detach().float().reshape(1).contiguous()
+        dq = torch.empty((B, H), dtype=torch.float32, device=dev)
+        ds = torch.empty(tuple(sc.shape), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _native.check(
+                lib.vodhip_retrieval_backward(
+                    qc.data_ptr(), sc.data_ptr(), _native.torch_dtype_code(enc), int(three_d), B, D, H,
+                    d_scores.data_ptr(), go.data_ptr(), dq.data_ptr(), ds.data_ptr(), _native.current_stream_ptr(dev),
+                )
+            )
+        return dq.to(q_dt), ds.to(s_dt), None, None, None, None
+
+
+class RetrievalGradients:
+    """KL-style retrieval objective with in-batch scoring, fused on the GPU."""
+
+    def __init__(self, guidance: str = "zero", guidance_weight: float = 0.0, self_supervision_weight: float = 0.0,
+                 score_decay: float = 0.0):
+        if guidance_weight > 0 or self_supervision_weight > 0 or score_decay > 0:
+            raise NotImplementedError("auxiliary losses (guidance / self-supervision / score decay) are outside the fused path")
+        self.guidance = guidance
+        self.guidance_weight = guidance_weight
+        self.self_supervision_weight = self_supervision_weight
+        self.score_decay = score_decay
+
+    def __call__(self, *, batch: typ.Any, query_encoding: torch.Tensor, section_encoding: torch.Tensor,
+                 lm_logits: None | torch.Tensor = None) -> RealmOutput:  # noqa: ARG002
+        get = (lambda k: batch.get(k)) if isinstance(batch, dict) else (lambda k: getattr(batch, k, None))
+        loss, scores, kl = _RetrievalLoss.apply(
+            query_encoding, section_encoding, get("section__score"), get("section__relevance"),
+            get("section__sparse"), get("section__dense"),
+        )
+        diagnostics = {"kl_score": kl[0]}
+        if get("section__sparse") is not None:
+            diagnostics["kl_sparse"] = kl[1]
+        if get("section__dense") is not None:
+            diagnostics["kl_dense"] = kl[2]
+        return RealmOutput(loss=loss, retriever_scores=scores, diagnostics=diagnostics)

@@ -1,0 +1,156 @@
+"""`HipMipsClient` / `HipMipsMaster`: drop-in for `FaissClient` / `FaissMaster`
+(/root/reference/src/vod_search/faiss_search/client.py:18-186).
+
+Same constructor fields (`host`, `port`), same keyword-only `search()` that ignores
+`text / subset_ids / ids / shard` (client.py:64-74), same `/fast-search` request and response encoding,
+same `RetrievalBatch` result with `meta["time"]`.  The master spawns `python -m vod_amd.search.server`,
+which owns the GPU-resident index; clients stay plain HTTP so they can be pickled into DataLoader workers.
+"""
+from __future__ import annotations
+
+import os
+import pathlib
+import sys
+import time
+from copy import copy
+
+import numpy as np
+import requests
+
+from vod_amd import io
+from vod_amd import types as vt
+from vod_amd.search import base
+from vod_amd.search.socket import find_available_port
+
+
+class HipMipsClient(base.SearchClient):
+    """HTTP client of the HIP MIPS server."""
+
+    requires_vectors = True
+
+    def __init__(self, host: str = "http://localhost", port: int = 7678):
+        self.host = host
+        self.port = port
+
+    def __repr__(self) -> str:
+        return f"{type(self).__name__}[{self.url}](requires_vectors={self.requires_vectors})"
+
+    @property
+    def url(self) -> str:
+        return f"{self.host}:{self.port}"
+
+    def ping(self, timeout: float = 120) -> bool:
+        try:
+            response = requests.get(f"{self.url}/", timeout=timeout)
+        except requests.exceptions.ConnectionError:
+            return False
+        response.raise_for_status()
+        return "OK" in response.text
+
+    def search_py(self, query_vec: np.ndarray, top_k: int = 3, timeout: float = 120) -> vt.RetrievalBatch:
+        """Legacy JSON-list route (`POST /search`, client.py:47-62)."""
+        response = requests.post(f"{self.url}/search", json={"vectors": np.asarray(query_vec).tolist(), "top_k": top_k}, timeout=timeout)
+        response.raise_for_status()
+        data = response.json()
+        return vt.RetrievalBatch.cast(indices=data["indices"], scores=_scores_from_json(data["scores"]))
+
+    def search(
+        self,
+        *,
+        vector: np.ndarray,
+        text: None | list[str] = None,  # noqa: ARG002
+        subset_ids: None | list[list[base.SubsetId]] = None,  # noqa: ARG002
+        ids: None | list[list[base.SectionId]] = None,  # noqa: ARG002
+        shard: None | list[base.ShardName] = None,  # noqa: ARG002
+        top_k: int = 3,
+        timeout: float = 120,
+    ) -> vt.RetrievalBatch:
+        start = time.time()
+        payload = {"vectors": io.serialize_np_array(np.asarray(vector)), "top_k": top_k}
+        response = requests.post(f"{self.url}/fast-search", json=payload, timeout=timeout)
+        try:
+            response.raise_for_status()
+        except requests.exceptions.HTTPError:
+            try:
+                print(response.json()["detail"], file=sys.stderr)
+            except Exception:
+                print(response.text, file=sys.stderr)
+            raise
+        data = response.json()
+        return vt.RetrievalBatch.cast(
+            indices=io.deserialize_np_array(data["indices"]),
+            scores=io.deserialize_np_array(data["scores"]),
+            labels=None,
+            meta={"time": time.time() - start},
+        )
+
+
+def _scores_from_json(rows: list) -> np.ndarray:
+    # JSON has no -inf literal in strict mode; the server encodes pads as None on the legacy route
+    return np.array([[(-np.inf if v is None else v) for v in r] for r in rows], dtype=np.float32)
+
+
+class HipMipsMaster(base.SearchMaster[HipMipsClient]):
+    """Spawns / terminates the HIP MIPS server.
+
+    ```python
+    with HipMipsMaster(vectors_path) as master:
+        client = master.get_client()
+        result = client.search(vector=queries, top_k=100)
+    ```
+    `vectors_path` is a `.npy` file ([N, D] float32 / float16) or a store directory written by
+    `vod_amd.store.save_vectors`.  Counterpart of `FaissMaster(index_path, nprobe, logging_level, host, port,
+    skip_setup, free_resources, serve_on_gpu)`; `nprobe` is accepted and ignored (the index is exact).
+    """
+
+    def __init__(  # noqa: PLR0913
+        self,
+        vectors_path: str | pathlib.Path,
+        nprobe: int = 8,  # noqa: ARG002 - exact index: nothing to probe
+        logging_level: str = "DEBUG",
+        host: str = "http://localhost",
+        port: int = 6637,
+        skip_setup: bool = False,
+        free_resources: bool = False,
+        dtype: str = "float16",
+        device: int = 0,
+    ):
+        super().__init__(skip_setup=skip_setup, free_resources=free_resources)
+        self.vectors_path = pathlib.Path(vectors_path)
+        self.logging_level = logging_level
+        self.host = host
+        self.port = find_available_port() if port < 0 else port
+        self.dtype = dtype
+        self.device = device
+
+    def _make_env(self) -> dict[str, str]:
+        env = copy(dict(os.environ))
+        root = str(pathlib.Path(__file__).resolve().parents[2])
+        env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+        return env
+
+    def _make_cmd(self) -> list[str]:
+        return [
+            sys.executable, "-m", "vod_amd.search.server",
+            "--vectors-path", str(self.vectors_path.absolute()),
+            "--host", str(self.host),
+            "--port", str(self.port),
+            "--logging-level", str(self.logging_level),
+            "--dtype", self.dtype,
+            "--device", str(self.device),
+        ]
+
+    def get_client(self) -> HipMipsClient:
+        return HipMipsClient(host=self.host, port=self.port)
+
+    @property
+    def url(self) -> str:
+        return f"{self.host}:{self.port}"
+
+    @property
+    def service_info(self) -> str:
+        return f"HipMipsServer[{self.url}]"
+
+    @property
+    def service_name(self) -> str:
+        return super().service_name + f"-{self.port}"

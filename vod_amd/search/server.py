@@ -1,0 +1,141 @@
+"""HTTP server that owns the GPU-resident index (counterpart of
+/root/reference/src/vod_search/faiss_search/server.py:39-98; wire models :30-79 of models.py).
+
+Routes and payloads are the reference's:
+  GET  /             -> "OK" | "ERROR: Index is empty"                 (server.py:57-65)
+  POST /search       {"vectors": [[...]], "top_k": k} -> {"scores": [[...]], "indices": [[...]]}   (:68-73)
+  POST /fast-search  {"vectors": b64(npy), "top_k": k} -> {"scores": b64(npy f32), "indices": b64(npy i64)}  (:76-91)
+Unknown fields are rejected (`extra = "forbid"`), a non-2-D query is an error, failures come back as
+HTTP 500 with the formatted trace in `detail`.
+
+`create_app(engine)` takes any object with `.ntotal` and `.search(np.ndarray[nq, d], k) -> (scores, ids)`;
+`main()` -- the only production entry point -- builds the HIP engine and fails loudly without a GPU or
+without libvodhip.so (there is no CPU engine in this package).
+"""
+from __future__ import annotations
+
+import argparse
+import re
+import threading
+import traceback
+
+import numpy as np
+import pydantic
+from fastapi import FastAPI, HTTPException
+
+from vod_amd import io
+
+
+class SearchQuery(pydantic.BaseModel):
+    model_config = pydantic.ConfigDict(extra="forbid")
+    vectors: list = pydantic.Field(..., description="A batch of vectors: list[list[float]].")
+    top_k: int = 3
+
+
+class FastSearchQuery(pydantic.BaseModel):
+    model_config = pydantic.ConfigDict(extra="forbid")
+    vectors: str = pydantic.Field(..., description="A batch of vectors, np.save bytes in urlsafe base64.")
+    top_k: int = 3
+
+
+class SearchResponse(pydantic.BaseModel):
+    model_config = pydantic.ConfigDict(extra="forbid")
+    scores: list
+    indices: list
+
+
+class FastSearchResponse(pydantic.BaseModel):
+    model_config = pydantic.ConfigDict(extra="forbid")
+    scores: str
+    indices: str
+
+
+def create_app(engine) -> FastAPI:
+    """Build the FastAPI app around a search engine.  Requests are serialised (one GPU stream, like the
+    reference's single uvicorn worker running faiss synchronously, server.py:69,78,98)."""
+    app = FastAPI()
+    lock = threading.Lock()
+
+    def _search(query_vec: np.ndarray, top_k: int) -> tuple[np.ndarray, np.ndarray]:
+        if query_vec.ndim != 2:
+            raise ValueError(f"Expected 2D array, got {query_vec.ndim}D array")
+        with lock:
+            scores, indices = engine.search(query_vec, top_k)
+        return np.asarray(scores, dtype=np.float32), np.asarray(indices, dtype=np.int64)
+
+    @app.get("/")
+    def health_check() -> str:
+        if engine.ntotal == 0:
+            return "ERROR: Index is empty"
+        return "OK"
+
+    @app.post("/search")
+    def search(query: SearchQuery) -> SearchResponse:
+        try:
+            scores, indices = _search(np.asarray(query.vectors, dtype=np.float32), query.top_k)
+            rows = [[(None if np.isneginf(v) else float(v)) for v in r] for r in scores]
+            return SearchResponse(scores=rows, indices=indices.tolist())
+        except Exception as exc:
+            raise HTTPException(status_code=500, detail=traceback.format_exc()) from exc
+
+    @app.post("/fast-search")
+    def fast_search(query: FastSearchQuery) -> FastSearchResponse:
+        try:
+            scores, indices = _search(io.deserialize_np_array(query.vectors), query.top_k)
+            return FastSearchResponse(scores=io.serialize_np_array(scores), indices=io.serialize_np_array(indices))
+        except Exception as exc:
+            raise HTTPException(status_code=500, detail=traceback.format_exc()) from exc
+
+    return app
+
+
+class HipEngine:
+    """The production engine: a `HipFlatIndex` fed from a vector file, searched on the GPU."""
+
+    def __init__(self, vectors_path: str, dtype: str = "float16", device: int = 0):
+        import torch
+
+        from vod_amd import store
+        from vod_amd.index import HipFlatIndex
+
+        self._torch = torch
+        vectors = store.open_vectors(vectors_path)
+        n, d = vectors.shape
+        self.index = HipFlatIndex(d, max(n, 1), dtype=getattr(torch, dtype), device=device)
+        step = 262144
+        for lo in range(0, n, step):  # H2D in slices; the store converts to fp16/bf16 on the device
+            self.index.add(np.ascontiguousarray(vectors[lo : lo + step]))
+
+    @property
+    def ntotal(self) -> int:
+        return self.index.ntotal
+
+    def search(self, query_vec: np.ndarray, top_k: int) -> tuple[np.ndarray, np.ndarray]:
+        if query_vec.shape[1] != self.index.dim:
+            raise ValueError(f"query dimension {query_vec.shape[1]} != index dimension {self.index.dim}")
+        scores, ids = self.index.search(query_vec, top_k)
+        return scores.cpu().numpy(), ids.cpu().numpy()
+
+
+def parse_args() -> argparse.Namespace:
+    p = argparse.ArgumentParser()
+    p.add_argument("--vectors-path", type=str, required=True)
+    p.add_argument("--host", type=str, default="localhost")
+    p.add_argument("--port", type=int, default=7678)
+    p.add_argument("--logging-level", type=str, default="INFO")
+    p.add_argument("--dtype", type=str, default="float16", choices=["float16", "bfloat16"])
+    p.add_argument("--device", type=int, default=0)
+    return p.parse_args()
+
+
+def main() -> None:
+    import uvicorn
+
+    args = parse_args()
+    engine = HipEngine(args.vectors_path, dtype=args.dtype, device=args.device)
+    host = re.sub(r"^(http|https)://", "", args.host)
+    uvicorn.run(create_app(engine), host=host, port=args.port, workers=1, log_level=args.logging_level.lower())
+
+
+if __name__ == "__main__":
+    main()
