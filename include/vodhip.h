@@ -110,8 +110,10 @@ int vodhip_merge_topk(const float* scores, const int64_t* ids, int n_shards, int
  *           (core/merge.py:8-164) + gather_values_by_indices (core/numpy_ops.py:126-143).
  * All pointers are DEVICE pointers.  lookup_idx/lookup_lbl [nq, k_lookup] (lookup scores are discarded
  * by the reference, search.py:92).  engine e: idx[e] int64 [nq, k_e], scr[e] float32 [nq, k_e].
- * Outputs have `out_stride` = k_lookup + sum(k_e) + 1 columns allocated; the reference's width
- * (max cursor + 1, merge.py:160-162) is written to *out_width (device int32).
+ * Outputs have `out_stride` = k_lookup + sum(k_e) + 1 columns allocated.  The reference cuts its buffer to
+ * `[: max_cursor + 1]` after every pairwise fold (merge.py:160-162); out_width (device int32[VODHIP_MAX_ENGINES])
+ * receives, per engine e, the maximum over rows of the cursor after engine e was folded in, from which the
+ * caller derives the reference's final width: W = k_lookup; for e: W = min(out_width[e] + 1, W + k_e).
  *   out_idx  int64  : union of ids in first-seen order, -1 padded
  *   out_scr  float32: sum_e w_e * (s_e - rowmin_e), -inf padded
  *   out_lbl  int64  : lookup label of the id, -1 if absent (pad column: see SURVEY quirk Q3)

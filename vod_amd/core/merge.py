@@ -35,6 +35,10 @@ def merge_hybrid_tensors(
     if len(names) > _native.MAX_ENGINES:
         raise ValueError(f"at most {_native.MAX_ENGINES} scored engines are supported, got {len(names)}")
     nq, kl = lookup_idx.shape
+    if not names:
+        # a single result set is returned as is, weighted (merge.py:18-22): no union, no pad column
+        zeros = torch.zeros((nq, kl), dtype=torch.float32, device=dev)
+        return lookup_idx, zeros, lookup_lbl, {}
     lookup_idx = lookup_idx.contiguous().long()
     if lookup_lbl is not None:
         lookup_lbl = lookup_lbl.contiguous().long()
@@ -49,7 +53,7 @@ def merge_hybrid_tensors(
     out_scr = torch.empty((nq, stride), dtype=torch.float32, device=dev)
     out_lbl = torch.empty((nq, stride), dtype=torch.int64, device=dev) if lookup_lbl is not None else None
     out_raw = [torch.empty((nq, stride), dtype=torch.float32, device=dev) for _ in names]
-    width = torch.zeros((1,), dtype=torch.int32, device=dev)
+    width = torch.zeros((_native.MAX_ENGINES,), dtype=torch.int32, device=dev)
 
     n_e = len(names)
     VP = ctypes.c_void_p
@@ -67,8 +71,11 @@ def merge_hybrid_tensors(
                 arr_raw, stride, width.data_ptr(), _native.current_stream_ptr(dev),
             )
         )
-    w = int(width.item()) if nq else 1
-    w = max(w, 1)
+    # the reference truncates to `max_cursor + 1` after every pairwise fold (merge.py:160-162)
+    stage_max = width.tolist()
+    w = kl
+    for e in range(n_e):
+        w = min(stage_max[e] + 1, w + ks[e])
     raw = {n: t[:, :w] for n, t in zip(names, out_raw)}
     return out_idx[:, :w], out_scr[:, :w], (out_lbl[:, :w] if out_lbl is not None else None), raw
 

@@ -110,7 +110,16 @@ __global__ __launch_bounds__(HY_THREADS) void merge_hybrid_kernel(HybridArgs a) 
         o_idx[c] = -1;
         o_scr[c] = -__builtin_inff();
     }
-    if (tid == 0) atomicMax(a.out_width, cursor + 1);  // merge.py:160-162: columns [: max_cursor + 1]
+    // The reference folds the engines pairwise and cuts the buffer to `[: max_cursor + 1]` after EVERY fold
+    // (merge.py:160-162), so the final width depends on the per-stage maxima over rows of the cursor.
+    // stage e = "after engine e has been folded in": cursor_e = #first occurrences among the first end_e entries.
+    if (tid < a.n_engines) {
+        int end = a.k_lookup;
+        for (int e = 0; e <= tid; ++e) end += a.engine_k[e];
+        int c = 0;
+        for (int p = 0; p < end; ++p) c += first[p];
+        atomicMax(&a.out_width[tid], c);
+    }
     __syncthreads();
 
     // ---- 5. labels from the lookup, raw (min-subtracted) scores per engine: first match wins ----
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(HY_THREADS) void merge_hybrid_kernel(HybridArgs a) 
 }
 
 hipError_t launch_merge_hybrid(const HybridArgs& a, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(a.out_width, 0, sizeof(int32_t), stream);
+    hipError_t e = hipMemsetAsync(a.out_width, 0, sizeof(int32_t) * 4, stream);
     if (e != hipSuccess) return e;
     if (a.nq == 0) return hipSuccess;
     int W = a.k_lookup;

@@ -448,7 +448,7 @@ int vodhip_merge_hybrid(const int64_t* lookup_idx, const int64_t* lookup_lbl, in
     a.n_engines = n_engines;
     int64_t width = k_lookup;
     for (int e = 0; e < n_engines; ++e) {
-        if (!engine_idx[e] || !engine_scr[e] || engine_k[e] < 0) return fail("engine %d: invalid arguments", e);
+        if (engine_k[e] < 0 || (engine_k[e] > 0 && (!engine_idx[e] || !engine_scr[e]))) return fail("engine %d: invalid arguments", e);
         a.engine_idx[e] = engine_idx[e];
         a.engine_scr[e] = engine_scr[e];
         a.engine_k[e] = engine_k[e];
