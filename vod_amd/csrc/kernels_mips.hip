@@ -20,6 +20,8 @@
 // Roofline: 2*nq*N*D flop per batch on MFMA vs N*D*2 bytes of HBM; arithmetic intensity = nq flop/B.
 #include "vodhip_internal.h"
 
+#include <type_traits>
+
 namespace vodhip {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -60,22 +62,53 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // ------------------------------------------------------------------------------------------------
 // filter kernel
 // ------------------------------------------------------------------------------------------------
-constexpr int BK = 64;            // K elements per LDS stage (128 B per row)
-constexpr int ROW_BYTES = BK * 2;  // 128
+#ifdef VODHIP_ABLATION
+// Diagnostic build only: in-kernel cycle stamps (s_memtime) of sampled workgroups, written to a buffer that no
+// other code reads.  Layout: [sample 0..63][wave 0..7][slot 0..15][6 stamps].
+__device__ unsigned long long g_stamps[64 * 8 * 16 * 6];
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#endif
 
-template <int DT, int BM, int BN, int WM, int WN, bool DENSE>
-__global__ __launch_bounds__(WM* WN * 64, 2) void mips_filter_kernel(
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    // counted wait: all but the N youngest vector-memory operations of this wave are complete
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "add the literal");
+}
+
+// BK      : K elements per LDS stage (64 -> 128-B rows, 32 -> 64-B rows)
+// NSTAGE  : LDS ring depth.  Slice t+NSTAGE-1 is being fetched while slice t is multiplied, so
+//           (NSTAGE-2) whole slices stay in flight ACROSS the per-slice barrier (counted vmcnt, raw s_barrier).
+template <int DT, int BM, int BN, int WM, int WN, int BK, int NSTAGE, bool DENSE, int ABLATE = 0, bool PINGPONG = false>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN * 64 * ((160 * 1024) / (NSTAGE * (BM + BN) * BK * 2))) / 256 >= 2 ? 2 : 1)
+void mips_filter_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
     int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
     key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow) {
     constexpr int NWAVES = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;  // per-wave tile
     constexpr int MI = TM / 32, NJ = TN / 32;  // 32x32 blocks per wave
+    constexpr int ROW_BYTES = BK * 2;
+    constexpr int CH = ROW_BYTES / 16;         // 16-B chunks per LDS row (8 | 4)
+    constexpr int RPI = 64 / CH;               // rows covered by one LDS-DMA wave-instruction (8 | 16)
+    constexpr int KK = BK / 16;                // MFMA k-steps per slice (4 | 2)
     constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int NA = BM / 8 / NWAVES;  // LDS-DMA wave-instructions per wave per stage (8 rows each)
-    constexpr int NB = BN / 8 / NWAVES;
-    static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "tile/wave mismatch");
+    constexpr int NA = BM / RPI / NWAVES;      // LDS-DMA wave-instructions per wave per slice
+    constexpr int NB = BN / RPI / NWAVES;
+    constexpr int G = NA + NB;
+    static_assert(BM % (RPI * NWAVES) == 0 && BN % (RPI * NWAVES) == 0, "tile/wave mismatch");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -95,40 +128,63 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mips_filter_kernel(
 
     const int x0 = row_begin + xt * BM;  // first corpus row of the tile
     const int q0 = qt * BN;              // first query of the tile
+#ifdef VODHIP_ABLATION
+    unsigned long long t_entry = 0;
+    if constexpr (ABLATE == 5) t_entry = stamp_now();
+#endif
 
-    // ---- per-lane LDS-DMA source pointers: lane -> (row = base + lane/8, 16-B slot = lane%8) ----
-    // slot s of row r holds logical chunk c = s ^ ((r >> 1) & 7)  (conflict-free ds_read_b128, see below)
-    const int st_row = lane >> 3, st_slot = lane & 7;
+    // ---- per-lane LDS-DMA source pointers: lane -> (row = base + lane/CH, 16-B slot = lane%CH) ----
+    // Slot s of row r holds logical chunk c = s ^ f(r), f(r) = (r>>1)&7 for 128-B rows, (r>>2)&3 for 64-B rows:
+    // the 16 rows of a ds_read_b128 lane group then hit 16 distinct 16-B slots of the 256-B bank row.
+    // The XOR is applied on the SOURCE address; the LDS image stays lane-linear as LDS-DMA requires.
+    auto swz_of_row = [](int r) { return CH == 8 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+    const int st_row = lane / CH, st_slot = lane % CH;
     const char* a_src[NA];
     const char* b_src[NB];
 #pragma unroll
     for (int t = 0; t < NA; ++t) {
-        const int r = (wave * NA + t) * 8 + st_row;
-        const int c = st_slot ^ ((r >> 1) & 7);
+        const int r = (wave * NA + t) * RPI + st_row;
+        const int c = st_slot ^ swz_of_row(r);
         a_src[t] = (const char*)X + ((size_t)(x0 + r) * dim_pad + c * 8) * 2;
+        if constexpr (ABLATE == 6)  // [8-row group][k-slice] blocks of 1 KiB: one wave-instruction = one contiguous KiB
+            a_src[t] = (const char*)X + ((size_t)(x0 / RPI + wave * NA + t) * (dim_pad / BK)) * 1024 + lane * 16;
     }
 #pragma unroll
     for (int t = 0; t < NB; ++t) {
-        const int r = (wave * NB + t) * 8 + st_row;
-        const int c = st_slot ^ ((r >> 1) & 7);
+        const int r = (wave * NB + t) * RPI + st_row;
+        const int c = st_slot ^ swz_of_row(r);
         b_src[t] = (const char*)Q + ((size_t)(q0 + r) * dim_pad + c * 8) * 2;
+        if constexpr (ABLATE == 6)
+            b_src[t] = (const char*)Q + ((size_t)(q0 / RPI + wave * NB + t) * (dim_pad / BK)) * 1024 + lane * 16;
     }
-
-    auto stage = [&](int buf, int kbyte) {
-        char* sa = smem + buf * STAGE_BYTES;
+    // K is a reduction, so its order is free: the n_qtiles workgroups that share a corpus tile (they run at the same
+    // time on one XCD) walk the K slices in ROTATED orders.  Each slice is then fetched from HBM by exactly one of
+    // them and found in L2 by the others a little later, instead of all of them queueing on the same HBM miss
+    // (measured on C3: filter kernel 15.9 -> 8.3 ms per batch; ABLATE == 10 switches it off for A/B runs).
+    const int nk_ = dim_pad / BK;
+    const int krot = (qt * nk_) / n_qtiles;
+    // `part` of `nparts` of slice `ks`'s LDS-DMA into ring slot ks % NSTAGE
+    auto stage_part = [&](int ks, int part, int nparts) {
+        char* sa = smem + (ks % NSTAGE) * STAGE_BYTES;
         char* sb = sa + A_BYTES;
+        const int kbyte = ABLATE == 6 ? ks * 1024 : (ABLATE != 10 ? ((ks + krot) % nk_) * ROW_BYTES : ks * ROW_BYTES);
 #pragma unroll
-        for (int t = 0; t < NA; ++t) glds16(a_src[t] + kbyte, sa + (wave * NA + t) * 8 * ROW_BYTES);
-#pragma unroll
-        for (int t = 0; t < NB; ++t) glds16(b_src[t] + kbyte, sb + (wave * NB + t) * 8 * ROW_BYTES);
+        for (int u = 0; u < G; ++u) {
+            if ((u * nparts) / G != part) continue;
+            if (u < NA) {
+                if constexpr (ABLATE != 8) glds16(a_src[u] + kbyte, sa + (wave * NA + u) * RPI * ROW_BYTES);
+            } else {
+                if constexpr (ABLATE != 7) glds16(b_src[u - NA] + kbyte, sb + (wave * NB + (u - NA)) * RPI * ROW_BYTES);
+            }
+        }
     };
 
     // ---- fragment read addressing --------------------------------------------------------------
     // MFMA 32x32x16: lane l supplies A[row l&31][k = 8h..8h+7] and B[k = 8h..8h+7][col l&31], h = l>>5.
-    // Logical chunk of k-substep kk is 2*kk + h; its slot is chunk ^ ((row>>1)&7) and, because every
-    // block starts at a multiple of 32 rows, (row>>1)&7 == (l>>1)&7 for every block.
+    // Logical chunk of k-step kk is 2*kk + h; every block starts at a multiple of 32 rows, so f(row) depends
+    // on the lane only.
     const int fr = lane & 31, fh = lane >> 5;
-    const int swz = (lane >> 1) & 7;
+    const int swz = swz_of_row(fr);
     const int a_row_off = (wm * TM + fr) * ROW_BYTES;
     const int b_row_off = A_BYTES + (wn * TN + fr) * ROW_BYTES;
 
@@ -140,37 +196,159 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mips_filter_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // thresholds of this lane's queries (loaded early; latency hidden behind the K loop)
+    const int nk = dim_pad / BK;
+    if constexpr (ABLATE == 12) {
+        if (wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the later-dispatched half
+    }
+    // prologue: fill NSTAGE-1 ring slots
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk) stage_part(s, 0, 1);
+
+    // thresholds of this lane's queries (issued after the DMA so they do not delay it; consumed in the epilogue)
     float thr[NJ];
     if constexpr (!DENSE) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int q = q0 + wn * TN + j * 32 + fr;
-            thr[j] = (q < nq) ? thr_s[q] : __builtin_inff();
+            thr[j] = (q < nq && ABLATE != 2 && ABLATE != 4 && !(ABLATE >= 6 && ABLATE <= 8)) ? thr_s[q] : __builtin_inff();
         }
     }
 
-    const int nk = dim_pad / BK;
-    stage(0, 0);
-    for (int t = 0; t < nk; ++t) {
-        __syncthreads();  // vmcnt(0): slice t has landed; barrier: everyone is done reading the other buffer
-        if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * ROW_BYTES);
-        const char* base = smem + (t & 1) * STAGE_BYTES;
+    auto load_frags = [&](const char* base, int kk, u32x4(&af)[MI], u32x4(&bf)[NJ]) {
+        if constexpr (ABLATE == 4 || (ABLATE >= 6 && ABLATE <= 8)) return;
+        if constexpr (ABLATE == 2) {  // timing-only build: no LDS reads, fragments made up from registers
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int slot_off = ((2 * kk + fh) ^ swz) << 4;
-            u32x4 af[MI], bf[NJ];
+            for (int i = 0; i < MI; ++i) { af[i] = u32x4{(unsigned)(kk + i), (unsigned)lane, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(af[i])); }
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *(const u32x4*)(base + a_row_off + i * 32 * ROW_BYTES + slot_off);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bf[j] = *(const u32x4*)(base + b_row_off + j * 32 * ROW_BYTES + slot_off);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(af[i], bf[j], acc[i][j]);
+            for (int j = 0; j < NJ; ++j) { bf[j] = u32x4{(unsigned)(kk + j), (unsigned)lane, 0x3c003c00u, 0x3c003c00u}; asm volatile("" : "+v"(bf[j])); }
+            return;
         }
+        const int slot_off = ((2 * kk + fh) ^ swz) << 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const u32x4*)(base + a_row_off + i * 32 * ROW_BYTES + slot_off);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[j] = *(const u32x4*)(base + b_row_off + j * 32 * ROW_BYTES + slot_off);
+    };
+    auto mfma_group = [&](u32x4(&af)[MI], u32x4(&bf)[NJ]) {
+        if constexpr (ABLATE == 4 || (ABLATE >= 6 && ABLATE <= 8)) return;
+        if constexpr (ABLATE == 13) __builtin_amdgcn_s_setprio(1);  // per-group priority flips measured -4 % here
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(af[i], bf[j], acc[i][j]);
+        if constexpr (ABLATE == 13) __builtin_amdgcn_s_setprio(0);
+    };
+    // One K-slice.  Software pipelined inside the slice: the fragments of k-step kk+1 are read from LDS while
+    // the MFMAs of k-step kk run, and the LDS-DMA of slice t+NSTAGE-1 is issued in KK parts between the MFMA
+    // groups instead of as one burst in front of them.
+    auto kslice = [&](int t, auto pre_tag) {
+        constexpr bool PRE = decltype(pre_tag)::value;
+        const char* base = smem + (t % NSTAGE) * STAGE_BYTES;
+        const int ks = t + NSTAGE - 1;
+        u32x4 af0[MI], bf0[NJ], af1[MI], bf1[NJ];
+        load_frags(base, 0, af0, bf0);
+        if constexpr (PRE && ABLATE != 1) stage_part(ks, 0, KK);
+        load_frags(base, 1, af1, bf1);
+        mfma_group(af0, bf0);
+        if constexpr (PRE && ABLATE != 1) stage_part(ks, 1, KK);
+        if constexpr (KK == 4) {
+            load_frags(base, 2, af0, bf0);
+            mfma_group(af1, bf1);
+            if constexpr (PRE && ABLATE != 1) stage_part(ks, 2, KK);
+            load_frags(base, 3, af1, bf1);
+            mfma_group(af0, bf0);
+            if constexpr (PRE && ABLATE != 1) stage_part(ks, 3, KK);
+        }
+        mfma_group(af1, bf1);
+    };
+    if constexpr (!PINGPONG) {
+        // Slice t is complete in LDS once all but the (NSTAGE-2)*G youngest DMAs of every wave have landed and
+        // every wave has passed the barrier (which also proves nobody still reads the slot being refilled).
+        int t = 0;
+#ifdef VODHIP_ABLATION
+        if constexpr (ABLATE == 5) {
+            // sampled workgroups of the large launches record, per K-slice: before the DMA wait, after it, after the
+            // barrier, after the slice's MFMAs were issued (stamps have lgkmcnt(0): all LDS reads retired)
+            const bool sampled = (gridDim.x > 4096) && ((bid & 1023) == 7) && ((bid >> 10) < 64);
+            unsigned long long* out = g_stamps + (((size_t)(bid >> 10) * 8 + wave) * 16) * 6;
+            const unsigned long long tk0 = stamp_now();
+            for (; t + NSTAGE - 1 < nk; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long s0 = stamp_now();
+                wait_vmcnt<(NSTAGE - 2) * G>();
+                const unsigned long long s1 = stamp_now();
+                __builtin_amdgcn_s_barrier();
+                const unsigned long long s2 = stamp_now();
+                __builtin_amdgcn_sched_barrier(0);
+                kslice(t, std::true_type{});
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long s3 = stamp_now();
+                if (sampled && lane == 0 && t < 16) {
+                    out[t * 6 + 0] = s0; out[t * 6 + 1] = s1; out[t * 6 + 2] = s2; out[t * 6 + 3] = s3; out[t * 6 + 4] = tk0;
+                }
+            }
+        }
+#endif
+        for (; t + NSTAGE - 1 < nk; ++t) {
+            wait_vmcnt<(NSTAGE - 2) * G>();
+            if constexpr (ABLATE != 3) __builtin_amdgcn_s_barrier();
+            kslice(t, std::true_type{});
+        }
+        for (; t < nk; ++t) {  // tail: nothing left to fetch, the ring drains
+            if (NSTAGE >= 4 && nk - 1 - t >= 2) wait_vmcnt<(NSTAGE >= 4 ? 2 : 0) * G>();
+            else if (NSTAGE >= 3 && nk - 1 - t >= 1) wait_vmcnt<(NSTAGE >= 3 ? 1 : 0) * G>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            kslice(t, std::false_type{});
+        }
+    } else {
+        // ---- ping-pong schedule (BK = 32, 4-slot ring) ------------------------------------------------
+        // The two waves that share a SIMD (wave w and w + NWAVES/2) run the same program one barrier apart:
+        // a phase is  LOAD {6 ds_read_b128 (+ the LDS-DMA of slice t+3 in odd phases)} | s_barrier |
+        // MFMA {8 x v_mfma 32x32x16} | s_barrier,  and the second half of the workgroup takes one extra
+        // barrier up front, so while one wave of a SIMD sits in its MFMA section its partner is in its LOAD
+        // section (LDS latency, DMA issue cost and waits hide behind the partner's matrix work).
+        // Hazards (b_n = n-th barrier; first half runs LOAD_p before b_2p, MFMA_p after it; second half one later):
+        //  WAR  slot (t+3)%4 was last read in LOAD_(2t-1); the second half retires those reads right after
+        //       b_(4t-1), so DMA(t+3) may be issued after b_4t: it is issued in LOAD_(2t+1) by both halves.
+        //  RAW  after issuing DMA(t+3) every wave waits until all but its 2*G youngest DMAs landed (=> slice
+        //       t+1 complete) BEFORE its next barrier; the first read of slice t+1 (LOAD_(2t+2)) is behind it.
+        static_assert(!PINGPONG || (BK == 32 && NSTAGE == 4), "ping-pong schedule is written for BK=32, 4 slots");
+        const bool second_half = wave >= NWAVES / 2;
+        wait_vmcnt<2 * G>();  // slice 0 landed (slices 1, 2 may still be in flight)
+        __builtin_amdgcn_s_barrier();
+        if (second_half) __builtin_amdgcn_s_barrier();
+        u32x4 af[MI], bf[NJ];
+        for (int t = 0; t < nk; ++t) {
+            const char* base = smem + (t % NSTAGE) * STAGE_BYTES;
+            // phase 2t
+            load_frags(base, 0, af, bf);
+            __builtin_amdgcn_s_barrier();
+            mfma_group(af, bf);
+            __builtin_amdgcn_s_barrier();
+            // phase 2t+1
+            load_frags(base, 1, af, bf);
+            const int rem = nk - 2 - t;  // slices beyond t+1 that exist
+            if (rem >= 2) {
+                stage_part(t + 3, 0, 1);
+                wait_vmcnt<2 * G>();
+            } else if (rem == 1) {
+                wait_vmcnt<G>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            mfma_group(af, bf);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (!second_half) __builtin_amdgcn_s_barrier();  // balance the barrier count
     }
 
+#ifdef VODHIP_ABLATION
+    unsigned long long t_kend = 0;
+    if constexpr (ABLATE == 5) { __builtin_amdgcn_sched_barrier(0); t_kend = stamp_now(); }
+#endif
     // ---- epilogue: threshold filter --------------------------------------------------------------
     // C layout of v_mfma_f32_32x32x16: col = lane&31 (query), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #pragma unroll
@@ -220,6 +398,246 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void mips_filter_kernel(
             }
         }
     }
+#ifdef VODHIP_ABLATION
+    if constexpr (ABLATE == 5) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t_end = stamp_now();
+        const bool sampled = (gridDim.x > 4096) && ((bid & 1023) == 7) && ((bid >> 10) < 64);
+        if (sampled && lane == 0) {
+            unsigned long long* out = g_stamps + (((size_t)(bid >> 10) * 8 + wave) * 16 + 15) * 6;
+            out[0] = t_entry; out[1] = t_kend; out[2] = t_end;
+        }
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// specialised filter kernel: 8 MFMA ("consumer") waves + NL LDS-DMA ("loader") waves per workgroup
+// ------------------------------------------------------------------------------------------------
+// Measured on MI355X (profiles/r01_ablation.md): the L2 -> LDS path sustains ~48 GB/s per CU (12.3 TB/s
+// chip-wide) for this access pattern, i.e. ~2400 cycles per 64 KB K-slice, about as long as the slice's
+// MFMA work; when the MFMA waves issue the LDS-DMA themselves, in-order issue parks them behind a full
+// memory pipeline and the two costs ADD (16 ms = 10 ms DMA + 6 ms MFMA per batch).  Here the DMA is issued
+// by dedicated waves (one per SIMD) whose stalls cost nothing, the MFMA waves only read LDS and multiply.
+template <int MI, int NJ, bool DENSE>
+__device__ __forceinline__ void filter_epilogue(const f32x16 (&acc)[MI][NJ], const float (&thr)[NJ], int qbase, int rbase0,
+                                                int fr, int fh, int nq, int row_begin, int row_end,
+                                                const key_t64* __restrict__ thr_key, key_t64* __restrict__ cand,
+                                                unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow) {
+    // C layout of v_mfma_f32_32x32x16: col = lane&31 (query), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = qbase + j * 32 + fr;
+        const bool q_ok = q < nq;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int rbase = rbase0 + i * 32 + 4 * fh;
+            if constexpr (DENSE) {
+                if (q_ok) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        const float s = acc[i][j][r];
+                        if (row < row_end) {
+                            const key_t64 key = (s == s) ? make_key(s, (unsigned)row) : 0ull;  // NaN never enters
+                            cand[(size_t)q * cap + (row - row_begin)] = key;
+                        }
+                    }
+                }
+            } else {
+                float m = acc[i][j][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
+                const bool hit = m >= thr[j];  // false for NaN and for padded queries (thr = +inf)
+                if (__any(hit)) {
+                    if (hit) {
+                        const key_t64 tk = thr_key[q];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = rbase + (r & 3) + 8 * (r >> 2);
+                            const float s = acc[i][j][r];
+                            if (s >= thr[j] && row < row_end) {
+                                const key_t64 key = make_key(s, (unsigned)row);
+                                if (key > tk) {
+                                    const unsigned slot = atomicAdd(&cnt[q], 1u);
+                                    if (slot < (unsigned)cap)
+                                        cand[(size_t)q * cap + slot] = key;
+                                    else
+                                        atomicOr(overflow, 1u);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int DT, int BK, int NSTAGE, int NL, bool DENSE, bool STAMP = false, int ABL = 0>
+__global__ __launch_bounds__((8 + NL) * 64, 3) void mips_filter_spec_kernel(
+    const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
+    int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
+    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow) {
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NCW = 8;
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NJ = TN / 32;
+    constexpr int ROW_BYTES = BK * 2, CH = ROW_BYTES / 16, RPI = 64 / CH, KK = BK / 16;
+    constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = BN * ROW_BYTES, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NI = (BM + BN) / RPI;  // LDS-DMA wave-instructions per slice
+    constexpr int GL = NI / NL;          // ... per loader wave
+    static_assert(NI % NL == 0 && (BM / RPI) % GL == 0, "loader split");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, jj = bid >> 3;
+    const int qt = jj % n_qtiles;
+    const int xt = (jj / n_qtiles) * 8 + xcd;
+    if (xt >= n_xtiles) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = row_begin + xt * BM;
+    const int q0 = qt * BN;
+    const int nk = dim_pad / BK;
+    auto swz_of_row = [](int r) { return CH == 8 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+
+    if (wave >= NCW) {
+        // ================================ loader wave ================================
+        // Loader waves issue a handful of instructions per slice but each one feeds the whole workgroup: they must
+        // win issue arbitration against the MFMA waves (measured: with the MFMA waves at raised priority a loader
+        // needed 1,550 cycles to issue 8 LDS-DMAs, 450 without MFMA traffic).
+        __builtin_amdgcn_s_setprio(3);
+        const int lw = wave - NCW;
+        const int st_row = lane / CH, st_slot = lane % CH;
+        const int krot = (qt * nk) / n_qtiles;  // rotated K order per q-tile workgroup (see mips_filter_kernel)
+        auto stage = [&](int ks) {
+            char* sbase = smem + (ks % NSTAGE) * STAGE_BYTES;
+            const int kbyte = ((ks + krot) % nk) * ROW_BYTES;
+#pragma unroll
+            for (int u = 0; u < GL; ++u) {
+                const int g = lw * GL + u;           // wave-uniform instruction index inside the slice
+                const int r = g * RPI + st_row;      // row inside [A rows | B rows]
+                const bool is_a = g * RPI < BM;      // wave-uniform
+                const int rr = is_a ? r : r - BM;
+                const int c = st_slot ^ swz_of_row(rr);
+                const uint16_t* src = is_a ? X + (size_t)(x0 + rr) * dim_pad : Q + (size_t)(q0 + rr) * dim_pad;
+                glds16((const char*)src + c * 16 + kbyte, sbase + g * RPI * ROW_BYTES);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < NSTAGE - 1; ++s)
+            if (s < nk) stage(s);
+        for (int t = 0; t < nk; ++t) {
+#ifdef VODHIP_ABLATION
+            unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            if constexpr (STAMP) s0 = stamp_now();
+#endif
+            const int ahead = nk - 1 - t;  // slices after t that have been issued at most NSTAGE-2
+            if (NSTAGE >= 4 && ahead >= 2) wait_vmcnt<(NSTAGE >= 4 ? 2 : 0) * GL>();
+            else if (NSTAGE >= 3 && ahead >= 1) wait_vmcnt<(NSTAGE >= 3 ? 1 : 0) * GL>();
+            else wait_vmcnt<0>();
+#ifdef VODHIP_ABLATION
+            if constexpr (STAMP) s1 = stamp_now();
+#endif
+            __builtin_amdgcn_s_barrier();  // B_t: slice t is complete; everyone is done with slice t-1
+#ifdef VODHIP_ABLATION
+            if constexpr (STAMP) s2 = stamp_now();
+#endif
+            if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1);
+#ifdef VODHIP_ABLATION
+            if constexpr (STAMP) {
+                s3 = stamp_now();
+                const bool sampled = (gridDim.x > 4096) && ((bid & 1023) == 7) && ((bid >> 10) < 64) && lw == 0;
+                if (sampled && lane == 0 && t < 15) {
+                    unsigned long long* out = g_stamps + (((size_t)(bid >> 10) * 8 + 7) * 16 + t) * 6;  // loader 0 uses wave slot 7
+                    out[0] = s0; out[1] = s1; out[2] = s2; out[3] = s3;
+                }
+            }
+#endif
+        }
+        return;
+    }
+
+    // ================================ MFMA wave ================================
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int swz = swz_of_row(fr);
+    const int a_row_off = (wm * TM + fr) * ROW_BYTES;
+    const int b_row_off = A_BYTES + (wn * TN + fr) * ROW_BYTES;
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float thr[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = q0 + wn * TN + j * 32 + fr;
+        thr[j] = (!DENSE && q < nq && ABL == 0) ? thr_s[q] : __builtin_inff();
+    }
+    auto load_frags = [&](const char* base, int kk, u32x4(&af)[MI], u32x4(&bf)[NJ]) {
+        if constexpr (ABL == 1) {  // timing-only: no LDS reads
+#pragma unroll
+            for (int i = 0; i < MI; ++i) { af[i] = u32x4{(unsigned)(kk + i), (unsigned)lane, 0u, 0u}; asm volatile("" : "+v"(af[i])); }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { bf[j] = u32x4{(unsigned)(kk + j), (unsigned)lane, 0u, 0u}; asm volatile("" : "+v"(bf[j])); }
+            return;
+        }
+        const int slot_off = ((2 * kk + fh) ^ swz) << 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = *(const u32x4*)(base + a_row_off + i * 32 * ROW_BYTES + slot_off);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bf[j] = *(const u32x4*)(base + b_row_off + j * 32 * ROW_BYTES + slot_off);
+    };
+    auto mfma_group = [&](u32x4(&af)[MI], u32x4(&bf)[NJ]) {
+        if constexpr (ABL == 2) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(bf[j]));
+            return;
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(af[i], bf[j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    for (int t = 0; t < nk; ++t) {
+#ifdef VODHIP_ABLATION
+        unsigned long long s0 = 0, s2 = 0;
+        if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); s0 = stamp_now(); }
+#endif
+        __builtin_amdgcn_s_barrier();  // B_t
+#ifdef VODHIP_ABLATION
+        if constexpr (STAMP) { s2 = stamp_now(); __builtin_amdgcn_sched_barrier(0); }
+#endif
+        const char* base = smem + (t % NSTAGE) * STAGE_BYTES;
+        // single fragment set (the 168-VGPR budget of 3 waves/SIMD leaves no room for a second one): the LDS
+        // latency of one wave's reads is covered by the MFMAs of the other MFMA wave on the same SIMD
+        u32x4 af[MI], bf[NJ];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            load_frags(base, kk, af, bf);
+            mfma_group(af, bf);
+        }
+#ifdef VODHIP_ABLATION
+        if constexpr (STAMP) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long s3 = stamp_now();
+            const bool sampled = (gridDim.x > 4096) && ((bid & 1023) == 7) && ((bid >> 10) < 64) && wave < 7;
+            if (sampled && lane == 0 && t < 15) {
+                unsigned long long* out = g_stamps + (((size_t)(bid >> 10) * 8 + wave) * 16 + t) * 6;
+                out[0] = s0; out[1] = s0; out[2] = s2; out[3] = s3;
+            }
+        }
+#endif
+    }
+    filter_epilogue<MI, NJ, DENSE>(acc, thr, q0 + wn * TN, x0 + wm * TM, fr, fh, nq, row_begin, row_end, thr_key, cand, cnt,
+                                   cap, overflow);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,10 +786,16 @@ hipError_t launch_search_init(const SearchWorkspace& ws, int64_t nq_pad, hipStre
     return hipGetLastError();
 }
 
-int filter_tile_rows(int tile) { return tile == 2 ? 256 : 128; }
-int filter_tile_cols(int tile) { return tile == 2 ? 256 : 128; }
+#ifdef VODHIP_ABLATION
+extern "C" int vodhip_debug_read_stamps(unsigned long long* host_out, long long n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), (size_t)n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
-template <int DT, int BM, int BN, int WM, int WN, bool DENSE>
+int filter_tile_rows(int tile) { return (tile == 1 || tile == 5) ? 128 : 256; }  // ablation ids 11..13 are 256
+int filter_tile_cols(int tile) { return (tile == 1 || tile == 5) ? 128 : 256; }
+
+template <int DT, int BM, int BN, int WM, int WN, int BK, int NSTAGE, bool DENSE, int ABLATE = 0, bool PINGPONG = false>
 static hipError_t launch_filter_cfg(const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin,
                                     int64_t row_end, int64_t nq, int64_t nq_pad, const SearchWorkspace& ws,
                                     hipStream_t stream) {
@@ -380,8 +804,8 @@ static hipError_t launch_filter_cfg(const void* store, const void* q_pad, int64_
     const int xgroups = (n_xtiles + 7) / 8;
     const unsigned grid = (unsigned)xgroups * 8u * (unsigned)n_qtiles;
     constexpr int threads = WM * WN * 64;
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * ROW_BYTES;
-    auto kern = mips_filter_kernel<DT, BM, BN, WM, WN, DENSE>;
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * BK * 2;
+    auto kern = mips_filter_kernel<DT, BM, BN, WM, WN, BK, NSTAGE, DENSE, ABLATE, PINGPONG>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -398,17 +822,100 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
                          int64_t row_begin, int64_t row_end, int64_t nq, int64_t nq_pad, const SearchWorkspace& ws,
                          hipStream_t stream) {
     if (row_end <= row_begin) return hipSuccess;
-#define VOD_FILTER(DT, TILE, BM, BN, WM, WN)                                                                          \
-    if (store_dtype == DT && tile == TILE) {                                                                          \
-        return dense ? launch_filter_cfg<DT, BM, BN, WM, WN, true>(store, q_pad, dim_pad, row_begin, row_end, nq,     \
-                                                                   nq_pad, ws, stream)                                \
-                     : launch_filter_cfg<DT, BM, BN, WM, WN, false>(store, q_pad, dim_pad, row_begin, row_end, nq,    \
-                                                                    nq_pad, ws, stream);                              \
+#define VOD_FILTER(DT, TILE, BM, BN, WM, WN, BK, NS)                                                                   \
+    if (store_dtype == DT && tile == TILE) {                                                                           \
+        return dense ? launch_filter_cfg<DT, BM, BN, WM, WN, BK, NS, true>(store, q_pad, dim_pad, row_begin, row_end,  \
+                                                                           nq, nq_pad, ws, stream)                     \
+                     : launch_filter_cfg<DT, BM, BN, WM, WN, BK, NS, false>(store, q_pad, dim_pad, row_begin, row_end, \
+                                                                            nq, nq_pad, ws, stream);                   \
     }
-    VOD_FILTER(0, 1, 128, 128, 2, 2)
-    VOD_FILTER(1, 1, 128, 128, 2, 2)
-    VOD_FILTER(0, 2, 256, 256, 2, 4)
-    VOD_FILTER(1, 2, 256, 256, 2, 4)
+#define VOD_FILTER_DT(TILE, BM, BN, WM, WN, BK, NS) VOD_FILTER(0, TILE, BM, BN, WM, WN, BK, NS) VOD_FILTER(1, TILE, BM, BN, WM, WN, BK, NS)
+    VOD_FILTER_DT(1, 128, 128, 2, 2, 64, 2)   // 64 KB LDS, 2 workgroups / CU
+    VOD_FILTER_DT(2, 256, 256, 2, 4, 64, 2)   // 128 KB LDS, drain-to-zero double buffer
+    VOD_FILTER_DT(3, 256, 256, 2, 4, 32, 4)   // 128 KB LDS, 4-slot ring, 2 slices in flight across the barrier
+    VOD_FILTER_DT(5, 128, 128, 2, 2, 32, 4)   // 64 KB LDS ring, 2 workgroups / CU
+#undef VOD_FILTER_DT
+    if (tile == 6 || tile == 7) {  // specialised: 8 MFMA waves + 4 loader waves
+        const int n_xtiles = (int)((row_end - row_begin + 255) / 256);
+        const int n_qtiles = (int)(nq_pad / 256);
+        const unsigned grid = (unsigned)((n_xtiles + 7) / 8) * 8u * (unsigned)n_qtiles;
+        constexpr size_t lds = 128 * 1024;
+#define VOD_SPEC(DT, BKK, NS, DENSE)                                                                                   \
+    {                                                                                                                  \
+        auto kern = mips_filter_spec_kernel<DT, BKK, NS, 4, DENSE>;                                                    \
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        if (e != hipSuccess) return e;                                                                                 \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, stream, (const uint16_t*)store, (const uint16_t*)q_pad,   \
+                           (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s,          \
+                           ws.thr_key, ws.cand, ws.cnt, (int)ws.cap, ws.overflow);                                     \
+        return hipGetLastError();                                                                                      \
+    }
+        if (tile == 6) {
+            if (store_dtype == 0 && dense) VOD_SPEC(0, 64, 2, true)
+            if (store_dtype == 0 && !dense) VOD_SPEC(0, 64, 2, false)
+            if (store_dtype == 1 && dense) VOD_SPEC(1, 64, 2, true)
+            if (store_dtype == 1 && !dense) VOD_SPEC(1, 64, 2, false)
+        } else {
+            if (store_dtype == 0 && dense) VOD_SPEC(0, 32, 4, true)
+            if (store_dtype == 0 && !dense) VOD_SPEC(0, 32, 4, false)
+            if (store_dtype == 1 && dense) VOD_SPEC(1, 32, 4, true)
+            if (store_dtype == 1 && !dense) VOD_SPEC(1, 32, 4, false)
+        }
+#undef VOD_SPEC
+    }
+    if (tile == 4) {  // 256x256, BK=32, 4-slot ring, ping-pong between the two waves of each SIMD
+#define VOD_PP(DT, DENSE) return launch_filter_cfg<DT, 256, 256, 2, 4, 32, 4, DENSE, 0, true>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream)
+        if (store_dtype == 0 && dense) VOD_PP(0, true);
+        if (store_dtype == 0 && !dense) VOD_PP(0, false);
+        if (store_dtype == 1 && dense) VOD_PP(1, true);
+        if (store_dtype == 1 && !dense) VOD_PP(1, false);
+#undef VOD_PP
+    }
+#ifdef VODHIP_ABLATION  // timing-only builds (wrong results): which resource bounds the K loop?
+    if (store_dtype == 0 && tile >= 11 && tile <= 13 && !dense) {
+        if (tile == 11) return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 1>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+        if (tile == 12) return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 2>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+        if (tile == 13) return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 3>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+    }
+    if (store_dtype == 0 && tile == 15 && !dense)  // DMA-only, 4-slot ring of 32-deep slices
+        return launch_filter_cfg<0, 256, 256, 2, 4, 32, 4, false, 4>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+    if (store_dtype == 0 && tile == 16 && !dense)  // ring without DMA in the loop
+        return launch_filter_cfg<0, 256, 256, 2, 4, 32, 4, false, 1>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+    if (store_dtype == 0 && tile == 22)  // tile 2 WITHOUT the rotated K order (A/B reference)
+        return dense ? launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, true, 10>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream)
+                     : launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 10>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+#define VOD_KNOB(T, AB) if (store_dtype == 0 && tile == T) return dense ? launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, true, AB>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream) : launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, AB>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+    VOD_KNOB(25, 13)  // WITH s_setprio flips around the MFMA groups
+    VOD_KNOB(26, 12)  // static priority for waves 4..7 instead
+#undef VOD_KNOB
+    if (store_dtype == 0 && tile == 20 && !dense)  // DMA-only, corpus operand only
+        return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 7>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+    if (store_dtype == 0 && tile == 21 && !dense)  // DMA-only, query operand only
+        return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 8>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+    if (store_dtype == 0 && tile == 19 && !dense)  // DMA-only, blocked source layout
+        return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 6>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+    if (store_dtype == 0 && (tile == 18 || tile == 23 || tile == 24) && !dense) {  // stamped builds of tile 7 (23: no ds_read, 24: no MFMA)
+        const int n_xtiles = (int)((row_end - row_begin + 255) / 256);
+        const int n_qtiles = (int)(nq_pad / 256);
+        const unsigned grid = (unsigned)((n_xtiles + 7) / 8) * 8u * (unsigned)n_qtiles;
+        auto kern = mips_filter_spec_kernel<0, 32, 4, 4, false, true>;
+        if (tile == 23) kern = mips_filter_spec_kernel<0, 32, 4, 4, false, true, 1>;
+        if (tile == 24) kern = mips_filter_spec_kernel<0, 32, 4, 4, false, true, 2>;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(768), 128 * 1024, stream, (const uint16_t*)store, (const uint16_t*)q_pad,
+                           (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s, ws.thr_key,
+                           ws.cand, ws.cnt, (int)ws.cap, ws.overflow);
+        return hipGetLastError();
+    }
+    if (store_dtype == 0 && tile == 17 && !dense)  // stamped build of tile 2
+        return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 5>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+    if (store_dtype == 0 && tile == 14 && !dense) {
+        return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 4>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+    }
+    if (store_dtype == 0 && tile >= 11 && tile <= 24 && dense)
+        return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, true>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+#endif
 #undef VOD_FILTER
     return hipErrorInvalidValue;
 }
