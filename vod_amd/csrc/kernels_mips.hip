@@ -145,7 +145,7 @@ void mips_filter_kernel(
     for (int t = 0; t < NA; ++t) {
         const int r = (wave * NA + t) * RPI + st_row;
         const int c = st_slot ^ swz_of_row(r);
-        a_src[t] = (const char*)X + ((size_t)(x0 + r) * dim_pad + c * 8) * 2;
+        a_src[t] = (const char*)X + ((size_t)((ABLATE == 14 ? row_begin + (xt & 15) * BM : x0) + r) * dim_pad + c * 8) * 2;  // 14: timing-only, corpus tile always L2-hot
         if constexpr (ABLATE == 6)  // [8-row group][k-slice] blocks of 1 KiB: one wave-instruction = one contiguous KiB
             a_src[t] = (const char*)X + ((size_t)(x0 / RPI + wave * NA + t) * (dim_pad / BK)) * 1024 + lane * 16;
     }
@@ -211,7 +211,7 @@ void mips_filter_kernel(
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int q = q0 + wn * TN + j * 32 + fr;
-            thr[j] = (q < nq && ABLATE != 2 && ABLATE != 4 && !(ABLATE >= 6 && ABLATE <= 8)) ? thr_s[q] : __builtin_inff();
+            thr[j] = (q < nq && ABLATE != 2 && ABLATE != 4 && ABLATE != 14 && !(ABLATE >= 6 && ABLATE <= 8)) ? thr_s[q] : __builtin_inff();
         }
     }
 
@@ -293,6 +293,18 @@ void mips_filter_kernel(
         for (; t + NSTAGE - 1 < nk; ++t) {
             wait_vmcnt<(NSTAGE - 2) * G>();
             if constexpr (ABLATE != 3) __builtin_amdgcn_s_barrier();
+            if constexpr (ABLATE == 15) {
+                // L2 touch-prefetch of the NEXT corpus tile of this XCD label (xt + 8): the n_qtiles workgroups that
+                // share tile xt each touch 1/n_qtiles of its 128-B lines, BM/n_qtiles lines per K slice, one lane per
+                // line, dumped into a junk LDS area (no VGPR, counted by vmcnt like the other LDS-DMAs).
+                const int x0n = x0 + 8 * BM;
+                const int per_slice = BM / n_qtiles;  // lines per slice for this workgroup
+                if (x0n + BM <= row_end && wave == (t % NWAVES) && lane < per_slice) {
+                    const size_t line = (size_t)qt * (size_t)(per_slice * nk) + (size_t)t * per_slice + lane;
+                    const char* src = (const char*)X + (size_t)x0n * dim_pad * 2 + line * 128;
+                    __builtin_amdgcn_global_load_lds((const AS1 void*)src, (AS3 void*)(smem + NSTAGE * STAGE_BYTES + wave * 256), 4, 0, 0);
+                }
+            }
             kslice(t, std::true_type{});
         }
         for (; t < nk; ++t) {  // tail: nothing left to fetch, the ring drains
@@ -804,7 +816,7 @@ static hipError_t launch_filter_cfg(const void* store, const void* q_pad, int64_
     const int xgroups = (n_xtiles + 7) / 8;
     const unsigned grid = (unsigned)xgroups * 8u * (unsigned)n_qtiles;
     constexpr int threads = WM * WN * 64;
-    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * BK * 2;
+    constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * BK * 2 + (ABLATE == 15 ? 2048 : 0);
     auto kern = mips_filter_kernel<DT, BM, BN, WM, WN, BK, NSTAGE, DENSE, ABLATE, PINGPONG>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -887,6 +899,8 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
 #define VOD_KNOB(T, AB) if (store_dtype == 0 && tile == T) return dense ? launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, true, AB>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream) : launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, AB>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
     VOD_KNOB(25, 13)  // WITH s_setprio flips around the MFMA groups
     VOD_KNOB(26, 12)  // static priority for waves 4..7 instead
+    VOD_KNOB(27, 14)  // corpus operand always L2-hot (timing only)
+    VOD_KNOB(28, 15)  // L2 touch-prefetch of the next corpus tile (results stay exact)
 #undef VOD_KNOB
     if (store_dtype == 0 && tile == 20 && !dense)  // DMA-only, corpus operand only
         return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 7>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
