@@ -66,7 +66,7 @@ struct vodhip_index {
     PendingSearch pending;
     // tunables
     int64_t cand_cap = 4096;
-    int64_t dense_rows = 2048;
+    int64_t dense_rows = 1024;
     int64_t growth_x100 = 0;  // 0 = derive from k
     int64_t force_safe = 0;
     int64_t tile = 0;
@@ -160,7 +160,7 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
 
     const int q_es = elem_size(ps.q_dtype);
     int tile = (int)ix->tile;
-    if (tile == 0) tile = ps.nq > 128 ? 2 : 1;
+    if (tile == 0) tile = ps.nq > 128 ? 8 : 1;  // 8 = 256x256 tile on v_mfma_f32_16x16x32 (fastest on C3), 1 = 128x128
     const int64_t bn = filter_tile_cols(tile);
     if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
     const SearchWorkspace& ws = ix->ws;
