@@ -94,7 +94,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN * 64 * ((160 * 1024) / (NSTAG
 void mips_filter_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
     int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
-    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow) {
+    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, int flags) {
+    const bool krot_on = (flags & 1) != 0;  // FILTER_FLAG_KROT
+
     constexpr int NWAVES = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;  // per-wave tile
     constexpr int MI = TM / 32, NJ = TN / 32;  // 32x32 blocks per wave
@@ -160,14 +162,16 @@ void mips_filter_kernel(
     // K is a reduction, so its order is free: the n_qtiles workgroups that share a corpus tile (they run at the same
     // time on one XCD) walk the K slices in ROTATED orders.  Each slice is then fetched from HBM by exactly one of
     // them and found in L2 by the others a little later, instead of all of them queueing on the same HBM miss
-    // (measured on C3: filter kernel 15.9 -> 8.3 ms per batch; ABLATE == 10 switches it off for A/B runs).
+    // Measured on C3: the DMA-only loop gets 17 % faster, the full kernel does not, and HBM traffic doubles (the
+    // over-subscribed 4 MiB L2 evicts a slice before the last sharer reads it: FETCH_SIZE 15.4 -> 34 GB per batch),
+    // so it is OFF by default and only kept as an experiment knob ("krot" parameter -> bit 0 of the `flags` argument).
     const int nk_ = dim_pad / BK;
-    const int krot = (qt * nk_) / n_qtiles;
+    const int krot = krot_on ? (qt * nk_) / n_qtiles : 0;  // rotation is opt-in (flags bit 0): see note above
     // `part` of `nparts` of slice `ks`'s LDS-DMA into ring slot ks % NSTAGE
     auto stage_part = [&](int ks, int part, int nparts) {
         char* sa = smem + (ks % NSTAGE) * STAGE_BYTES;
         char* sb = sa + A_BYTES;
-        const int kbyte = ABLATE == 6 ? ks * 1024 : (ABLATE != 10 ? ((ks + krot) % nk_) * ROW_BYTES : ks * ROW_BYTES);
+        const int kbyte = ABLATE == 6 ? ks * 1024 : ((ks + krot) % nk_) * ROW_BYTES;
 #pragma unroll
         for (int u = 0; u < G; ++u) {
             if ((u * nparts) / G != part) continue;
@@ -490,7 +494,9 @@ template <int DT, int BK, int NSTAGE, int NL, bool DENSE, bool STAMP = false, in
 __global__ __launch_bounds__((8 + NL) * 64, 3) void mips_filter_spec_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
     int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
-    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow) {
+    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, int flags) {
+    const bool krot_on = (flags & 1) != 0;  // FILTER_FLAG_KROT
+
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NCW = 8;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NJ = TN / 32;
     constexpr int ROW_BYTES = BK * 2, CH = ROW_BYTES / 16, RPI = 64 / CH, KK = BK / 16;
@@ -521,7 +527,7 @@ __global__ __launch_bounds__((8 + NL) * 64, 3) void mips_filter_spec_kernel(
         __builtin_amdgcn_s_setprio(3);
         const int lw = wave - NCW;
         const int st_row = lane / CH, st_slot = lane % CH;
-        const int krot = (qt * nk) / n_qtiles;  // rotated K order per q-tile workgroup (see mips_filter_kernel)
+        const int krot = krot_on ? (qt * nk) / n_qtiles : 0;  // optional rotated K order (see mips_filter_kernel)
         auto stage = [&](int ks) {
             char* sbase = smem + (ks % NSTAGE) * STAGE_BYTES;
             const int kbyte = ((ks + krot) % nk) * ROW_BYTES;
@@ -675,7 +681,9 @@ template <int DT, bool DENSE>
 __global__ __launch_bounds__(512, 2) void mips_filter16_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
     int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
-    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow) {
+    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, int flags) {
+    const bool krot_on = (flags & 1) != 0;  // FILTER_FLAG_KROT
+
     constexpr int BM = 256, BN = 256, WN = 4, NWAVES = 8, BK = 64, NSTAGE = 2;
     constexpr int TM = 128, TN = 64;
     constexpr int MB = TM / 16, NB16 = TN / 16;  // 8 x 4 blocks of 16x16 per wave
@@ -696,7 +704,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter16_kernel(
     const int x0 = row_begin + xt * BM;
     const int q0 = qt * BN;
     const int nk = dim_pad / BK;
-    const int krot = (qt * nk) / n_qtiles;
+    const int krot = krot_on ? (qt * nk) / n_qtiles : 0;
 
     const int st_row = lane >> 3, st_slot = lane & 7;
     const char* a_src[NA];
@@ -1026,7 +1034,7 @@ static hipError_t launch_filter_cfg(const void* store, const void* q_pad, int64_
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, (const uint16_t*)store, (const uint16_t*)q_pad,
                        (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s, ws.thr_key,
-                       ws.cand, ws.cnt, (int)ws.cap, ws.overflow);
+                       ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.flags);
     return hipGetLastError();
 }
 
@@ -1059,7 +1067,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, (const uint16_t*)store, (const uint16_t*)q_pad,   \
                            (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s,          \
-                           ws.thr_key, ws.cand, ws.cnt, (int)ws.cap, ws.overflow);                                     \
+                           ws.thr_key, ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.flags);                                     \
         return hipGetLastError();                                                                                      \
     }
         if (store_dtype == 0 && dense) VOD_K16(0, true)
@@ -1080,7 +1088,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, stream, (const uint16_t*)store, (const uint16_t*)q_pad,   \
                            (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s,          \
-                           ws.thr_key, ws.cand, ws.cnt, (int)ws.cap, ws.overflow);                                     \
+                           ws.thr_key, ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.flags);                                     \
         return hipGetLastError();                                                                                      \
     }
         if (tile == 6) {
@@ -1140,7 +1148,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(768), 128 * 1024, stream, (const uint16_t*)store, (const uint16_t*)q_pad,
                            (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s, ws.thr_key,
-                           ws.cand, ws.cnt, (int)ws.cap, ws.overflow);
+                           ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.flags);
         return hipGetLastError();
     }
     if (store_dtype == 0 && tile == 17 && !dense)  // stamped build of tile 2

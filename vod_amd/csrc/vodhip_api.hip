@@ -70,6 +70,7 @@ struct vodhip_index {
     int64_t growth_x100 = 0;  // 0 = derive from k
     int64_t force_safe = 0;
     int64_t tile = 0;
+    int64_t krot = 0;
     int64_t profile = 0;  // 1: bracket every filter launch with HIP events (bench / roofline accounting)
     // stats
     int64_t last_overflow = 0, last_chunks = 0, last_safe_reruns = 0;
@@ -163,6 +164,7 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
     if (tile == 0) tile = ps.nq > 128 ? 8 : 1;  // 8 = 256x256 tile on v_mfma_f32_16x16x32 (fastest on C3), 1 = 128x128
     const int64_t bn = filter_tile_cols(tile);
     if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
+    ix->ws.flags = ix->krot ? 1 : 0;
     const SearchWorkspace& ws = ix->ws;
     HIP_OK(hipMemsetAsync(ws.overflow, 0, sizeof(unsigned int), stream));
     for (int64_t qb = 0; qb < ps.nq; qb += MAX_NQ_PER_PASS) {
@@ -391,6 +393,8 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
         ix->growth_x100 = value;  // growth factor * 100; 0 = derive from k
     } else if (!strcmp(key, "force_safe")) {
         ix->force_safe = value;
+    } else if (!strcmp(key, "krot")) {
+        ix->krot = value;
     } else if (!strcmp(key, "profile")) {
         ix->profile = value;
     } else if (!strcmp(key, "tile")) {

@@ -21,6 +21,7 @@ struct SearchWorkspace {
     int64_t nq_cap = 0;
     int64_t cap = 0;
     int64_t kp = 0;
+    int flags = 0;  // bit 0: rotated K order per q-tile workgroup (experiment knob)
 };
 
 // ---- launchers (kernels_mips.hip) -------------------------------------------------------------
