@@ -147,6 +147,24 @@ int vodhip_retrieval_backward(const void* q, const void* s, int enc_dtype, int s
                               int64_t B, int64_t D, int64_t H, const float* d_scores, const float* grad_out,
                               float* dq, float* ds, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * H7  labeled priority sampling of the merged candidates (the collate stage right after the merge).
+ * Replaces: _labeled_priority_sampling_2d_ / _labeled_priority_sampling_1d_ / _priority_sampling_1d
+ *           (src/vod_dataloaders/core/sample.py:160-219,245-352) and the numba log-softmax helpers
+ *           (src/vod_dataloaders/core/numpy_ops.py:162-216).
+ * DEVICE pointers.  scores float32 [nq, width]; labels uint8 [nq, width] (non-zero = positive);
+ * noise float32 [nq, width] = Exp(1) draws supplied by the caller (the reference draws them with
+ * np.random.exponential on the host, sample.py:398), width <= 4096.
+ * Outputs: samples int64 [nq, k_total] = column index into the row (-1 padded), log_weights float32
+ * [nq, k_total] (-inf padded), out_labels uint8 [nq, k_total], lse float32 [nq, 2] (positives, negatives).
+ * Reference quirks kept: support truncation masks entries >= the
+ * `max_support_size`-th largest; ties in the priority keys are broken by the smaller column.
+ * ------------------------------------------------------------------------------------------- */
+int vodhip_priority_sample(const float* scores, const uint8_t* labels, const float* noise, int64_t nq, int width,
+                           int k_positive, int k_total, float temperature, int max_support_size, int normalized,
+                           int64_t* out_samples, float* out_log_weights, uint8_t* out_labels, float* out_lse,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,110 @@
+"""Labeled priority sampling of the merged candidates on the GPU (host wrapper over `vodhip_priority_sample`).
+
+Mirror of `sample_search_results` / `labeled_priority_sampling`
+(/root/reference/src/vod_dataloaders/core/sample.py:22-157): same arguments, same
+`PrioritySampledSections` result (batch of sampled indices / scores / labels, log-weights, lse_pos / lse_neg,
+max_sampling_id, sampled raw scores).  The Exp(1) noise is drawn on the host with NumPy exactly where the
+reference draws it (`np.random.exponential(size=scores.shape).astype(dtype)`, sample.py:398), so a seeded
+`np.random` gives the same draws; the per-row selection runs in one kernel launch.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+import torch
+
+from vod_amd import _native
+from vod_amd import types as vt
+
+
+@dataclasses.dataclass(frozen=True)
+class PrioritySampledSections:
+    batch: vt.RetrievalBatch
+    log_weights: np.ndarray
+    max_sampling_id: np.ndarray
+    lse_pos: np.ndarray
+    lse_neg: np.ndarray
+    raw_scores: dict[str, np.ndarray]
+
+
+def labeled_priority_sampling_tensors(
+    scores: torch.Tensor,
+    labels: torch.Tensor,
+    noise: torch.Tensor,
+    k_positive: int,
+    k_total: int,
+    normalized: bool = True,
+    temperature: float = 1.0,
+    max_support_size: int | None = None,
+) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Device-tensor API: returns (samples i64 [nq,k_total], log_weights f32, labels bool, lse f32 [nq,2])."""
+    lib = _native.load_library()
+    if not scores.is_cuda:
+        raise _native.NativeLibraryError("labeled_priority_sampling_tensors needs device tensors (there is no CPU path)")
+    max_support_size = max_support_size or -1
+    if max_support_size >= 0:
+        max_support_size = max(max_support_size, k_total)  # sample.py:126-128
+    nq, width = scores.shape
+    dev = scores.device
+    sc = scores.contiguous().float()
+    lb = (labels > 0).to(torch.uint8).contiguous()
+    nz = noise.contiguous().float()
+    samples = torch.empty((nq, k_total), dtype=torch.int64, device=dev)
+    logw = torch.empty((nq, k_total), dtype=torch.float32, device=dev)
+    olab = torch.empty((nq, k_total), dtype=torch.uint8, device=dev)
+    lse = torch.empty((nq, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _native.check(
+            lib.vodhip_priority_sample(
+                sc.data_ptr(), lb.data_ptr(), nz.data_ptr(), nq, width, int(k_positive), int(k_total), float(temperature),
+                int(max_support_size), int(bool(normalized)), samples.data_ptr(), logw.data_ptr(), olab.data_ptr(),
+                lse.data_ptr(), _native.current_stream_ptr(dev),
+            )
+        )
+    return samples, logw, olab.bool(), lse
+
+
+def sample_search_results(
+    *,
+    search_results: vt.RetrievalBatch,
+    raw_scores: dict[str, np.ndarray],
+    total: None | int,
+    max_pos_sections: None | int,
+    temperature: float = 1.0,
+    max_support_size: None | int = None,
+    device: int = 0,
+) -> PrioritySampledSections:
+    """Sample positive and negative sections with per-label priority sampling (sample.py:22-84)."""
+    total = total or search_results.shape[-1]
+    max_pos_sections = max_pos_sections or total
+    dev = torch.device("cuda", device)
+    scores_ref = np.ascontiguousarray(search_results.scores, dtype=np.float32)
+    indices_ref = search_results.indices
+    labels_ref = np.zeros_like(scores_ref, dtype=np.bool_) if search_results.labels is None else search_results.labels > 0
+    noise = np.random.exponential(size=scores_ref.shape).astype(scores_ref.dtype)  # same draw as the reference
+    t_scores = torch.from_numpy(scores_ref).to(dev)
+    local, logw, labels, lse = labeled_priority_sampling_tensors(
+        t_scores, torch.from_numpy(labels_ref).to(dev), torch.from_numpy(noise).to(dev), max_pos_sections, total,
+        normalized=True, temperature=temperature, max_support_size=max_support_size,
+    )
+    width = scores_ref.shape[1]
+    gidx = torch.where(local < 0, local + width, local)  # np.take_along_axis semantics for the -1 pads (last column)
+    take = lambda a: torch.gather(torch.from_numpy(np.ascontiguousarray(a)).to(dev), 1, gidx)  # noqa: E731
+    indices = take(indices_ref)
+    scores = torch.gather(t_scores, 1, gidx)
+    sampled_raw = {k: take(v).cpu().numpy() for k, v in raw_scores.items()}
+    # rank diagnostic (sample.py:64-70): negatives of the pool scoring at least the lowest sampled finite negative
+    neg_finite = (~labels) & torch.isfinite(scores)
+    min_neg = torch.where(neg_finite, scores, torch.full_like(scores, float("inf"))).amin(dim=-1, keepdim=True)
+    t_labels_ref = torch.from_numpy(labels_ref).to(dev)
+    larger = (~t_labels_ref) & torch.isfinite(t_scores) & (t_scores >= min_neg)
+    max_sampling_id = larger.float().sum(dim=-1)
+    return PrioritySampledSections(
+        batch=vt.RetrievalBatch(indices=indices.cpu().numpy(), scores=scores.cpu().numpy(), labels=labels.cpu().numpy()),
+        max_sampling_id=max_sampling_id.cpu().numpy(),
+        lse_pos=lse[:, 0].cpu().numpy(),
+        lse_neg=lse[:, 1].cpu().numpy(),
+        log_weights=logw.cpu().numpy(),
+        raw_scores=sampled_raw,
+    )

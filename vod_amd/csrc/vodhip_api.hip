@@ -496,4 +496,18 @@ int vodhip_retrieval_backward(const void* q, const void* s, int enc_dtype, int s
     return 0;
 }
 
+int vodhip_priority_sample(const float* scores, const uint8_t* labels, const float* noise, int64_t nq, int width,
+                           int k_positive, int k_total, float temperature, int max_support_size, int normalized,
+                           int64_t* out_samples, float* out_log_weights, uint8_t* out_labels, float* out_lse,
+                           void* stream) {
+    if (nq < 0 || width < 0 || k_total < 1 || k_positive < 0) return fail("invalid sizes");
+    if (width > 4096) return fail("width=%d exceeds 4096 candidates per row", width);
+    if (k_total > 4096) return fail("k_total=%d exceeds 4096", k_total);
+    if (nq == 0) return 0;
+    if (!scores || !labels || !noise || !out_samples || !out_log_weights || !out_labels || !out_lse) return fail("NULL argument");
+    HIP_OK(launch_priority_sample(scores, labels, noise, nq, width, k_positive, k_total, temperature, max_support_size,
+                                  normalized, out_samples, out_log_weights, out_labels, out_lse, (hipStream_t)stream));
+    return 0;
+}
+
 }  // extern "C"

@@ -69,4 +69,10 @@ hipError_t launch_retrieval_backward(const void* q, const void* s, int enc_dtype
                                      int64_t H, const float* d_scores, const float* grad_out, float* dq, float* ds,
                                      hipStream_t stream);
 
+// ---- launchers (kernels_sample.hip) -----------------------------------------------------------
+hipError_t launch_priority_sample(const float* scores, const uint8_t* labels, const float* noise, int64_t nq, int width,
+                                  int k_positive, int k_total, float temperature, int max_support_size, int normalized,
+                                  int64_t* out_samples, float* out_log_weights, uint8_t* out_labels, float* out_lse,
+                                  hipStream_t stream);
+
 }  // namespace vodhip
