@@ -13,7 +13,7 @@ per-shard top-k, merge.  Inputs are synthetic N(0,1) embeddings generated on the
 query seed 4321); queries are resident in HBM when the timed region starts.
 
 Prints ONE JSON line on rank 0 (see the keys below); `roofline` is for the dominant kernel
-(`mips_filter16_kernel`, MFMA-bound at nq = 1024), `cpu_baseline` is the oracle-side faiss-CPU restatement
+(`mips_filter16p_kernel`, MFMA-bound at nq = 1024), `cpu_baseline` is the oracle-side faiss-CPU restatement
 timed on the host cores of this box (rank 0, N = 1 only).
 """
 from __future__ import annotations
@@ -202,7 +202,7 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "mips_filter16_kernel" if (args.tile in (0, 8) and nq > 128) else f"mips_filter_kernel[tile={args.tile}]",
+                "kernel": "mips_filter16p_kernel" if (args.tile in (0, 9) and nq > 128) else f"mips_filter_kernel[tile={args.tile}]",
                 "achieved": achieved_tf,
                 "peak": 2500.0,
                 "unit": "TFLOP/s",

@@ -835,6 +835,167 @@ __global__ __launch_bounds__(512, 2) void mips_filter16_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// persistent flavour of mips_filter16_kernel: one workgroup per CU walks a list of corpus tiles
+// ------------------------------------------------------------------------------------------------
+// Same tile, staging and MFMA shape as mips_filter16_kernel.  The grid is (a multiple of 8 * n_qtiles) <= #CUs and a
+// workgroup keeps its q-tile while it steps through corpus tiles xt, xt + G/n_qtiles, ...  The K slices of
+// consecutive tiles form ONE stream through the two LDS slots: the LDS-DMA of the next tile's first slice is issued
+// during the current tile's last slice, so its HBM latency hides behind that slice's MFMAs and the threshold-filter
+// epilogue instead of opening every tile with an idle matrix pipe (measured prologue: ~2,200 cycles of a 48,000
+// cycle tile), and there is no per-tile workgroup launch / drain.
+template <int DT>
+__global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
+    const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
+    int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
+    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, int flags) {
+    constexpr int BM = 256, BN = 256, WN = 4, NWAVES = 8, BK = 64, NSTAGE = 2;
+    constexpr int TM = 128, TN = 64;
+    constexpr int MB = TM / 16, NB16 = TN / 16;
+    constexpr int ROW_BYTES = BK * 2, RPI = 8;
+    constexpr int A_BYTES = BM * ROW_BYTES, STAGE_BYTES = (BM + BN) * ROW_BYTES;
+    constexpr int NA = BM / RPI / NWAVES, NBI = BN / RPI / NWAVES, G = NA + NBI;
+    (void)flags;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, jj = bid >> 3;
+    const int qt = jj % n_qtiles;
+    const int xt0 = (jj / n_qtiles) * 8 + xcd;
+    const int xt_step = (int)gridDim.x / n_qtiles;  // gridDim.x is a multiple of 8 * n_qtiles
+    if (xt0 >= n_xtiles) return;
+    const int n_my = (n_xtiles - 1 - xt0) / xt_step + 1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int q0 = qt * BN;
+    const int nk = dim_pad / BK;
+    const size_t tile_step_bytes = (size_t)xt_step * BM * dim_pad * 2;
+
+    const int st_row = lane >> 3, st_slot = lane & 7;
+    const char* a_src[NA];
+    const char* b_src[NBI];
+#pragma unroll
+    for (int t = 0; t < NA; ++t) {
+        const int r = (wave * NA + t) * RPI + st_row;
+        a_src[t] = (const char*)X + ((size_t)(row_begin + xt0 * BM + r) * dim_pad + (st_slot ^ ((r >> 1) & 7)) * 8) * 2;
+    }
+#pragma unroll
+    for (int t = 0; t < NBI; ++t) {
+        const int r = (wave * NBI + t) * RPI + st_row;
+        b_src[t] = (const char*)Q + ((size_t)(q0 + r) * dim_pad + (st_slot ^ ((r >> 1) & 7)) * 8) * 2;
+    }
+    auto stage_part = [&](int slot, int kbyte, int part, int nparts) {
+        char* sa = smem + slot * STAGE_BYTES;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            if ((u * nparts) / G != part) continue;
+            if (u < NA)
+                glds16(a_src[u] + kbyte, sa + (wave * NA + u) * RPI * ROW_BYTES);
+            else
+                glds16(b_src[u - NA] + kbyte, sb + (wave * NBI + (u - NA)) * RPI * ROW_BYTES);
+        }
+    };
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int swz = (fr >> 1) & 7;
+    const int a_row_off = (wm * TM + fr) * ROW_BYTES;
+    const int b_row_off = A_BYTES + (wn * TN + fr) * ROW_BYTES;
+
+    stage_part(0, 0, 0, 1);
+    float thr[NB16];
+#pragma unroll
+    for (int j = 0; j < NB16; ++j) {
+        const int q = q0 + wn * TN + j * 16 + fr;
+        thr[j] = (q < nq) ? thr_s[q] : __builtin_inff();
+    }
+
+    int g = 0;  // global slice counter of this workgroup: LDS slot = g & 1
+    for (int it = 0; it < n_my; ++it) {
+        const int x0 = row_begin + (xt0 + it * xt_step) * BM;
+        f32x4 acc[MB][NB16];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int t = 0; t < nk; ++t, ++g) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            const char* base = smem + (g & 1) * STAGE_BYTES;
+            // what to fetch during this slice: the next slice of this tile, or slice 0 of the next tile
+            bool pre = true;
+            int kbyte = (t + 1) * ROW_BYTES;
+            if (t + 1 == nk) {
+                kbyte = 0;
+                pre = it + 1 < n_my;
+                if (pre) {
+#pragma unroll
+                    for (int u = 0; u < NA; ++u) a_src[u] += tile_step_bytes;
+                }
+            }
+            const int nslot = (g + 1) & 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int slot_off = ((4 * ks + fq) ^ swz) << 4;
+                u32x4 bf[NB16], a0[4], a1[4];
+#pragma unroll
+                for (int j = 0; j < NB16; ++j) bf[j] = *(const u32x4*)(base + b_row_off + j * 16 * ROW_BYTES + slot_off);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a0[i] = *(const u32x4*)(base + a_row_off + i * 16 * ROW_BYTES + slot_off);
+                if (pre) stage_part(nslot, kbyte, 2 * ks, 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a1[i] = *(const u32x4*)(base + a_row_off + (4 + i) * 16 * ROW_BYTES + slot_off);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB16; ++j) acc[i][j] = mfma16<DT>(a0[i], bf[j], acc[i][j]);
+                if (pre) stage_part(nslot, kbyte, 2 * ks + 1, 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB16; ++j) acc[4 + i][j] = mfma16<DT>(a1[i], bf[j], acc[4 + i][j]);
+            }
+        }
+
+        // threshold filter of this tile (the next tile's first slice is already in flight)
+#pragma unroll
+        for (int j = 0; j < NB16; ++j) {
+            const int q = q0 + wn * TN + j * 16 + fr;
+            float m = acc[0][j][0];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[i][j][r]);
+            const bool hit = m >= thr[j];
+            if (__any(hit)) {
+                if (hit) {
+                    const key_t64 tk = thr_key[q];
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = x0 + wm * TM + i * 16 + 4 * fq + r;
+                            const float sc = acc[i][j][r];
+                            if (sc >= thr[j] && row < row_end) {
+                                const key_t64 key = make_key(sc, (unsigned)row);
+                                if (key > tk) {
+                                    const unsigned slot = atomicAdd(&cnt[q], 1u);
+                                    if (slot < (unsigned)cap)
+                                        cand[(size_t)q * cap + slot] = key;
+                                    else
+                                        atomicOr(overflow, 1u);
+                                }
+                            }
+                        }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // select kernel: fold the chunk's candidates into the running sorted top-k, tighten the threshold
 // ------------------------------------------------------------------------------------------------
 // Descending bitonic sort of P (power of two) keys in LDS by 256 threads.  Each thread gathers up to CE_UNROLL
@@ -1055,7 +1216,32 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
     VOD_FILTER_DT(3, 256, 256, 2, 4, 32, 4)   // 128 KB LDS, 4-slot ring, 2 slices in flight across the barrier
     VOD_FILTER_DT(5, 128, 128, 2, 2, 32, 4)   // 64 KB LDS ring, 2 workgroups / CU
 #undef VOD_FILTER_DT
-    if (tile == 8) {  // 256x256, 16x16x32 MFMA shape
+    if (tile == 9 && !dense) {  // persistent 256x256 / 16x16x32: one workgroup per CU streams its list of corpus tiles
+        const int n_xtiles = (int)((row_end - row_begin + 255) / 256);
+        const int n_qtiles = (int)(nq_pad / 256);
+        int dev = 0, n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        const int unit = 8 * n_qtiles;
+        const int total = ((n_xtiles + 7) / 8) * unit;
+        int grid = (n_cu / unit) * unit;
+        if (grid < unit) grid = unit;
+        if (grid > total) grid = total;
+        constexpr size_t lds = 128 * 1024;
+#define VOD_K16P(DT)                                                                                                   \
+    {                                                                                                                  \
+        auto kern = mips_filter16p_kernel<DT>;                                                                         \
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        if (e != hipSuccess) return e;                                                                                 \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, (const uint16_t*)store,                 \
+                           (const uint16_t*)q_pad, (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles,     \
+                           (int)nq, ws.thr_s, ws.thr_key, ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.flags);        \
+        return hipGetLastError();                                                                                      \
+    }
+        if (store_dtype == 0) VOD_K16P(0)
+        if (store_dtype == 1) VOD_K16P(1)
+#undef VOD_K16P
+    }
+    if (tile == 8 || tile == 9) {  // 256x256, 16x16x32 MFMA shape (9: dense chunk of the persistent flavour)
         const int n_xtiles = (int)((row_end - row_begin + 255) / 256);
         const int n_qtiles = (int)(nq_pad / 256);
         const unsigned grid = (unsigned)((n_xtiles + 7) / 8) * 8u * (unsigned)n_qtiles;

@@ -161,7 +161,7 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
 
     const int q_es = elem_size(ps.q_dtype);
     int tile = (int)ix->tile;
-    if (tile == 0) tile = ps.nq > 128 ? 8 : 1;  // 8 = 256x256 tile on v_mfma_f32_16x16x32 (fastest on C3), 1 = 128x128
+    if (tile == 0) tile = ps.nq > 128 ? 9 : 1;  // 9 = persistent 256x256 tile on v_mfma_f32_16x16x32 (fastest on C3), 1 = 128x128
     const int64_t bn = filter_tile_cols(tile);
     if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
     ix->ws.flags = ix->krot ? 1 : 0;
