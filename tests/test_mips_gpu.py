@@ -53,7 +53,7 @@ def _assert_exact(ix, q, x, k, **kw):
 MANIFEST = json.loads((GOLDEN / "manifest.json").read_text())
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("name", ["flat_ip_exact_small", "flat_ip_exact_768"])
 def test_golden_exact_fixtures(name, tile):
     p = MANIFEST[name]["params"]
@@ -66,7 +66,7 @@ def test_golden_exact_fixtures(name, tile):
         assert ix.get_stat("last_overflow") == 0
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize(
     "n,d,nq,k",
     [
@@ -210,7 +210,7 @@ def _check_gaussian(q, x, s, i, k):
 
 
 @pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_gaussian_matches_fp64_oracle(dtype, tile):
     rng = np.random.default_rng(31)
     n, d, nq, k = 50000, 768, 64, 100

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Summarize gpurun_out/prof_<tag> (rocprofv3 --stats) and gpurun_out/pmc_<tag> (three --pmc passes) into profiles/."""
+import collections, csv, glob, json, shutil, sys
+
+tag, rnd = sys.argv[1], sys.argv[2]  # e.g. v4 r01
+st = glob.glob(f"gpurun_out/prof_{tag}/*/*_kernel_stats.csv")[0]
+shutil.copy(st, f"profiles/{rnd}_{tag}_bench_c3_kernel_stats.csv")
+shutil.copy(f"gpurun_out/bench_c3_{tag}.json", f"profiles/{rnd}_{tag}_bench_c3.json")
+for r in list(csv.DictReader(open(st)))[:4]:
+    print(r["Name"][:60], r["Calls"], r["AverageNs"], r["Percentage"])
+tot = collections.defaultdict(float)
+per_step = 0
+for d in ["sq1", "tcc1", "tcc2"]:
+    rows = list(csv.DictReader(open(glob.glob(f"gpurun_out/pmc_{tag}/{d}/*/*_counter_collection.csv")[0])))
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in rows:
+        if "mips_filter" in r["Kernel_Name"]:
+            per[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    ids = sorted(per)
+    per_step = len(ids) // 3  # bench ran warmup 1 + steps 2
+    for i in ids[-per_step:]:
+        for k, v in per[i].items():
+            tot[k] += v
+s = dict(tot)
+fetch, wr = tot["FETCH_SIZE"] * 1024 * 2, tot["WRITE_SIZE"] * 1024
+s.update(filter_launches_per_step=per_step, hbm_read_bytes_corrected=fetch, hbm_write_bytes=wr,
+         hbm_traffic_bytes_per_step=fetch + wr, algorithmic_bytes_per_step=10_000_000 * 768 * 2 + 1024 * 768 * 2 + 1024 * 100 * 12,
+         mfma_busy_frac=tot["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (tot["GRBM_GUI_ACTIVE"] / 8),
+         l2_hit_rate=tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]),
+         note="FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide streaming reads); separate --pmc passes "
+              "sq1/tcc1/tcc2; sums over the filter launches of one batch")
+json.dump(s, open(f"profiles/{rnd}_{tag}_pmc_filter_per_step.json", "w"), indent=1)
+json.dump({"10000000x768x1024@1": fetch + wr, "_source": f"profiles/{rnd}_{tag}_pmc_filter_per_step.json"}, open("profiles/hbm_traffic.json", "w"))
+print({k: s[k] for k in ["hbm_traffic_bytes_per_step", "algorithmic_bytes_per_step", "mfma_busy_frac", "l2_hit_rate", "SQ_LDS_BANK_CONFLICT"]})

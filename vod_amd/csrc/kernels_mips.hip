@@ -843,7 +843,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter16_kernel(
 // during the current tile's last slice, so its HBM latency hides behind that slice's MFMAs and the threshold-filter
 // epilogue instead of opening every tile with an idle matrix pipe (measured prologue: ~2,200 cycles of a 48,000
 // cycle tile), and there is no per-tile workgroup launch / drain.
-template <int DT>
+template <int DT, bool A3 = false>
 __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
     int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
@@ -897,18 +897,63 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
                 glds16(b_src[u - NA] + kbyte, sb + (wave * NBI + (u - NA)) * RPI * ROW_BYTES);
         }
     };
+    // A3 layout: three corpus slots [0, 3*A_BYTES) + two query slots behind them (all 160 KiB of LDS): the corpus
+    // operand (HBM first touch, slow) is fetched TWO slices ahead, the L2-hot query operand one slice ahead.
+    constexpr int B_BASE_A3 = 3 * A_BYTES;
+    auto stage_a = [&](int aslot, int kbyte, int half) {  // half 0|1: first / second NA/2 wave-instructions
+#pragma unroll
+        for (int u = 0; u < NA; ++u)
+            if (u / (NA / 2) == half) glds16(a_src[u] + kbyte, smem + aslot * A_BYTES + (wave * NA + u) * RPI * ROW_BYTES);
+    };
+    auto stage_b = [&](int bslot, int kbyte, int half) {
+#pragma unroll
+        for (int u = 0; u < NBI; ++u)
+            if (u / (NBI / 2) == half)
+                glds16(b_src[u] + kbyte, smem + B_BASE_A3 + bslot * A_BYTES + (wave * NBI + u) * RPI * ROW_BYTES);
+    };
 
     const int fr = lane & 15, fq = lane >> 4;
     const int swz = (fr >> 1) & 7;
     const int a_row_off = (wm * TM + fr) * ROW_BYTES;
     const int b_row_off = A_BYTES + (wn * TN + fr) * ROW_BYTES;
 
-    stage_part(0, 0, 0, 1);
+    // thresholds first, and retired (the dummy use makes the compiler wait HERE): a later compiler-inserted
+    // vmcnt wait for them would also drain the LDS-DMAs that are meant to stay in flight across the epilogue
     float thr[NB16];
 #pragma unroll
     for (int j = 0; j < NB16; ++j) {
         const int q = q0 + wn * TN + j * 16 + fr;
         thr[j] = (q < nq) ? thr_s[q] : __builtin_inff();
+    }
+#pragma unroll
+    for (int j = 0; j < NB16; ++j) asm volatile("" : "+v"(thr[j]));
+    // stream state of the A3 variant: next slice to fetch for each operand (global slice index, tile-local k index)
+    const int S = n_my * nk;
+    int sa_next = 0, ta_next = 0, sb_next = 0, tb_next = 0;
+    auto issue_a = [&](int half) {  // corpus slice sa_next into slot sa_next % 3; bookkeeping advances after half 1
+        stage_a(sa_next % 3, ta_next * ROW_BYTES, half);
+        if (half == 1) {
+            ++sa_next;
+            if (++ta_next == nk) {
+                ta_next = 0;
+#pragma unroll
+                for (int u = 0; u < NA; ++u) a_src[u] += tile_step_bytes;
+            }
+        }
+    };
+    auto issue_b = [&](int half) {
+        stage_b(sb_next & 1, tb_next * ROW_BYTES, half);
+        if (half == 1) {
+            ++sb_next;
+            if (++tb_next == nk) tb_next = 0;
+        }
+    };
+    if constexpr (A3) {
+        issue_a(0); issue_a(1);                    // A(0)
+        issue_b(0); issue_b(1);                    // B(0)
+        if (S > 1) { issue_a(0); issue_a(1); }     // A(1)
+    } else {
+        stage_part(0, 0, 0, 1);
     }
 
     int g = 0;  // global slice counter of this workgroup: LDS slot = g & 1
@@ -921,37 +966,55 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
             for (int j = 0; j < NB16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int t = 0; t < nk; ++t, ++g) {
-            wait_vmcnt<0>();
+            if constexpr (A3) {
+                // everything but the 4 youngest LDS-DMAs (= the corpus slice g+1, if it exists) has landed
+                if (g + 1 < S) wait_vmcnt<NA>(); else wait_vmcnt<0>();
+            } else {
+                wait_vmcnt<0>();
+            }
             __builtin_amdgcn_s_barrier();
             const char* base = smem + (g & 1) * STAGE_BYTES;
+            const char* base_a = A3 ? smem + (g % 3) * A_BYTES - 0 : base;
+            const char* base_b = A3 ? smem + B_BASE_A3 + (g & 1) * A_BYTES - A_BYTES : base;  // b_row_off already adds A_BYTES
             // what to fetch during this slice: the next slice of this tile, or slice 0 of the next tile
             bool pre = true;
             int kbyte = (t + 1) * ROW_BYTES;
-            if (t + 1 == nk) {
-                kbyte = 0;
-                pre = it + 1 < n_my;
-                if (pre) {
+            if constexpr (!A3) {
+                if (t + 1 == nk) {
+                    kbyte = 0;
+                    pre = it + 1 < n_my;
+                    if (pre) {
 #pragma unroll
-                    for (int u = 0; u < NA; ++u) a_src[u] += tile_step_bytes;
+                        for (int u = 0; u < NA; ++u) a_src[u] += tile_step_bytes;
+                    }
                 }
             }
+            const bool pre_b = sb_next < S, pre_a = sa_next < S;  // A3: query slice g+1 first, then corpus slice g+2
             const int nslot = (g + 1) & 1;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int slot_off = ((4 * ks + fq) ^ swz) << 4;
                 u32x4 bf[NB16], a0[4], a1[4];
 #pragma unroll
-                for (int j = 0; j < NB16; ++j) bf[j] = *(const u32x4*)(base + b_row_off + j * 16 * ROW_BYTES + slot_off);
+                for (int j = 0; j < NB16; ++j) bf[j] = *(const u32x4*)(base_b + b_row_off + j * 16 * ROW_BYTES + slot_off);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a0[i] = *(const u32x4*)(base + a_row_off + i * 16 * ROW_BYTES + slot_off);
-                if (pre) stage_part(nslot, kbyte, 2 * ks, 4);
+                for (int i = 0; i < 4; ++i) a0[i] = *(const u32x4*)(base_a + a_row_off + i * 16 * ROW_BYTES + slot_off);
+                if constexpr (A3) {
+                    if (ks == 0) { if (pre_b) issue_b(0); } else { if (pre_a) issue_a(0); }
+                } else {
+                    if (pre) stage_part(nslot, kbyte, 2 * ks, 4);
+                }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a1[i] = *(const u32x4*)(base + a_row_off + (4 + i) * 16 * ROW_BYTES + slot_off);
+                for (int i = 0; i < 4; ++i) a1[i] = *(const u32x4*)(base_a + a_row_off + (4 + i) * 16 * ROW_BYTES + slot_off);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < NB16; ++j) acc[i][j] = mfma16<DT>(a0[i], bf[j], acc[i][j]);
-                if (pre) stage_part(nslot, kbyte, 2 * ks + 1, 4);
+                if constexpr (A3) {
+                    if (ks == 0) { if (pre_b) issue_b(1); } else { if (pre_a) issue_a(1); }
+                } else {
+                    if (pre) stage_part(nslot, kbyte, 2 * ks + 1, 4);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1216,7 +1279,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
     VOD_FILTER_DT(3, 256, 256, 2, 4, 32, 4)   // 128 KB LDS, 4-slot ring, 2 slices in flight across the barrier
     VOD_FILTER_DT(5, 128, 128, 2, 2, 32, 4)   // 64 KB LDS ring, 2 workgroups / CU
 #undef VOD_FILTER_DT
-    if (tile == 9 && !dense) {  // persistent 256x256 / 16x16x32: one workgroup per CU streams its list of corpus tiles
+    if ((tile == 9 || tile == 10) && !dense) {  // persistent 256x256 / 16x16x32 (10: 3 corpus + 2 query LDS slots): one workgroup per CU streams its list of corpus tiles
         const int n_xtiles = (int)((row_end - row_begin + 255) / 256);
         const int n_qtiles = (int)(nq_pad / 256);
         int dev = 0, n_cu = 256;
@@ -1226,10 +1289,11 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         int grid = (n_cu / unit) * unit;
         if (grid < unit) grid = unit;
         if (grid > total) grid = total;
-        constexpr size_t lds = 128 * 1024;
+        const size_t lds = tile == 10 ? 160 * 1024 : 128 * 1024;
 #define VOD_K16P(DT)                                                                                                   \
     {                                                                                                                  \
-        auto kern = mips_filter16p_kernel<DT>;                                                                         \
+        auto kern = tile == 10 ? mips_filter16p_kernel<DT, true> : mips_filter16p_kernel<DT, false>;                  \
+        (void)0;                                                                      \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, (const uint16_t*)store,                 \
@@ -1241,7 +1305,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         if (store_dtype == 1) VOD_K16P(1)
 #undef VOD_K16P
     }
-    if (tile == 8 || tile == 9) {  // 256x256, 16x16x32 MFMA shape (9: dense chunk of the persistent flavour)
+    if (tile == 8 || tile == 9 || tile == 10) {  // 256x256, 16x16x32 MFMA shape (9, 10: dense chunk of the persistent flavours)
         const int n_xtiles = (int)((row_end - row_begin + 255) / 256);
         const int n_qtiles = (int)(nq_pad / 256);
         const unsigned grid = (unsigned)((n_xtiles + 7) / 8) * 8u * (unsigned)n_qtiles;
