@@ -161,7 +161,9 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
 
     const int q_es = elem_size(ps.q_dtype);
     int tile = (int)ix->tile;
-    if (tile == 0) tile = ps.nq > 128 ? 9 : 1;  // 9 = persistent 256x256 tile on v_mfma_f32_16x16x32 (fastest on C3), 1 = 128x128
+    // auto: 128x128 tile (2 workgroups / CU) up to 128 queries; persistent 256x256 tile on v_mfma_f32_16x16x32 above,
+    // with the corpus operand fetched two slices ahead (3 + 2 LDS slots) when ONE q-tile makes every corpus read an HBM miss
+    if (tile == 0) tile = ps.nq > 256 ? 9 : (ps.nq > 128 ? 10 : 1);
     const int64_t bn = filter_tile_cols(tile);
     if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
     ix->ws.flags = ix->krot ? 1 : 0;
