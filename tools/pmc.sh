@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect PMC counters for the bench workload in separate passes (never combined with trace domains other than kernel-trace).
-# usage: tools_pmc.sh <out_subdir> [bench args...]
+# usage: tools/pmc.sh <out_subdir> [bench args...]
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
