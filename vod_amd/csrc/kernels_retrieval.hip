@@ -86,7 +86,7 @@ __device__ float row_kld(const float* __restrict__ ref_row, const float* p_lp, i
     return block_sum(acc, red);
 }
 
-template <int DT, bool S3D>
+template <int DT, bool S3D, bool PRE = false>
 __global__ __launch_bounds__(RT_THREADS) void retrieval_forward_kernel(
     const void* __restrict__ q, const void* __restrict__ s, int D, int H, const float* __restrict__ score,
     const int64_t* __restrict__ relevance, const float* __restrict__ sparse, const float* __restrict__ dense,
@@ -98,19 +98,24 @@ __global__ __launch_bounds__(RT_THREADS) void retrieval_forward_kernel(
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int h = tid; h < H; h += RT_THREADS) qrow[h] = ld_enc<DT>(q, b * H + h);
-    __syncthreads();
-
-    // 1. scores: one wavefront per section, lanes split the hidden dimension (coalesced reads of s)
-    const int64_t s_base = S3D ? b * (int64_t)D * H : 0;
-    for (int d = wave; d < D; d += RT_THREADS / 64) {
-        const int64_t off = s_base + (int64_t)d * H;
-        float acc = 0.f;
-        for (int h = lane; h < H; h += 64) acc = fmaf(qrow[h], ld_enc<DT>(s, off + h), acc);
-        acc = wave_sum(acc);
-        if (lane == 0) S[d] = acc;
+    if constexpr (PRE) {
+        // 1'. the contraction was done by small_gemm_kernel (MFMA) into `retriever_scores`
+        for (int d = tid; d < D; d += RT_THREADS) S[d] = retriever_scores[b * D + d];
+        __syncthreads();
+    } else {
+        for (int h = tid; h < H; h += RT_THREADS) qrow[h] = ld_enc<DT>(q, b * H + h);
+        __syncthreads();
+        // 1. scores: one wavefront per section, lanes split the hidden dimension (coalesced reads of s)
+        const int64_t s_base = S3D ? b * (int64_t)D * H : 0;
+        for (int d = wave; d < D; d += RT_THREADS / 64) {
+            const int64_t off = s_base + (int64_t)d * H;
+            float acc = 0.f;
+            for (int h = lane; h < H; h += 64) acc = fmaf(qrow[h], ld_enc<DT>(s, off + h), acc);
+            acc = wave_sum(acc);
+            if (lane == 0) S[d] = acc;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // 2. padding mask, masked scores out
     const float* score_row = score + b * D;
@@ -273,12 +278,123 @@ __global__ __launch_bounds__(RT_THREADS) void retrieval_ds_kernel(const void* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// small_gemm_kernel: C[M,N] (f32) = alpha * A[M,K] * B[K,N] with arbitrary element strides, f32 accumulate on
+// v_mfma_f32_32x32x2_f32 (exact f32 products and sums, MI355X_MICROARCH "FP32-input MFMA").
+// Used for the in-batch contraction einsum("bh,dh->bd") and its two gradients when the section encodings are the
+// flattened in-batch set (D = B * n_sections ~ 2048): 0.2 GFLOP, launch-latency bound - the point is one MFMA
+// launch instead of every workgroup re-reading the whole section matrix.
+// Workgroup = 4 waves = 64 x 64 tile of C (wave (wm, wn) owns 32 x 32); K tile 32 staged through LDS as f32.
+// ------------------------------------------------------------------------------------------------
+typedef float g_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int DTA, int DTB>
+__global__ __launch_bounds__(256) void small_gemm_kernel(const void* __restrict__ A, int64_t sa_m, int64_t sa_k,
+                                                         const void* __restrict__ Bm, int64_t sb_k, int64_t sb_n,
+                                                         float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                         const float* __restrict__ alpha_ptr, int k_per_split,
+                                                         int64_t c_split_stride) {
+    constexpr int TMN = 64, KT = 32;
+    __shared__ float As[TMN][KT + 1];
+    __shared__ float Bs[KT][TMN + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * TMN, n0 = blockIdx.x * TMN;
+    const float alpha = alpha_ptr ? alpha_ptr[0] : 1.0f;
+    g_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool a_k_fast = sa_k == 1, b_n_fast = sb_n == 1;
+    // split-K: blockIdx.z owns K range [z * k_per_split, ...) and writes its own slab of C (summed by reduce_slabs_kernel
+    // in a fixed order: bitwise reproducible, unlike float atomics)
+    const int k_begin = blockIdx.z * k_per_split;
+    const int k_end = min(K, k_begin + k_per_split);
+    C += (int64_t)blockIdx.z * c_split_stride;
+    K = k_end;
+    for (int k0 = k_begin; k0 < k_end; k0 += KT) {
+        // stage A tile [64][32] and B tile [32][64]; consecutive threads follow the unit-stride dimension
+        for (int e = tid; e < TMN * KT; e += 256) {
+            const int m = a_k_fast ? e / KT : e % TMN, k = a_k_fast ? e % KT : e / TMN;
+            const int gm = m0 + m, gk = k0 + k;
+            As[m][k] = (gm < M && gk < K) ? ld_enc<DTA>(A, gm * sa_m + gk * sa_k) : 0.f;
+        }
+        for (int e = tid; e < KT * TMN; e += 256) {
+            const int k = b_n_fast ? e / TMN : e % KT, n = b_n_fast ? e % TMN : e / KT;
+            const int gk = k0 + k, gn = n0 + n;
+            Bs[k][n] = (gk < K && gn < N) ? ld_enc<DTB>(Bm, gk * sb_k + gn * sb_n) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 2) {
+            // 32x32x2 f32 operands: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]
+            const float a = As[wm * 32 + (lane & 31)][kk + (lane >> 5)];
+            const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int gn = n0 + wn * 32 + (lane & 31);
+        if (gm < M && gn < N) C[(int64_t)gm * ldc + gn] = alpha * acc[r];
+    }
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int64_t count, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float acc = 0.f;
+    for (int z = 0; z < n_slabs; ++z) acc += slabs[(int64_t)z * count + i];
+    out[i] = acc;
+}
+
+static hipError_t launch_small_gemm(int dta, int dtb, const void* A, int64_t sa_m, int64_t sa_k, const void* B, int64_t sb_k,
+                                    int64_t sb_n, float* C, int64_t ldc, int M, int N, int K, const float* alpha,
+                                    hipStream_t stream, int n_splits = 1, int64_t c_split_stride = 0) {
+    const int k_per_split = ((K + n_splits - 1) / n_splits + 31) / 32 * 32;
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)n_splits);
+#define VOD_SG(X, Y)                                                                                              \
+    if (dta == X && dtb == Y) {                                                                                   \
+        hipLaunchKernelGGL((small_gemm_kernel<X, Y>), grid, dim3(256), 0, stream, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, M, N, K, \
+                           alpha, k_per_split, c_split_stride);                                                   \
+        return hipGetLastError();                                                                                 \
+    }
+    VOD_SG(0, 0) VOD_SG(1, 1) VOD_SG(2, 2) VOD_SG(2, 0) VOD_SG(2, 1)
+#undef VOD_SG
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype, int sections_3d, int64_t B, int64_t D,
                                     int64_t H, const float* score, const int64_t* relevance, const float* sparse,
                                     const float* dense, float* retriever_scores, float* d_scores, float* loss, float* kl,
                                     float* workspace, hipStream_t stream) {
     const size_t lds = (size_t)(H + D + 4) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (!sections_3d) {
+        // einsum("bh,dh->bd"): scores[b,d] = sum_h q[b,h] * s[d,h]  ->  A = q [B,H] (k fast), B = s^T (k = h fast)
+        hipError_t e = launch_small_gemm(enc_dtype, enc_dtype, q, H, 1, s, 1, H, retriever_scores, D, (int)B, (int)D, (int)H,
+                                         nullptr, stream);
+        if (e != hipSuccess) return e;
+#define VOD_FWDP(DT)                                                                                                  \
+    if (enc_dtype == DT) {                                                                                            \
+        auto kern = retrieval_forward_kernel<DT, false, true>;                                                        \
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
+        if (e != hipSuccess) return e;                                                                                \
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(RT_THREADS), lds, stream, q, s, (int)D, (int)H, score,       \
+                           relevance, sparse, dense, retriever_scores, d_scores, workspace);                          \
+    }
+        VOD_FWDP(0) VOD_FWDP(1) VOD_FWDP(2)
+#undef VOD_FWDP
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const int64_t n_el = B * D;
+        const unsigned blk = (unsigned)std::min<int64_t>(1024, (n_el + RT_THREADS - 1) / RT_THREADS);
+        hipLaunchKernelGGL(retrieval_finalize_kernel, dim3(blk), dim3(RT_THREADS), 0, stream, workspace, (int)B, n_el, d_scores,
+                           loss, kl);
+        return hipGetLastError();
+    }
 #define VOD_FWD(DT, S3)                                                                                              \
     if (enc_dtype == DT && (sections_3d != 0) == S3) {                                                               \
         auto kern = retrieval_forward_kernel<DT, S3>;                                                                \
@@ -302,6 +418,28 @@ hipError_t launch_retrieval_backward(const void* q, const void* s, int enc_dtype
                                      int64_t H, const float* d_scores, const float* grad_out, float* dq, float* ds,
                                      hipStream_t stream) {
     const size_t lds = (size_t)D * sizeof(float);
+    if (!sections_3d) {
+        // dq[b,h] = go * sum_d dS[b,d] s[d,h]   : A = dS [B,D] (k = d fast), B = s [D,H] (n = h fast)
+        // K = D is long and the output tiny: split K over workgroups into slabs parked in the (not yet written) `ds`
+        // buffer, then sum them in order
+        int n_splits = (int)std::min<int64_t>(16, D / std::max<int64_t>(B, 1));
+        if (n_splits < 2 || D < 512) n_splits = 1;
+        hipError_t e;
+        if (n_splits == 1) {
+            e = launch_small_gemm(2, enc_dtype, d_scores, D, 1, s, H, 1, dq, H, (int)B, (int)H, (int)D, grad_out, stream);
+        } else {
+            e = launch_small_gemm(2, enc_dtype, d_scores, D, 1, s, H, 1, ds, H, (int)B, (int)H, (int)D, grad_out, stream, n_splits,
+                                  B * H);
+            if (e != hipSuccess) return e;
+            const int64_t count = B * H;
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, ds, n_splits,
+                               count, dq);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) return e;
+        // ds[d,h] = go * sum_b dS[b,d] q[b,h]   : A = dS^T [D,B] (m = d fast), B = q [B,H] (n = h fast)
+        return launch_small_gemm(2, enc_dtype, d_scores, 1, D, q, H, 1, ds, H, (int)D, (int)H, (int)B, grad_out, stream);
+    }
 #define VOD_BWD(DT, S3)                                                                                               \
     if (enc_dtype == DT && (sections_3d != 0) == S3) {                                                                \
         hipLaunchKernelGGL((retrieval_dq_kernel<DT, S3>), dim3((unsigned)B), dim3(RT_THREADS), lds, stream, s, (int)D, \
