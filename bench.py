@@ -69,7 +69,7 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from vod_amd.index import HipFlatIndex, merge_topk
+    from vod_amd.index import HipFlatIndex, PackedTopk, merge_topk
 
     tdt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     n_total, d, nq, k = args.rows, args.dim, args.nq, args.k
@@ -95,18 +95,16 @@ def main() -> None:
     gq = torch.Generator(device=dev).manual_seed(4321)
     queries = torch.randn((nq, d), generator=gq, device=dev, dtype=torch.float32).to(tdt)
 
-    out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    packed = PackedTopk(nq, k, dev)  # [scores | ids] record of this rank: the exchange is ONE all-gather of 12*nq*k bytes
+    out_s, out_i = packed.scores, packed.ids
     if world > 1:
-        gat_s = torch.empty((world * nq, k), dtype=torch.float32, device=dev)  # rank-major concatenation
-        gat_i = torch.empty((world * nq, k), dtype=torch.int64, device=dev)
+        gathered = torch.empty((world * packed.nbytes,), dtype=torch.uint8, device=dev)
 
     def step():
         index.search(queries, k, id_base=row_lo, out=(out_s, out_i))
         if world > 1:
-            dist.all_gather_into_tensor(gat_s, out_s)
-            dist.all_gather_into_tensor(gat_i, out_i)
-            return merge_topk(gat_s.view(world, nq, k), gat_i.view(world, nq, k))
+            dist.all_gather_into_tensor(gathered, packed.buffer)
+            return packed.merge_gathered(gathered, world)
         return out_s, out_i
 
     def fence():

@@ -102,6 +102,11 @@ int vodhip_index_get_stat(const vodhip_index_t* index, const char* key, int64_t*
  * ------------------------------------------------------------------------------------------- */
 int vodhip_merge_topk(const float* scores, const int64_t* ids, int n_shards, int64_t nq, int k,
                       int k_out, float* out_scores, int64_t* out_ids, void* stream);
+/* Same, with explicit element strides between shards: lets ONE all-gather move a packed per-rank record
+ * [scores f32 nq*k | ids i64 nq*k] and the merge read both parts in place. */
+int vodhip_merge_topk_strided(const float* scores, int64_t shard_stride_scores, const int64_t* ids,
+                              int64_t shard_stride_ids, int n_shards, int64_t nq, int k, int k_out,
+                              float* out_scores, int64_t* out_ids, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * H4  hybrid score merge (lookup + up to VODHIP_MAX_ENGINES scored engines), one query row per wavefront.

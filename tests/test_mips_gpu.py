@@ -288,3 +288,28 @@ def test_merge_topk_handles_pads_and_ties():
     rs, ri = merge_shard_topk(list(s), list(ids), k)
     np.testing.assert_array_equal(mi.cpu().numpy(), ri)
     np.testing.assert_array_equal(ms.cpu().numpy(), rs)
+
+
+def test_packed_record_merge_matches_plain_merge():
+    """The one-all-gather exchange format: [scores | ids] records laid end to end, merged in place."""
+    from vod_amd.index import PackedTopk, merge_topk
+
+    rng = np.random.default_rng(4)
+    world, nq, k = 8, 37, 100
+    recs, plain_s, plain_i = [], [], []
+    for r in range(world):
+        p = PackedTopk(nq, k, torch.device("cuda", 0))
+        s = -np.sort(-rng.integers(-5, 6, size=(nq, k)).astype(np.float32), axis=1)
+        i = np.sort(rng.choice(100000, size=(nq, k)), axis=1).astype(np.int64) + r * 100000
+        for row in range(nq):
+            o = np.lexsort((i[row], -s[row]))
+            s[row], i[row] = s[row][o], i[row][o]
+        p.scores.copy_(torch.from_numpy(s))
+        p.ids.copy_(torch.from_numpy(i))
+        recs.append(p)
+        plain_s.append(p.scores.clone())
+        plain_i.append(p.ids.clone())
+    gathered = torch.cat([p.buffer for p in recs])
+    ms, mi = recs[0].merge_gathered(gathered, world)
+    rs, ri = merge_topk(torch.stack(plain_s), torch.stack(plain_i))
+    assert torch.equal(ms, rs) and torch.equal(mi, ri)

@@ -49,6 +49,7 @@ SIGNATURES: dict[str, tuple] = {
     "vodhip_index_set_param": (_i32, [_vp, _c.c_char_p, _i64]),
     "vodhip_index_get_stat": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i64)]),
     "vodhip_merge_topk": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "vodhip_merge_topk_strided": (_i32, [_vp, _i64, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "vodhip_merge_hybrid": (
         _i32,
         [_vp, _vp, _i32, _i32, _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_i32), _c.POINTER(_c.c_float), _i64,

@@ -1446,7 +1446,7 @@ __device__ __forceinline__ bool pair_before(float sa, int64_t ia, float sb, int6
 }
 
 __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict__ scores, const int64_t* __restrict__ ids,
-                                                         int n_shards, int64_t nq, int k, int k_out,
+                                                         int64_t stride_s, int64_t stride_i, int n_shards, int64_t nq, int k, int k_out,
                                                          float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int total = n_shards * k;
@@ -1461,8 +1461,8 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
         int64_t id = -1;
         if (i < total) {
             const int sh = i / k, c = i % k;
-            s = scores[((int64_t)sh * nq + q) * k + c];
-            id = ids[((int64_t)sh * nq + q) * k + c];
+            s = scores[(int64_t)sh * stride_s + q * k + c];
+            id = ids[(int64_t)sh * stride_i + q * k + c];
             if (id < 0 || s != s) {
                 id = -1;
                 s = -__builtin_inff();
@@ -1502,8 +1502,8 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
     }
 }
 
-hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_shards, int64_t nq, int k, int k_out,
-                             float* out_scores, int64_t* out_ids, hipStream_t stream) {
+hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int64_t stride_s, int64_t stride_i, int n_shards,
+                             int64_t nq, int k, int k_out, float* out_scores, int64_t* out_ids, hipStream_t stream) {
     if (nq == 0) return hipSuccess;
     const int total = n_shards * k;
     size_t P = 64;
@@ -1517,7 +1517,7 @@ hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_shar
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(256), lds, stream, scores, ids, n_shards, nq, k, k_out,
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(256), lds, stream, scores, ids, stride_s, stride_i, n_shards, nq, k, k_out,
                        out_scores, out_ids);
     return hipGetLastError();
 }

@@ -436,7 +436,18 @@ int vodhip_merge_topk(const float* scores, const int64_t* ids, int n_shards, int
     if (n_shards < 1 || k < 1 || k_out < 1 || nq < 0) return fail("invalid sizes");
     if ((int64_t)n_shards * k > 8192) return fail("n_shards * k = %lld exceeds 8192", (long long)n_shards * k);
     if (nq > 0 && (!scores || !ids || !out_scores || !out_ids)) return fail("NULL argument");
-    HIP_OK(launch_merge_topk(scores, ids, n_shards, nq, k, k_out, out_scores, out_ids, (hipStream_t)stream));
+    HIP_OK(launch_merge_topk(scores, ids, nq * k, nq * k, n_shards, nq, k, k_out, out_scores, out_ids, (hipStream_t)stream));
+    return 0;
+}
+
+int vodhip_merge_topk_strided(const float* scores, int64_t shard_stride_scores, const int64_t* ids, int64_t shard_stride_ids,
+                              int n_shards, int64_t nq, int k, int k_out, float* out_scores, int64_t* out_ids, void* stream) {
+    if (n_shards < 1 || k < 1 || k_out < 1 || nq < 0) return fail("invalid sizes");
+    if ((int64_t)n_shards * k > 8192) return fail("n_shards * k = %lld exceeds 8192", (long long)n_shards * k);
+    if (nq > 0 && (!scores || !ids || !out_scores || !out_ids)) return fail("NULL argument");
+    if (shard_stride_scores < nq * k || shard_stride_ids < nq * k) return fail("shard strides smaller than nq * k");
+    HIP_OK(launch_merge_topk(scores, ids, shard_stride_scores, shard_stride_ids, n_shards, nq, k, k_out, out_scores, out_ids,
+                             (hipStream_t)stream));
     return 0;
 }
 

@@ -35,8 +35,8 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
 hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, hipStream_t stream);
 hipError_t launch_output(const SearchWorkspace& ws, int64_t nq, int k, int64_t id_base, float* out_scores,
                          int64_t* out_ids, hipStream_t stream);
-hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int n_shards, int64_t nq, int k, int k_out,
-                             float* out_scores, int64_t* out_ids, hipStream_t stream);
+hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int64_t stride_s, int64_t stride_i, int n_shards,
+                             int64_t nq, int k, int k_out, float* out_scores, int64_t* out_ids, hipStream_t stream);
 int filter_tile_rows(int tile);  // BM of the tile config
 int filter_tile_cols(int tile);  // BN of the tile config
 

@@ -33,10 +33,12 @@ class ShardedFlatIndex:
         self.local_index = local_index
         self.row_offset = int(row_offset)
         self.group = group
+        self._native_path = local_search is None and merge is None  # HIP search + ONE packed all-gather + HIP merge
         self._local_search = local_search or (lambda q, k, base: local_index.search(q, k, id_base=base))
         if merge is None:
             from vod_amd.index import merge_topk as merge  # HIP k-way merge
         self._merge = merge
+        self._packed = None
 
     @property
     def world(self) -> int:
@@ -44,8 +46,19 @@ class ShardedFlatIndex:
 
     def search(self, queries: torch.Tensor, k: int) -> tuple[torch.Tensor, torch.Tensor]:
         """queries [nq, d], identical on every rank.  Returns (scores f32 [nq, k], global ids i64 [nq, k])."""
-        s, i = self._local_search(queries, k, self.row_offset)
         world = self.world
+        if self._native_path and world > 1:
+            from vod_amd.index import PackedTopk
+
+            nq = int(queries.shape[0])
+            if self._packed is None or (self._packed.nq, self._packed.k) != (nq, int(k)):
+                self._packed = PackedTopk(nq, k, self.local_index.device)
+                self._gathered = torch.empty((world * self._packed.nbytes,), dtype=torch.uint8, device=self.local_index.device)
+            p = self._packed
+            self.local_index.search(queries, k, id_base=self.row_offset, out=(p.scores, p.ids))
+            dist.all_gather_into_tensor(self._gathered, p.buffer, group=self.group)  # 12 * nq * k bytes per rank, one collective
+            return p.merge_gathered(self._gathered, world)
+        s, i = self._local_search(queries, k, self.row_offset)
         if world == 1:
             return s, i
         nq, kk = s.shape

@@ -179,3 +179,34 @@ def merge_topk(scores: torch.Tensor, ids: torch.Tensor, k_out: int | None = None
                                   out_i.data_ptr(), _native.current_stream_ptr(scores.device))
         )
     return out_s, out_i
+
+
+class PackedTopk:
+    """One contiguous per-rank record `[scores f32 nq*k | ids i64 nq*k]` so that the multi-GPU exchange is ONE all-gather.
+
+    `scores` / `ids` are views into `buffer` (uint8); `merge_gathered` merges `world` such records laid end to end.
+    """
+
+    def __init__(self, nq: int, k: int, device: torch.device):
+        self.nq, self.k = int(nq), int(k)
+        n = self.nq * self.k
+        self._s_bytes = (n * 4 + 7) // 8 * 8  # keep the id block 8-byte aligned
+        self.nbytes = self._s_bytes + n * 8
+        self.buffer = torch.empty((self.nbytes,), dtype=torch.uint8, device=device)
+        self.scores = self.buffer[: n * 4].view(torch.float32).view(self.nq, self.k)
+        self.ids = self.buffer[self._s_bytes :].view(torch.int64).view(self.nq, self.k)
+
+    def merge_gathered(self, gathered: torch.Tensor, world: int, k_out: int | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+        """`gathered`: uint8 [world * nbytes] (rank-major).  Returns merged (scores [nq,k_out], ids [nq,k_out])."""
+        lib = _native.load_library()
+        k_out = self.k if k_out is None else int(k_out)
+        dev = gathered.device
+        out_s = torch.empty((self.nq, k_out), dtype=torch.float32, device=dev)
+        out_i = torch.empty((self.nq, k_out), dtype=torch.int64, device=dev)
+        base = gathered.data_ptr()
+        with torch.cuda.device(dev):
+            _native.check(
+                lib.vodhip_merge_topk_strided(base, self.nbytes // 4, base + self._s_bytes, self.nbytes // 8, int(world), self.nq,
+                                              self.k, k_out, out_s.data_ptr(), out_i.data_ptr(), _native.current_stream_ptr(dev))
+            )
+        return out_s, out_i
