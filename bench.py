@@ -43,6 +43,7 @@ def parse_args() -> argparse.Namespace:
     p.add_argument("--k", type=int, default=100)
     p.add_argument("--dtype", choices=["f16", "bf16"], default="f16")
     p.add_argument("--tile", type=int, default=0)
+    p.add_argument("--growth", type=int, default=0, help="chunk growth factor x100 (0 = library default)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -84,6 +85,8 @@ def main() -> None:
     index = HipFlatIndex(d, max(n_local, 1), dtype=tdt, device=local_rank)
     if args.tile:
         index.set_param("tile", args.tile)
+    if args.growth:
+        index.set_param("growth", args.growth)
     t_build0 = time.perf_counter()
     for c in range(c_lo, c_hi):
         g = torch.Generator(device=dev).manual_seed(1234 + c)

@@ -55,6 +55,40 @@ __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     }
 }
 
+// Append the survivors among NV scores of ONE query held by this lane: count first, reserve the slots with ONE
+// returning atomic, then write the keys (a chain of per-hit atomics costs a memory round trip each; early chunks,
+// where ~10 % of the scores pass, spent most of their time there).  val(i) / row(i) must be compile-time indexable.
+template <int NV, typename ValFn, typename RowFn>
+__device__ __forceinline__ void append_survivors(float thr, int q, int row_end, ValFn val, RowFn row,
+                                                 const key_t64* __restrict__ thr_key, key_t64* __restrict__ cand,
+                                                 unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow) {
+    const key_t64 tk = thr_key[q];
+    unsigned n_hit = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float sc = val(i);
+        const int rw = row(i);
+        n_hit += (sc >= thr && rw < row_end && make_key(sc, (unsigned)rw) > tk) ? 1u : 0u;
+    }
+    if (n_hit == 0) return;
+    unsigned slot = atomicAdd(&cnt[q], n_hit);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float sc = val(i);
+        const int rw = row(i);
+        if (sc >= thr && rw < row_end) {
+            const key_t64 key = make_key(sc, (unsigned)rw);
+            if (key > tk) {
+                if (slot < (unsigned)cap)
+                    cand[(size_t)q * cap + slot] = key;
+                else
+                    atomicOr(overflow, 1u);
+                ++slot;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const AS1 void*)gsrc, (AS3 void*)lds_dst, 16, 0, 0);
 }
@@ -392,24 +426,10 @@ void mips_filter_kernel(
                 for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
                 const bool hit = m >= thr[j];  // false for NaN and for padded queries (thr = +inf)
                 if (__any(hit)) {
-                    if (hit) {
-                        const key_t64 tk = thr_key[q];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = rbase + (r & 3) + 8 * (r >> 2);
-                            const float s = acc[i][j][r];
-                            if (s >= thr[j] && row < row_end) {
-                                const key_t64 key = make_key(s, (unsigned)row);
-                                if (key > tk) {
-                                    const unsigned slot = atomicAdd(&cnt[q], 1u);
-                                    if (slot < (unsigned)cap)
-                                        cand[(size_t)q * cap + slot] = key;
-                                    else
-                                        atomicOr(overflow, 1u);
-                                }
-                            }
-                        }
-                    }
+                    if (hit)
+                        append_survivors<16>(
+                            thr[j], q, row_end, [&](int r) { return acc[i][j][r]; },
+                            [&](int r) { return rbase + (r & 3) + 8 * (r >> 2); }, thr_key, cand, cnt, cap, overflow);
                 }
             }
         }
@@ -466,24 +486,10 @@ __device__ __forceinline__ void filter_epilogue(const f32x16 (&acc)[MI][NJ], con
                 for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[i][j][r]);
                 const bool hit = m >= thr[j];  // false for NaN and for padded queries (thr = +inf)
                 if (__any(hit)) {
-                    if (hit) {
-                        const key_t64 tk = thr_key[q];
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = rbase + (r & 3) + 8 * (r >> 2);
-                            const float s = acc[i][j][r];
-                            if (s >= thr[j] && row < row_end) {
-                                const key_t64 key = make_key(s, (unsigned)row);
-                                if (key > tk) {
-                                    const unsigned slot = atomicAdd(&cnt[q], 1u);
-                                    if (slot < (unsigned)cap)
-                                        cand[(size_t)q * cap + slot] = key;
-                                    else
-                                        atomicOr(overflow, 1u);
-                                }
-                            }
-                        }
-                    }
+                    if (hit)
+                        append_survivors<16>(
+                            thr[j], q, row_end, [&](int r) { return acc[i][j][r]; },
+                            [&](int r) { return rbase + (r & 3) + 8 * (r >> 2); }, thr_key, cand, cnt, cap, overflow);
                 }
             }
         }
@@ -809,26 +815,10 @@ __global__ __launch_bounds__(512, 2) void mips_filter16_kernel(
                 for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[i][j][r]);
             const bool hit = m >= thr[j];
             if (__any(hit)) {
-                if (hit) {
-                    const key_t64 tk = thr_key[q];
-#pragma unroll
-                    for (int i = 0; i < MB; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = x0 + wm * TM + i * 16 + 4 * fq + r;
-                            const float sc = acc[i][j][r];
-                            if (sc >= thr[j] && row < row_end) {
-                                const key_t64 key = make_key(sc, (unsigned)row);
-                                if (key > tk) {
-                                    const unsigned slot = atomicAdd(&cnt[q], 1u);
-                                    if (slot < (unsigned)cap)
-                                        cand[(size_t)q * cap + slot] = key;
-                                    else
-                                        atomicOr(overflow, 1u);
-                                }
-                            }
-                        }
-                }
+                if (hit)
+                    append_survivors<MB * 4>(
+                        thr[j], q, row_end, [&](int v) { return acc[v >> 2][j][v & 3]; },
+                        [&](int v) { return x0 + wm * TM + (v >> 2) * 16 + 4 * fq + (v & 3); }, thr_key, cand, cnt, cap, overflow);
             }
         }
     }
@@ -1033,26 +1023,10 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
                 for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[i][j][r]);
             const bool hit = m >= thr[j];
             if (__any(hit)) {
-                if (hit) {
-                    const key_t64 tk = thr_key[q];
-#pragma unroll
-                    for (int i = 0; i < MB; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = x0 + wm * TM + i * 16 + 4 * fq + r;
-                            const float sc = acc[i][j][r];
-                            if (sc >= thr[j] && row < row_end) {
-                                const key_t64 key = make_key(sc, (unsigned)row);
-                                if (key > tk) {
-                                    const unsigned slot = atomicAdd(&cnt[q], 1u);
-                                    if (slot < (unsigned)cap)
-                                        cand[(size_t)q * cap + slot] = key;
-                                    else
-                                        atomicOr(overflow, 1u);
-                                }
-                            }
-                        }
-                }
+                if (hit)
+                    append_survivors<MB * 4>(
+                        thr[j], q, row_end, [&](int v) { return acc[v >> 2][j][v & 3]; },
+                        [&](int v) { return x0 + wm * TM + (v >> 2) * 16 + 4 * fq + (v & 3); }, thr_key, cand, cnt, cap, overflow);
             }
         }
     }
@@ -1099,16 +1073,61 @@ __device__ __forceinline__ void bitonic_sort_desc_lds(key_t64* keys, int P, int 
     __syncthreads();
 }
 
-// One workgroup per query.  The LDS buffer holds SB keys (SB >= 2*kp, power of two): the running top-kp sits in
-// front, candidates are folded in rounds of SB - kp, each round sorts only the power of two that covers it, so
-// the common case (a few hundred candidates) costs a 1024-key sort at 8 workgroups per CU.
+// k-th largest of `total` DISTINCT-or-zero 64-bit keys in LDS (zeros = padding, `total` >= k): MSB-first radix select,
+// 8 passes of one byte with a 256-bin LDS histogram.  Returns the key on every thread.  `hist` = 256 ints + 2 scratch.
+__device__ key_t64 radix_select_kth_lds(const key_t64* keys, int total, int k, int* hist, int tid) {
+    key_t64 prefix = 0, mask = 0;
+    int rank = k;  // 1-based rank from the top among the keys that match the prefix
+    for (int byte = 7; byte >= 0; --byte) {
+        hist[tid] = 0;
+        __syncthreads();
+        const int sh = byte * 8;
+        for (int i = tid; i < total; i += 256) {
+            const key_t64 e = keys[i];
+            if ((e & mask) == prefix) atomicAdd(&hist[(int)((e >> sh) & 255ull)], 1);
+        }
+        __syncthreads();
+        // suffix sums over the 256 bins: thread t learns above(t) = #keys in bins > t; exactly one t has
+        // above(t) < rank <= above(t) + hist[t]
+        int mine = hist[tid];
+        int above = 0;
+        {   // inclusive suffix scan through LDS (4 waves): Hillis-Steele on 256 entries
+            int v = mine;
+            for (int off = 1; off < 256; off <<= 1) {
+                __syncthreads();
+                hist[tid] = v;
+                __syncthreads();
+                if (tid + off < 256) v += hist[tid + off];
+            }
+            above = v - mine;
+            __syncthreads();
+        }
+        if (above < rank && rank <= above + mine) {
+            hist[256] = tid;
+            hist[257] = rank - above;
+        }
+        __syncthreads();
+        const int digit = hist[256];
+        rank = hist[257];
+        prefix |= (key_t64)digit << sh;
+        mask |= 255ull << sh;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// One workgroup per query.  The LDS buffer holds SB keys (SB >= 2*kp, power of two): the running top-k sits in
+// front, candidates are folded in rounds of SB - kp.  Between chunks only the k-th best key (the threshold) and the
+// SET of the k best are needed, so intermediate launches use a radix select + compaction (unsorted top-k);
+// the last launch of a search (`final_sort`) sorts, which is what the output stage reads.
 __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ topk, int kp, int k, int sb,
                                                           const key_t64* __restrict__ cand,
                                                           unsigned int* __restrict__ cnt, int cap, int dense_n,
                                                           float* __restrict__ thr_s, key_t64* __restrict__ thr_key,
-                                                          unsigned int* __restrict__ overflow) {
+                                                          unsigned int* __restrict__ overflow, int final_sort) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     key_t64* keys = (key_t64*)smem;
+    int* hist = (int*)(keys + sb);  // [256 + 2] + compaction counter at [258]
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     unsigned n = dense_n >= 0 ? (unsigned)dense_n : cnt[q];
@@ -1119,18 +1138,43 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
     for (int i = tid; i < kp; i += 256) keys[i] = topk[(size_t)q * kp + i];
     const int room = sb - kp;
     int done = 0;
+    key_t64 kth = 0;
     do {
         const int take = min((int)n - done, room);
         const int total = kp + take;
-        int P = 64;
-        while (P < total) P <<= 1;
-        for (int i = kp + tid; i < P; i += 256) keys[i] = (i < total) ? cand[(size_t)q * cap + done + (i - kp)] : 0ull;
-        bitonic_sort_desc_lds(keys, P, tid);
+        const bool last_round = done + take >= (int)n;
+        if (final_sort && last_round) {
+            int P = 64;
+            while (P < total) P <<= 1;
+            for (int i = kp + tid; i < P; i += 256) keys[i] = (i < total) ? cand[(size_t)q * cap + done + (i - kp)] : 0ull;
+            bitonic_sort_desc_lds(keys, P, tid);
+            kth = keys[k - 1];
+        } else {
+            for (int i = kp + tid; i < total; i += 256) keys[i] = cand[(size_t)q * cap + done + (i - kp)];
+            __syncthreads();
+            kth = radix_select_kth_lds(keys, total, k, hist, tid);  // total >= kp >= k (zeros pad the running top-k)
+            // compaction: the keys >= kth (exactly k of them unless kth == 0) move to the front, zeros behind
+            key_t64 mine[16];  // SB <= 4096 keys / 256 threads
+            int n_mine = 0;
+            for (int i = tid; i < total; i += 256) {
+                const key_t64 e = keys[i];
+                if (e >= kth && e != 0ull && n_mine < 16) mine[n_mine++] = e;
+            }
+            if (tid == 0) hist[258] = 0;
+            __syncthreads();
+            int base = n_mine ? atomicAdd(&hist[258], n_mine) : 0;
+            __syncthreads();  // every thread has read its keys before anyone overwrites the front
+            for (int i = tid; i < kp; i += 256) keys[i] = 0ull;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (u < n_mine) keys[base + u] = mine[u];
+            __syncthreads();
+        }
         done += take;
     } while (done < (int)n);
     for (int i = tid; i < kp; i += 256) topk[(size_t)q * kp + i] = keys[i];
     if (tid == 0) {
-        const key_t64 kth = keys[k - 1];
         thr_key[q] = kth;
         thr_s[q] = kth ? unflip_f32((unsigned)(kth >> 32)) : -__builtin_inff();
         cnt[q] = 0;
@@ -1413,12 +1457,12 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, hipStream_t stream) {
+hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, bool final_sort, hipStream_t stream) {
     int sb = 2048;  // keys per workgroup buffer: 16 KB -> 8 workgroups per CU
     while (sb < 2 * ws.kp) sb <<= 1;
-    const size_t lds = (size_t)sb * sizeof(key_t64);
+    const size_t lds = (size_t)sb * sizeof(key_t64) + 260 * sizeof(int);
     hipLaunchKernelGGL(mips_select_kernel, dim3((unsigned)nq), dim3(256), lds, stream, ws.topk, (int)ws.kp, k, sb, ws.cand,
-                       ws.cnt, (int)ws.cap, (int)dense_n, ws.thr_s, ws.thr_key, ws.overflow);
+                       ws.cnt, (int)ws.cap, (int)dense_n, ws.thr_s, ws.thr_key, ws.overflow, final_sort ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -192,7 +192,7 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
             HIP_OK(launch_filter(ix->dtype, tile, dense[c], ix->data, ws.q_pad, ix->dim_pad, chunks[c].first,
                                  chunks[c].second, nq, nq_pad, ws, stream));
             if (ix->profile) HIP_OK(hipEventRecord(ev1, stream));
-            HIP_OK(launch_select(ws, nq, k, dense[c] ? chunks[c].second - chunks[c].first : -1, stream));
+            HIP_OK(launch_select(ws, nq, k, dense[c] ? chunks[c].second - chunks[c].first : -1, c + 1 == chunks.size(), stream));
         }
         HIP_OK(launch_output(ws, nq, k, ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k, stream));
     }

@@ -32,7 +32,7 @@ hipError_t launch_search_init(const SearchWorkspace& ws, int64_t nq_pad, hipStre
 hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* store, const void* q_pad, int64_t dim_pad,
                          int64_t row_begin, int64_t row_end, int64_t nq, int64_t nq_pad, const SearchWorkspace& ws,
                          hipStream_t stream);
-hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, hipStream_t stream);
+hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, bool final_sort, hipStream_t stream);
 hipError_t launch_output(const SearchWorkspace& ws, int64_t nq, int k, int64_t id_base, float* out_scores,
                          int64_t* out_ids, hipStream_t stream);
 hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int64_t stride_s, int64_t stride_i, int n_shards,
