@@ -207,6 +207,17 @@ def test_server_routes_and_wire_format():
     assert np.all(ids[:, 50:] == -1) and np.all(np.isneginf(scores[:, 50:]))
     r2 = http.post("/search", json={"vectors": q.tolist(), "top_k": 5})
     assert r2.status_code == 200 and np.array(r2.json()["indices"]).tolist() == ids[:, :5].tolist()
+    # binary transport (extension): raw npy in, raw f32|i64 out
+    import io as _io
+
+    buf = _io.BytesIO()
+    np.save(buf, q)
+    r3 = http.post("/raw-search", params={"top_k": 7}, content=buf.getvalue(), headers={"content-type": "application/octet-stream"})
+    assert r3.status_code == 200 and r3.headers["x-nq"] == "3" and r3.headers["x-k"] == "7"
+    bs = np.frombuffer(r3.content, dtype=np.float32, count=21).reshape(3, 7)
+    bi = np.frombuffer(r3.content, dtype=np.int64, count=21, offset=84).reshape(3, 7)
+    np.testing.assert_array_equal(bs, scores[:, :7])
+    np.testing.assert_array_equal(bi, ids[:, :7])
     # contract errors
     assert http.post("/fast-search", json={"vectors": vio.serialize_np_array(q), "top_k": 3, "extra": 1}).status_code == 422
     bad = http.post("/fast-search", json={"vectors": vio.serialize_np_array(q[0]), "top_k": 3})

@@ -36,9 +36,32 @@ def test_master_client_roundtrip_config1(tmp_path, monkeypatch):
         assert r2.meta["time"] > 0 and r2.indices.shape == (3, 5)
         r3 = direct.search_py(q[:3], top_k=5)
         np.testing.assert_array_equal(r3.indices, r2.indices)
+        binary = type(direct)(host=direct.host, port=direct.port, binary=True)  # raw-bytes transport, same results
+        r4 = binary.search(vector=q, top_k=k)
+        np.testing.assert_array_equal(r4.indices + 1000, ri)
+        np.testing.assert_array_equal(r4.scores, rs)
         import requests
 
         with pytest.raises(requests.exceptions.HTTPError):
             direct.search(vector=q[0], top_k=5)  # 1-D query -> HTTP 500 with the trace in `detail`
     assert not master.get_client().ping()  # server terminated on exit
     assert os.path.exists(f"{master.service_name}.stderr.log")
+
+
+def test_index_save_load_roundtrip(tmp_path):
+    from vod_amd.index import HipFlatIndex
+
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(5000, 96)).astype(np.float32)
+    q = torch.from_numpy(rng.normal(size=(9, 96)).astype(np.float32)).cuda()
+    for dt in (torch.float16, torch.bfloat16):
+        with HipFlatIndex(96, 5000, dtype=dt) as a:
+            a.add(x)
+            a.save(tmp_path / "store.npy", chunk=1234)
+            ref = a.search(q, 20)
+            stored = a.stored_rows()
+        with HipFlatIndex.load(tmp_path / "store.npy", dtype=dt, chunk=999) as b:
+            assert b.ntotal == 5000
+            assert torch.equal(b.stored_rows(), stored)  # re-rounding stored values is the identity
+            got = b.search(q, 20)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])

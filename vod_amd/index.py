@@ -107,6 +107,30 @@ class HipFlatIndex:
             )
         return out
 
+    # -- persistence (the store itself is the on-disk format, no faiss file round trip) -----------
+    def save(self, path, chunk: int = 1 << 20) -> None:
+        """Write the stored rows (as stored: fp16, or bf16 widened to fp32) to a `.npy`, slice by slice."""
+        n = self.ntotal
+        np_dtype = np.float16 if self.dtype == torch.float16 else np.float32
+        out = np.lib.format.open_memmap(path, mode="w+", dtype=np_dtype, shape=(n, self.dim))
+        for lo in range(0, n, chunk):
+            rows = self.stored_rows(lo, min(chunk, n - lo))
+            out[lo : lo + rows.shape[0]] = (rows if self.dtype == torch.float16 else rows.float()).cpu().numpy()
+        out.flush()
+        del out
+
+    @classmethod
+    def load(cls, path, dtype: torch.dtype = torch.float16, device: int | torch.device = 0, capacity: int | None = None,
+             chunk: int = 1 << 18) -> "HipFlatIndex":
+        """Build an index from a 2-D float16/float32 `.npy` (memory-mapped, streamed to HBM in slices)."""
+        arr = np.load(path, mmap_mode="r", allow_pickle=False)
+        if arr.ndim != 2:
+            raise ValueError(f"expected a 2-D vector file, got shape {arr.shape}")
+        ix = cls(arr.shape[1], max(capacity or arr.shape[0], 1), dtype=dtype, device=device)
+        for lo in range(0, arr.shape[0], chunk):
+            ix.add(np.ascontiguousarray(arr[lo : lo + chunk]))
+        return ix
+
     # -- search ------------------------------------------------------------------------------------
     def set_param(self, key: str, value: int) -> None:
         _native.check(self._lib.vodhip_index_set_param(self._h, key.encode(), int(value)))

@@ -28,9 +28,10 @@ class HipMipsClient(base.SearchClient):
 
     requires_vectors = True
 
-    def __init__(self, host: str = "http://localhost", port: int = 7678):
+    def __init__(self, host: str = "http://localhost", port: int = 7678, binary: bool = False):
         self.host = host
         self.port = port
+        self.binary = binary  # use the raw-bytes route (`/raw-search`) instead of base64-in-JSON (`/fast-search`)
 
     def __repr__(self) -> str:
         return f"{type(self).__name__}[{self.url}](requires_vectors={self.requires_vectors})"
@@ -66,6 +67,8 @@ class HipMipsClient(base.SearchClient):
         timeout: float = 120,
     ) -> vt.RetrievalBatch:
         start = time.time()
+        if self.binary:
+            return self._search_binary(np.asarray(vector), top_k, timeout, start)
         payload = {"vectors": io.serialize_np_array(np.asarray(vector)), "top_k": top_k}
         response = requests.post(f"{self.url}/fast-search", json=payload, timeout=timeout)
         try:
@@ -83,6 +86,21 @@ class HipMipsClient(base.SearchClient):
             labels=None,
             meta={"time": time.time() - start},
         )
+
+
+    def _search_binary(self, vector: np.ndarray, top_k: int, timeout: float, start: float) -> vt.RetrievalBatch:
+        import io as _io
+
+        buf = _io.BytesIO()
+        np.save(buf, vector, allow_pickle=False)
+        response = requests.post(f"{self.url}/raw-search", params={"top_k": top_k}, data=buf.getvalue(),
+                                 headers={"content-type": "application/octet-stream"}, timeout=timeout)
+        response.raise_for_status()
+        nq, k = int(response.headers["x-nq"]), int(response.headers["x-k"])
+        raw = response.content
+        scores = np.frombuffer(raw, dtype=np.float32, count=nq * k).reshape(nq, k).copy()
+        indices = np.frombuffer(raw, dtype=np.int64, count=nq * k, offset=nq * k * 4).reshape(nq, k).copy()
+        return vt.RetrievalBatch(scores=scores, indices=indices, labels=None, meta={"time": time.time() - start})
 
 
 def _scores_from_json(rows: list) -> np.ndarray:

@@ -21,7 +21,7 @@ import traceback
 
 import numpy as np
 import pydantic
-from fastapi import FastAPI, HTTPException
+from fastapi import FastAPI, HTTPException, Request, Response
 
 from vod_amd import io
 
@@ -83,6 +83,23 @@ def create_app(engine) -> FastAPI:
         try:
             scores, indices = _search(io.deserialize_np_array(query.vectors), query.top_k)
             return FastSearchResponse(scores=io.serialize_np_array(scores), indices=io.serialize_np_array(indices))
+        except Exception as exc:
+            raise HTTPException(status_code=500, detail=traceback.format_exc()) from exc
+
+    @app.post("/raw-search")
+    async def raw_search(request: Request, top_k: int = 3) -> Response:
+        """Binary transport (not in the reference): body = raw `.npy` bytes of the [nq, d] queries,
+        reply = raw bytes `scores float32 [nq, k]` followed by `indices int64 [nq, k]`; shapes in the headers.
+        Skips base64 + JSON, which is ~6 ms of the reference's per-batch floor."""
+        try:
+            import io as _io
+
+            body = await request.body()
+            query_vec = np.load(_io.BytesIO(body), allow_pickle=False)
+            scores, indices = _search(query_vec, top_k)
+            payload = np.ascontiguousarray(scores).tobytes() + np.ascontiguousarray(indices).tobytes()
+            return Response(content=payload, media_type="application/octet-stream",
+                            headers={"x-nq": str(scores.shape[0]), "x-k": str(scores.shape[1])})
         except Exception as exc:
             raise HTTPException(status_code=500, detail=traceback.format_exc()) from exc
 
