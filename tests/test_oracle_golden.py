@@ -164,3 +164,24 @@ def test_flat_ip_pads_when_fewer_rows_than_k():
     s, i = flat_ip_topk(q, x, 5)
     assert i[:, 3:].tolist() == [[-1, -1], [-1, -1]] and np.all(np.isneginf(s[:, 3:]))
     assert i[:, :3].tolist() == [[0, 1, 2], [0, 1, 2]]
+
+
+def test_cpu_baseline_port_is_an_exact_topk():
+    """bench.py's `cpu_baseline` leg times this port: it must return the same ids as the fp64 oracle."""
+    import torch
+
+    from oracle.cpu_baseline import flat_ip_topk_cpu
+
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(30000, 48)).astype(np.float32)
+    q = rng.normal(size=(19, 48)).astype(np.float32)
+    for k, block in ((20, 4096), (100, 1000), (5, 50000)):
+        s, i = flat_ip_topk_cpu(torch.from_numpy(q), torch.from_numpy(x), k, block=block)
+        rs, ri = flat_ip_topk(q, x, k)
+        assert np.array_equal(i.numpy(), ri)
+        np.testing.assert_allclose(s.numpy(), rs, atol=1e-4)
+    # ascending scores along the rows: every block floods the candidate buffer (fallback path)
+    xs = x[np.argsort(x @ q[0])]
+    s, i = flat_ip_topk_cpu(torch.from_numpy(q[:1]), torch.from_numpy(xs), 10, block=2048)
+    rs, ri = flat_ip_topk(q[:1], xs, 10)
+    assert np.array_equal(i.numpy(), ri)
