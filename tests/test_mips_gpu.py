@@ -313,3 +313,12 @@ def test_packed_record_merge_matches_plain_merge():
     ms, mi = recs[0].merge_gathered(gathered, world)
     rs, ri = merge_topk(torch.stack(plain_s), torch.stack(plain_i))
     assert torch.equal(ms, rs) and torch.equal(mi, ri)
+
+
+@pytest.mark.parametrize("nq", [700, 1300, 1600, 1800, 2048])
+@pytest.mark.parametrize("tile", [9, 10, 8])
+def test_persistent_kernel_odd_qtile_counts(nq, tile):
+    """n_qtiles = 3, 6, 7, 8: the persistent grid is rounded to a multiple of 8 * n_qtiles."""
+    q, x = _int_data(nq, 24000, 64, nq)
+    with _index(x, tile=tile) as ix:
+        _assert_exact(ix, q, x, 10)
