@@ -89,6 +89,16 @@ int vodhip_index_search_async(vodhip_index_t* index, const void* queries, int q_
                               int64_t id_base, float* out_scores, int64_t* out_ids, void* stream);
 int vodhip_index_search_finish(vodhip_index_t* index, void* stream);
 
+/* Optional subset filter.  The reference's SearchClient.search carries `subset_ids`; its Elasticsearch and
+ * Qdrant engines restrict hits to sections whose subset id is listed (src/vod_search/es_search/client.py:185-191,
+ * qdrant_search/client.py:124-136) while its faiss client ignores it (faiss_search/client.py:67-72).  Here every stored
+ * row may carry an int32 label (`labels` [n_rows], host or device; NULL clears), and the next searches may pass, per
+ * query, up to `n_per_query` allowed labels (DEVICE int32 [nq, n_per_query], caller-owned until cleared with NULL;
+ * -1 = empty slot; a query whose slots are all -1 is unrestricted).  A row is eligible iff its label is listed.
+ * Results stay exact top-k over the eligible rows. */
+int vodhip_index_set_row_labels(vodhip_index_t* index, const int32_t* labels, int64_t n_rows, int location, void* stream);
+int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels_dev, int n_per_query);
+
 /* Tunables / introspection (tests and bench).  key: "cand_cap", "dense_rows", "growth", "force_safe",
  * "tile" (0 = auto, 1 = 128x128, 2 = 256x256); stats: "last_overflow", "last_chunks", "last_safe_reruns". */
 int vodhip_index_set_param(vodhip_index_t* index, const char* key, int64_t value);

@@ -322,3 +322,35 @@ def test_persistent_kernel_odd_qtile_counts(nq, tile):
     q, x = _int_data(nq, 24000, 64, nq)
     with _index(x, tile=tile) as ix:
         _assert_exact(ix, q, x, 10)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 8, 9])
+def test_subset_filtered_search(tile):
+    """per-row labels + per-query allowed labels; exact top-k over the eligible rows only."""
+    from oracle.flat_ip import topk_desc_tiebreak
+
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 40000, 64, 300 if tile != 1 else 100, 50
+    q, x = _int_data(78, n, d, nq)
+    labels = rng.integers(0, 12, size=n).astype(np.int32)
+    subset = np.full((nq, 3), -1, dtype=np.int32)
+    for r in range(nq):
+        m = rng.integers(0, 4)                       # 0 -> unrestricted query
+        subset[r, :m] = rng.choice(12, size=m, replace=False)
+    subset[5] = [99, -1, -1]                         # a label nobody carries -> no hits at all
+    with _index(x, tile=tile) as ix:
+        ix.set_row_labels(labels)
+        s, i = ix.search(torch.from_numpy(q).cuda(), k, subset=subset)
+        s2, i2 = ix.search(torch.from_numpy(q).cuda(), k)           # filter cleared again
+    full = q.astype(np.float64) @ x.astype(np.float64).T
+    masked = full.copy()
+    for r in range(nq):
+        allowed = subset[r][subset[r] >= 0]
+        if allowed.size:
+            masked[r, ~np.isin(labels, allowed)] = np.nan            # NaN scores never enter the oracle's result
+    rs, ri = topk_desc_tiebreak(masked, k)
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(s.cpu().numpy(), rs)
+    assert np.all(ri[5] == -1)
+    us, ui = topk_desc_tiebreak(full, k)
+    np.testing.assert_array_equal(i2.cpu().numpy(), ui)

@@ -24,6 +24,11 @@ class NativeLibraryError(RuntimeError):
 
 
 def lib_path() -> pathlib.Path:
+    import os
+
+    override = os.environ.get("VODHIP_LIB")  # A/B runs of two builds in one process environment (still a libvodhip build)
+    if override:
+        return pathlib.Path(override)
     return pathlib.Path(__file__).resolve().parent / "csrc" / _LIB_NAME
 
 
@@ -46,6 +51,8 @@ SIGNATURES: dict[str, tuple] = {
     "vodhip_index_search": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]),
     "vodhip_index_search_async": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]),
     "vodhip_index_search_finish": (_i32, [_vp, _vp]),
+    "vodhip_index_set_row_labels": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "vodhip_index_set_query_labels": (_i32, [_vp, _vp, _i32]),
     "vodhip_index_set_param": (_i32, [_vp, _c.c_char_p, _i64]),
     "vodhip_index_get_stat": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i64)]),
     "vodhip_merge_topk": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),

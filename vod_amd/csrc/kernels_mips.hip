@@ -58,29 +58,77 @@ __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
 // Append the survivors among NV scores of ONE query held by this lane: count first, reserve the slots with ONE
 // returning atomic, then write the keys (a chain of per-hit atomics costs a memory round trip each; early chunks,
 // where ~10 % of the scores pass, spent most of their time there).  val(i) / row(i) must be compile-time indexable.
-template <int NV, typename ValFn, typename RowFn>
+// Subset filter (the `subset_ids` of the reference's SearchClient.search, honoured by its Elasticsearch / Qdrant engines,
+// src/vod_search/es_search/client.py:185-191, qdrant_search/client.py:124-136, and ignored by its faiss client,
+// faiss_search/client.py:67-72): a row is eligible for query q when q lists no label or lists the row's label.
+__device__ __forceinline__ bool subset_allows(const FilterExtra& ex, int q, int row) {
+    if (ex.row_label == nullptr) return true;
+    const int lab = ex.row_label[row];
+    bool any = false, ok = false;
+#pragma unroll 1
+    for (int s = 0; s < ex.n_qlab; ++s) {
+        const int ql = ex.q_label[(size_t)q * ex.n_qlab + s];
+        any |= ql >= 0;
+        ok |= ql == lab;
+    }
+    return ok || !any;
+}
+
+template <int NV, bool SUBSET, typename ValFn, typename RowFn>
 __device__ __forceinline__ void append_survivors(float thr, int q, int row_end, ValFn val, RowFn row,
                                                  const key_t64* __restrict__ thr_key, key_t64* __restrict__ cand,
-                                                 unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow) {
+                                                 unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow,
+                                                 const FilterExtra& ex) {
     const key_t64 tk = thr_key[q];
-    unsigned n_hit = 0;
+    if constexpr (!SUBSET) {
+        unsigned n_hit = 0;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const float sc = val(i);
-        const int rw = row(i);
-        n_hit += (sc >= thr && rw < row_end && make_key(sc, (unsigned)rw) > tk) ? 1u : 0u;
-    }
-    if (n_hit == 0) return;
-    unsigned slot = atomicAdd(&cnt[q], n_hit);
+        for (int i = 0; i < NV; ++i) {
+            const float sc = val(i);
+            const int rw = row(i);
+            n_hit += (sc >= thr && rw < row_end && make_key(sc, (unsigned)rw) > tk) ? 1u : 0u;
+        }
+        if (n_hit == 0) return;
+        unsigned slot = atomicAdd(&cnt[q], n_hit);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const float sc = val(i);
-        const int rw = row(i);
-        if (sc >= thr && rw < row_end) {
-            const key_t64 key = make_key(sc, (unsigned)rw);
-            if (key > tk) {
+        for (int i = 0; i < NV; ++i) {
+            const float sc = val(i);
+            const int rw = row(i);
+            if (sc >= thr && rw < row_end) {
+                const key_t64 key = make_key(sc, (unsigned)rw);
+                if (key > tk) {
+                    if (slot < (unsigned)cap)
+                        cand[(size_t)q * cap + slot] = key;
+                    else
+                        atomicOr(overflow, 1u);
+                    ++slot;
+                }
+            }
+        }
+    } else {
+        // subset filter: survivors of the threshold test are marked in a bit mask, then a ROLLED loop drops the
+        // ineligible ones (keeps the hot code small; this instantiation only runs when row labels are set)
+        static_assert(NV <= 32, "survivor mask is 32 bits");
+        unsigned mask = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float sc = val(i);
+            const int rw = row(i);
+            mask |= (sc >= thr && rw < row_end && make_key(sc, (unsigned)rw) > tk) ? (1u << i) : 0u;
+        }
+        unsigned m2 = mask;
+        while (m2) {
+            const int i = __builtin_ctz(m2);
+            m2 &= m2 - 1;
+            if (!subset_allows(ex, q, row(i))) mask &= ~(1u << i);
+        }
+        if (mask == 0) return;
+        unsigned slot = atomicAdd(&cnt[q], (unsigned)__builtin_popcount(mask));
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (mask & (1u << i)) {
                 if (slot < (unsigned)cap)
-                    cand[(size_t)q * cap + slot] = key;
+                    cand[(size_t)q * cap + slot] = make_key(val(i), (unsigned)row(i));
                 else
                     atomicOr(overflow, 1u);
                 ++slot;
@@ -123,13 +171,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // BK      : K elements per LDS stage (64 -> 128-B rows, 32 -> 64-B rows)
 // NSTAGE  : LDS ring depth.  Slice t+NSTAGE-1 is being fetched while slice t is multiplied, so
 //           (NSTAGE-2) whole slices stay in flight ACROSS the per-slice barrier (counted vmcnt, raw s_barrier).
-template <int DT, int BM, int BN, int WM, int WN, int BK, int NSTAGE, bool DENSE, int ABLATE = 0, bool PINGPONG = false>
+template <int DT, int BM, int BN, int WM, int WN, int BK, int NSTAGE, bool DENSE, int ABLATE = 0, bool PINGPONG = false, bool SUBSET = false>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN * 64 * ((160 * 1024) / (NSTAGE * (BM + BN) * BK * 2))) / 256 >= 2 ? 2 : 1)
 void mips_filter_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
     int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
-    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, int flags) {
-    const bool krot_on = (flags & 1) != 0;  // FILTER_FLAG_KROT
+    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, FilterExtra ex) {
+    const bool krot_on = (ex.flags & 1) != 0;  // FILTER_FLAG_KROT
 
     constexpr int NWAVES = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;  // per-wave tile
@@ -419,6 +467,13 @@ void mips_filter_kernel(
                             cand[(size_t)q * cap + (row - row_begin)] = key;
                         }
                     }
+                    if constexpr (SUBSET) {  // subset filter: blank the ineligible rows (rolled loop, dense chunk only)
+#pragma unroll 1
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = rbase + (r & 3) + 8 * (r >> 2);
+                            if (row < row_end && !subset_allows(ex, q, row)) cand[(size_t)q * cap + (row - row_begin)] = 0ull;
+                        }
+                    }
                 }
             } else {
                 float m = acc[i][j][0];
@@ -427,9 +482,9 @@ void mips_filter_kernel(
                 const bool hit = m >= thr[j];  // false for NaN and for padded queries (thr = +inf)
                 if (__any(hit)) {
                     if (hit)
-                        append_survivors<16>(
+                        append_survivors<16, SUBSET>(
                             thr[j], q, row_end, [&](int r) { return acc[i][j][r]; },
-                            [&](int r) { return rbase + (r & 3) + 8 * (r >> 2); }, thr_key, cand, cnt, cap, overflow);
+                            [&](int r) { return rbase + (r & 3) + 8 * (r >> 2); }, thr_key, cand, cnt, cap, overflow, ex);
                 }
             }
         }
@@ -455,11 +510,11 @@ void mips_filter_kernel(
 // MFMA work; when the MFMA waves issue the LDS-DMA themselves, in-order issue parks them behind a full
 // memory pipeline and the two costs ADD (16 ms = 10 ms DMA + 6 ms MFMA per batch).  Here the DMA is issued
 // by dedicated waves (one per SIMD) whose stalls cost nothing, the MFMA waves only read LDS and multiply.
-template <int MI, int NJ, bool DENSE>
+template <int MI, int NJ, bool DENSE, bool SUBSET = false>
 __device__ __forceinline__ void filter_epilogue(const f32x16 (&acc)[MI][NJ], const float (&thr)[NJ], int qbase, int rbase0,
                                                 int fr, int fh, int nq, int row_begin, int row_end,
                                                 const key_t64* __restrict__ thr_key, key_t64* __restrict__ cand,
-                                                unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow) {
+                                                unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, const FilterExtra& ex) {
     // C layout of v_mfma_f32_32x32x16: col = lane&31 (query), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -479,6 +534,13 @@ __device__ __forceinline__ void filter_epilogue(const f32x16 (&acc)[MI][NJ], con
                             cand[(size_t)q * cap + (row - row_begin)] = key;
                         }
                     }
+                    if constexpr (SUBSET) {  // subset filter: blank the ineligible rows (rolled loop, dense chunk only)
+#pragma unroll 1
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = rbase + (r & 3) + 8 * (r >> 2);
+                            if (row < row_end && !subset_allows(ex, q, row)) cand[(size_t)q * cap + (row - row_begin)] = 0ull;
+                        }
+                    }
                 }
             } else {
                 float m = acc[i][j][0];
@@ -487,9 +549,9 @@ __device__ __forceinline__ void filter_epilogue(const f32x16 (&acc)[MI][NJ], con
                 const bool hit = m >= thr[j];  // false for NaN and for padded queries (thr = +inf)
                 if (__any(hit)) {
                     if (hit)
-                        append_survivors<16>(
+                        append_survivors<16, SUBSET>(
                             thr[j], q, row_end, [&](int r) { return acc[i][j][r]; },
-                            [&](int r) { return rbase + (r & 3) + 8 * (r >> 2); }, thr_key, cand, cnt, cap, overflow);
+                            [&](int r) { return rbase + (r & 3) + 8 * (r >> 2); }, thr_key, cand, cnt, cap, overflow, ex);
                 }
             }
         }
@@ -500,8 +562,8 @@ template <int DT, int BK, int NSTAGE, int NL, bool DENSE, bool STAMP = false, in
 __global__ __launch_bounds__((8 + NL) * 64, 3) void mips_filter_spec_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
     int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
-    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, int flags) {
-    const bool krot_on = (flags & 1) != 0;  // FILTER_FLAG_KROT
+    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, FilterExtra ex) {
+    const bool krot_on = (ex.flags & 1) != 0;  // FILTER_FLAG_KROT
 
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, NCW = 8;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NJ = TN / 32;
@@ -661,7 +723,7 @@ __global__ __launch_bounds__((8 + NL) * 64, 3) void mips_filter_spec_kernel(
 #endif
     }
     filter_epilogue<MI, NJ, DENSE>(acc, thr, q0 + wn * TN, x0 + wm * TM, fr, fh, nq, row_begin, row_end, thr_key, cand, cnt,
-                                   cap, overflow);
+                                   cap, overflow, ex);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -683,12 +745,12 @@ __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
     }
 }
 
-template <int DT, bool DENSE>
+template <int DT, bool DENSE, bool SUBSET = false>
 __global__ __launch_bounds__(512, 2) void mips_filter16_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
     int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
-    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, int flags) {
-    const bool krot_on = (flags & 1) != 0;  // FILTER_FLAG_KROT
+    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, FilterExtra ex) {
+    const bool krot_on = (ex.flags & 1) != 0;  // FILTER_FLAG_KROT
 
     constexpr int BM = 256, BN = 256, WN = 4, NWAVES = 8, BK = 64, NSTAGE = 2;
     constexpr int TM = 128, TN = 64;
@@ -806,6 +868,13 @@ __global__ __launch_bounds__(512, 2) void mips_filter16_kernel(
                         const float sc = acc[i][j][r];
                         if (row < row_end) cand[(size_t)q * cap + (row - row_begin)] = (sc == sc) ? make_key(sc, (unsigned)row) : 0ull;
                     }
+                if constexpr (SUBSET) {  // subset filter: blank the ineligible rows (rolled loop, dense chunk only)
+#pragma unroll 1
+                    for (int v = 0; v < MB * 4; ++v) {
+                        const int row = x0 + wm * TM + (v >> 2) * 16 + 4 * fq + (v & 3);
+                        if (row < row_end && !subset_allows(ex, q, row)) cand[(size_t)q * cap + (row - row_begin)] = 0ull;
+                    }
+                }
             }
         } else {
             float m = acc[0][j][0];
@@ -816,9 +885,9 @@ __global__ __launch_bounds__(512, 2) void mips_filter16_kernel(
             const bool hit = m >= thr[j];
             if (__any(hit)) {
                 if (hit)
-                    append_survivors<MB * 4>(
+                    append_survivors<MB * 4, SUBSET>(
                         thr[j], q, row_end, [&](int v) { return acc[v >> 2][j][v & 3]; },
-                        [&](int v) { return x0 + wm * TM + (v >> 2) * 16 + 4 * fq + (v & 3); }, thr_key, cand, cnt, cap, overflow);
+                        [&](int v) { return x0 + wm * TM + (v >> 2) * 16 + 4 * fq + (v & 3); }, thr_key, cand, cnt, cap, overflow, ex);
             }
         }
     }
@@ -833,18 +902,17 @@ __global__ __launch_bounds__(512, 2) void mips_filter16_kernel(
 // during the current tile's last slice, so its HBM latency hides behind that slice's MFMAs and the threshold-filter
 // epilogue instead of opening every tile with an idle matrix pipe (measured prologue: ~2,200 cycles of a 48,000
 // cycle tile), and there is no per-tile workgroup launch / drain.
-template <int DT, bool A3 = false>
+template <int DT, bool A3 = false, bool SUBSET = false>
 __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
     int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
-    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, int flags) {
+    key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow, FilterExtra ex) {
     constexpr int BM = 256, BN = 256, WN = 4, NWAVES = 8, BK = 64, NSTAGE = 2;
     constexpr int TM = 128, TN = 64;
     constexpr int MB = TM / 16, NB16 = TN / 16;
     constexpr int ROW_BYTES = BK * 2, RPI = 8;
     constexpr int A_BYTES = BM * ROW_BYTES, STAGE_BYTES = (BM + BN) * ROW_BYTES;
     constexpr int NA = BM / RPI / NWAVES, NBI = BN / RPI / NWAVES, G = NA + NBI;
-    (void)flags;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = blockIdx.x;
@@ -1024,9 +1092,9 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
             const bool hit = m >= thr[j];
             if (__any(hit)) {
                 if (hit)
-                    append_survivors<MB * 4>(
+                    append_survivors<MB * 4, SUBSET>(
                         thr[j], q, row_end, [&](int v) { return acc[v >> 2][j][v & 3]; },
-                        [&](int v) { return x0 + wm * TM + (v >> 2) * 16 + 4 * fq + (v & 3); }, thr_key, cand, cnt, cap, overflow);
+                        [&](int v) { return x0 + wm * TM + (v >> 2) * 16 + 4 * fq + (v & 3); }, thr_key, cand, cnt, cap, overflow, ex);
             }
         }
     }
@@ -1283,7 +1351,7 @@ extern "C" int vodhip_debug_read_stamps(unsigned long long* host_out, long long 
 int filter_tile_rows(int tile) { return (tile == 1 || tile == 5) ? 128 : 256; }  // ablation ids 11..13 are 256
 int filter_tile_cols(int tile) { return (tile == 1 || tile == 5) ? 128 : 256; }
 
-template <int DT, int BM, int BN, int WM, int WN, int BK, int NSTAGE, bool DENSE, int ABLATE = 0, bool PINGPONG = false>
+template <int DT, int BM, int BN, int WM, int WN, int BK, int NSTAGE, bool DENSE, int ABLATE = 0, bool PINGPONG = false, bool SUBSET = false>
 static hipError_t launch_filter_cfg(const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin,
                                     int64_t row_end, int64_t nq, int64_t nq_pad, const SearchWorkspace& ws,
                                     hipStream_t stream) {
@@ -1293,7 +1361,7 @@ static hipError_t launch_filter_cfg(const void* store, const void* q_pad, int64_
     const unsigned grid = (unsigned)xgroups * 8u * (unsigned)n_qtiles;
     constexpr int threads = WM * WN * 64;
     constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * BK * 2 + (ABLATE == 15 ? 2048 : 0);
-    auto kern = mips_filter_kernel<DT, BM, BN, WM, WN, BK, NSTAGE, DENSE, ABLATE, PINGPONG>;
+    auto kern = mips_filter_kernel<DT, BM, BN, WM, WN, BK, NSTAGE, DENSE, ABLATE, PINGPONG, SUBSET>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1302,7 +1370,7 @@ static hipError_t launch_filter_cfg(const void* store, const void* q_pad, int64_
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, (const uint16_t*)store, (const uint16_t*)q_pad,
                        (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s, ws.thr_key,
-                       ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.flags);
+                       ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.extra);
     return hipGetLastError();
 }
 
@@ -1310,6 +1378,19 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
                          int64_t row_begin, int64_t row_end, int64_t nq, int64_t nq_pad, const SearchWorkspace& ws,
                          hipStream_t stream) {
     if (row_end <= row_begin) return hipSuccess;
+    const bool subset = ws.extra.row_label != nullptr;
+    if (subset) {
+        // the subset filter is instantiated for the production variants only (1: 128x128, 8/9/10: 256x256 16x16x32)
+        if (tile != 1 && tile != 8 && tile != 9 && tile != 10) return hipErrorNotSupported;
+        if (tile == 1) {
+#define VOD_SUB1(DT, DENSE) return launch_filter_cfg<DT, 128, 128, 2, 2, 64, 2, DENSE, 0, false, true>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream)
+            if (store_dtype == 0 && dense) VOD_SUB1(0, true);
+            if (store_dtype == 0 && !dense) VOD_SUB1(0, false);
+            if (store_dtype == 1 && dense) VOD_SUB1(1, true);
+            if (store_dtype == 1 && !dense) VOD_SUB1(1, false);
+#undef VOD_SUB1
+        }
+    }
 #define VOD_FILTER(DT, TILE, BM, BN, WM, WN, BK, NS)                                                                   \
     if (store_dtype == DT && tile == TILE) {                                                                           \
         return dense ? launch_filter_cfg<DT, BM, BN, WM, WN, BK, NS, true>(store, q_pad, dim_pad, row_begin, row_end,  \
@@ -1336,13 +1417,14 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         const size_t lds = tile == 10 ? 160 * 1024 : 128 * 1024;
 #define VOD_K16P(DT)                                                                                                   \
     {                                                                                                                  \
-        auto kern = tile == 10 ? mips_filter16p_kernel<DT, true> : mips_filter16p_kernel<DT, false>;                  \
+        auto kern = tile == 10 ? (subset ? mips_filter16p_kernel<DT, true, true> : mips_filter16p_kernel<DT, true, false>)  \
+                               : (subset ? mips_filter16p_kernel<DT, false, true> : mips_filter16p_kernel<DT, false, false>); \
         (void)0;                                                                      \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, (const uint16_t*)store,                 \
                            (const uint16_t*)q_pad, (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles,     \
-                           (int)nq, ws.thr_s, ws.thr_key, ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.flags);        \
+                           (int)nq, ws.thr_s, ws.thr_key, ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.extra);        \
         return hipGetLastError();                                                                                      \
     }
         if (store_dtype == 0) VOD_K16P(0)
@@ -1356,12 +1438,12 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         constexpr size_t lds = 128 * 1024;
 #define VOD_K16(DT, DENSE)                                                                                             \
     {                                                                                                                  \
-        auto kern = mips_filter16_kernel<DT, DENSE>;                                                                   \
+        auto kern = subset ? mips_filter16_kernel<DT, DENSE, true> : mips_filter16_kernel<DT, DENSE, false>;           \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, (const uint16_t*)store, (const uint16_t*)q_pad,   \
                            (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s,          \
-                           ws.thr_key, ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.flags);                                     \
+                           ws.thr_key, ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.extra);                                     \
         return hipGetLastError();                                                                                      \
     }
         if (store_dtype == 0 && dense) VOD_K16(0, true)
@@ -1382,7 +1464,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, stream, (const uint16_t*)store, (const uint16_t*)q_pad,   \
                            (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s,          \
-                           ws.thr_key, ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.flags);                                     \
+                           ws.thr_key, ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.extra);                                     \
         return hipGetLastError();                                                                                      \
     }
         if (tile == 6) {
@@ -1442,7 +1524,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(768), 128 * 1024, stream, (const uint16_t*)store, (const uint16_t*)q_pad,
                            (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s, ws.thr_key,
-                           ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.flags);
+                           ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.extra);
         return hipGetLastError();
     }
     if (store_dtype == 0 && tile == 17 && !dense)  // stamped build of tile 2

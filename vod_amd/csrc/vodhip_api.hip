@@ -60,6 +60,9 @@ struct vodhip_index {
     int64_t ntotal = 0;
     int dtype = VODHIP_F16;
     uint16_t* data = nullptr;
+    int* row_label = nullptr;        // [capacity_pad] subset label per row (optional)
+    const int* q_label = nullptr;    // caller-owned device [nq, n_qlab] for the next searches (optional)
+    int n_qlab = 0;
     void* stage_dev = nullptr;  // raw-dtype staging for host ingest
     SearchWorkspace ws;
     unsigned int* overflow_host = nullptr;  // pinned
@@ -166,7 +169,10 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
     if (tile == 0) tile = ps.nq > 256 ? 9 : (ps.nq > 128 ? 10 : 1);
     const int64_t bn = filter_tile_cols(tile);
     if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
-    ix->ws.flags = ix->krot ? 1 : 0;
+    ix->ws.extra.flags = ix->krot ? 1 : 0;
+    ix->ws.extra.row_label = (ix->row_label && ix->q_label) ? ix->row_label : nullptr;
+    ix->ws.extra.q_label = ix->q_label;
+    ix->ws.extra.n_qlab = ix->n_qlab;
     const SearchWorkspace& ws = ix->ws;
     HIP_OK(hipMemsetAsync(ws.overflow, 0, sizeof(unsigned int), stream));
     for (int64_t qb = 0; qb < ps.nq; qb += MAX_NQ_PER_PASS) {
@@ -176,6 +182,7 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
         HIP_OK(hipMemsetAsync(ws.q_pad, 0, (size_t)nq_pad * ix->dim_pad * 2, stream));
         HIP_OK(launch_convert_rows((const char*)ps.queries + (size_t)qb * ix->dim * q_es, ps.q_dtype, nq, ix->dim,
                                    ws.q_pad, ix->dtype, ix->dim_pad, stream));
+        ix->ws.extra.q_label = ix->q_label ? ix->q_label + (size_t)qb * ix->n_qlab : nullptr;
         HIP_OK(launch_search_init(ws, nq_pad, stream));
         for (size_t c = 0; c < chunks.size(); ++c) {
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -245,6 +252,7 @@ int vodhip_index_destroy(vodhip_index_t* ix) {
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
     (void)hipFree(ix->data);
     (void)hipFree(ix->stage_dev);
+    (void)hipFree(ix->row_label);
     (void)hipHostFree(ix->overflow_host);
     delete ix;
     return 0;
@@ -321,6 +329,35 @@ int vodhip_index_get_rows(const vodhip_index_t* ix, int64_t row_begin, int64_t n
     HIP_OK(hipMemcpy2DAsync(dst, (size_t)ix->dim * 2, ix->data + (size_t)row_begin * ix->dim_pad, (size_t)ix->dim_pad * 2,
                             (size_t)ix->dim * 2, (size_t)n_rows, kind, stream));
     if (dst_location != VODHIP_DEVICE) HIP_OK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int vodhip_index_set_row_labels(vodhip_index_t* ix, const int32_t* labels, int64_t n_rows, int location, void* stream_) {
+    if (!ix) return fail("index is NULL");
+    HIP_OK(hipSetDevice(ix->device));
+    if (!labels) {  // clear
+        (void)hipFree(ix->row_label);
+        ix->row_label = nullptr;
+        return 0;
+    }
+    if (n_rows < 0 || n_rows > ix->capacity) return fail("n_rows=%lld out of range", (long long)n_rows);
+    if (!ix->row_label) {
+        HIP_OK(hipMalloc((void**)&ix->row_label, (size_t)ix->capacity_pad * sizeof(int)));
+        HIP_OK(hipMemset(ix->row_label, 0xFF, (size_t)ix->capacity_pad * sizeof(int)));  // -1: matches no query label
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_OK(hipMemcpyAsync(ix->row_label, labels, (size_t)n_rows * sizeof(int),
+                          location == VODHIP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int vodhip_index_set_query_labels(vodhip_index_t* ix, const int32_t* q_labels_dev, int n_per_query) {
+    if (!ix) return fail("index is NULL");
+    if (q_labels_dev && (n_per_query < 1 || n_per_query > 64)) return fail("n_per_query must be in [1, 64]");
+    if (q_labels_dev && !ix->row_label) return fail("set the row labels first (vodhip_index_set_row_labels)");
+    ix->q_label = q_labels_dev;
+    ix->n_qlab = q_labels_dev ? n_per_query : 0;
     return 0;
 }
 

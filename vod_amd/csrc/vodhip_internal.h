@@ -10,6 +10,14 @@ namespace vodhip {
 // Key 0 is reserved for "no entry" and sorts below every real key.
 typedef unsigned long long key_t64;
 
+// Extra, optional inputs of the filter kernels (passed by value).
+struct FilterExtra {
+    int flags = 0;                    // bit 0: rotated K order per q-tile workgroup (experiment knob)
+    const int* row_label = nullptr;   // [ntotal] subset label of every stored row, or NULL (no subset filtering)
+    const int* q_label = nullptr;     // [nq, n_qlab] allowed labels per query (-1 = empty slot; all -1 = unrestricted)
+    int n_qlab = 0;
+};
+
 struct SearchWorkspace {
     uint16_t* q_pad = nullptr;       // [nq_pad][dim_pad] queries rounded to the store dtype, zero padded
     key_t64* topk = nullptr;         // [nq_pad][kp] running top-k keys, sorted descending
@@ -21,7 +29,7 @@ struct SearchWorkspace {
     int64_t nq_cap = 0;
     int64_t cap = 0;
     int64_t kp = 0;
-    int flags = 0;  // bit 0: rotated K order per q-tile workgroup (experiment knob)
+    FilterExtra extra;  // flags + optional subset filter of the current search
 };
 
 // ---- launchers (kernels_mips.hip) -------------------------------------------------------------

@@ -107,6 +107,22 @@ class HipFlatIndex:
             )
         return out
 
+    # -- subset filter ---------------------------------------------------------------
+    def set_row_labels(self, labels: np.ndarray | torch.Tensor | None) -> None:
+        """Attach an int32 subset label to every stored row (None clears).  Needed before `search(..., subset=...)`."""
+        with torch.cuda.device(self.device):
+            if labels is None:
+                _native.check(self._lib.vodhip_index_set_row_labels(self._h, None, 0, _native.HOST, None))
+                return
+            if isinstance(labels, torch.Tensor) and labels.is_cuda:
+                lab = labels.to(torch.int32).contiguous()
+                _native.check(self._lib.vodhip_index_set_row_labels(self._h, lab.data_ptr(), lab.numel(), _native.DEVICE,
+                                                                    _native.current_stream_ptr(self.device)))
+                return
+            lab = np.ascontiguousarray(np.asarray(labels), dtype=np.int32)
+            _native.check(self._lib.vodhip_index_set_row_labels(self._h, lab.ctypes.data, lab.size, _native.HOST,
+                                                                _native.current_stream_ptr(self.device)))
+
     # -- persistence (SURVEY 8f-1: the store itself is the on-disk format, no faiss file round trip) -----------
     def save(self, path, chunk: int = 1 << 20) -> None:
         """Write the stored rows (as stored: fp16, or bf16 widened to fp32) to a `.npy`, slice by slice."""
@@ -156,10 +172,23 @@ class HipFlatIndex:
             raise ValueError(f"expected [nq, {self.dim}] queries, got {tuple(q.shape)}")
         return q
 
-    def search_async(self, queries, k: int, id_base: int = 0, out: tuple[torch.Tensor, torch.Tensor] | None = None):
-        """Enqueue a search on the current stream; call `finish()` before trusting the outputs."""
+    def search_async(self, queries, k: int, id_base: int = 0, out: tuple[torch.Tensor, torch.Tensor] | None = None,
+                     subset: np.ndarray | torch.Tensor | None = None):
+        """Enqueue a search on the current stream; call `finish()` before trusting the outputs.
+
+        `subset`: optional int32 [nq, S] allowed row labels per query (-1 = empty slot, all -1 = unrestricted)."""
         q = self._prep_queries(queries)
         nq = q.shape[0]
+        if subset is not None:
+            sub = subset if isinstance(subset, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(subset))
+            sub = sub.to(self.device, torch.int32).contiguous()
+            if sub.ndim != 2 or sub.shape[0] != nq:
+                raise ValueError(f"expected subset labels of shape [{nq}, S], got {tuple(sub.shape)}")
+            self._keep_subset = sub
+            _native.check(self._lib.vodhip_index_set_query_labels(self._h, sub.data_ptr(), int(sub.shape[1])))
+        else:
+            self._keep_subset = None
+            _native.check(self._lib.vodhip_index_set_query_labels(self._h, None, 0))
         if out is None:
             scores = torch.empty((nq, k), dtype=torch.float32, device=self.device)
             ids = torch.empty((nq, k), dtype=torch.int64, device=self.device)
@@ -178,10 +207,10 @@ class HipFlatIndex:
         _native.check(self._lib.vodhip_index_search_finish(self._h, _native.current_stream_ptr(self.device)))
         self._keep = None
 
-    def search(self, queries, k: int, id_base: int = 0, out=None) -> tuple[torch.Tensor, torch.Tensor]:
+    def search(self, queries, k: int, id_base: int = 0, out=None, subset=None) -> tuple[torch.Tensor, torch.Tensor]:
         """Exact top-k by inner product: (scores f32 [nq,k] desc, ids i64 [nq,k]); ties -> smaller id; pad -inf/-1."""
         with torch.cuda.device(self.device):
-            res = self.search_async(queries, k, id_base, out)
+            res = self.search_async(queries, k, id_base, out, subset)
             self.finish()
         return res
 
