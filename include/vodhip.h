@@ -94,7 +94,8 @@ int vodhip_index_search_finish(vodhip_index_t* index, void* stream);
  * qdrant_search/client.py:124-136) while its faiss client ignores it (faiss_search/client.py:67-72).  Here every stored
  * row may carry an int32 label (`labels` [n_rows], host or device; NULL clears), and the next searches may pass, per
  * query, up to `n_per_query` allowed labels (DEVICE int32 [nq, n_per_query], caller-owned until cleared with NULL;
- * -1 = empty slot; a query whose slots are all -1 is unrestricted).  A row is eligible iff its label is listed.
+ * -1 = empty slot; a query whose slots are all -1 is unrestricted; any other value, e.g. -2 for an unknown id,
+ * restricts the query).  A row is eligible iff its label is listed.
  * Results stay exact top-k over the eligible rows. */
 int vodhip_index_set_row_labels(vodhip_index_t* index, const int32_t* labels, int64_t n_rows, int location, void* stream);
 int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels_dev, int n_per_query);

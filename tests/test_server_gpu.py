@@ -65,3 +65,42 @@ def test_index_save_load_roundtrip(tmp_path):
             assert torch.equal(b.stored_rows(), stored)  # re-rounding stored values is the identity
             got = b.search(q, 20)
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+
+def test_server_subset_ids_roundtrip(tmp_path, monkeypatch):
+    """`subset_ids` forwarded over the wire and honoured by the GPU index (the reference's faiss client drops them)."""
+    from oracle.flat_ip import topk_desc_tiebreak
+    from vod_amd import store
+    from vod_amd.search.client import HipMipsClient, HipMipsMaster
+
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(3)
+    n, d, nq, k = 20000, 64, 12, 10
+    x = rng.integers(-8, 9, size=(n, d)).astype(np.float32)
+    q = rng.integers(-8, 9, size=(nq, d)).astype(np.float32)
+    names = np.array([f"doc{v}" for v in rng.integers(0, 7, size=n)])
+    store.save_vectors(tmp_path / "v.npy", x, dtype=np.float16)
+    np.save(tmp_path / "subsets.npy", names)
+
+    class Master(HipMipsMaster):
+        def _make_cmd(self):
+            return super()._make_cmd() + ["--subset-ids-path", str(tmp_path / "subsets.npy")]
+
+    subset_ids = [[f"doc{r % 7}"] if r % 3 else [] for r in range(nq)]
+    subset_ids[1] = ["doc1", "doc5"]
+    subset_ids[2] = ["nope"]  # unknown id: restricted to nothing
+    with Master(tmp_path / "v.npy", port=-1, logging_level="warning") as m:
+        c = HipMipsClient(host=m.host, port=m.port, forward_subset_ids=True)
+        res = c.search(vector=q, subset_ids=subset_ids, top_k=k)
+        plain = m.get_client().search(vector=q, subset_ids=subset_ids, top_k=k)  # reference behaviour: ignored
+    full = q.astype(np.float64) @ x.astype(np.float64).T
+    rs, ri = topk_desc_tiebreak(full, k)
+    np.testing.assert_array_equal(plain.indices, ri)
+    masked = full.copy()
+    for r, names_r in enumerate(subset_ids):
+        if names_r:
+            masked[r, ~np.isin(names, names_r)] = np.nan
+    ms, mi = topk_desc_tiebreak(masked, k)
+    np.testing.assert_array_equal(res.indices, mi)
+    np.testing.assert_array_equal(res.scores, ms)
+    assert np.all(res.indices[2] == -1)

@@ -68,7 +68,7 @@ __device__ __forceinline__ bool subset_allows(const FilterExtra& ex, int q, int 
 #pragma unroll 1
     for (int s = 0; s < ex.n_qlab; ++s) {
         const int ql = ex.q_label[(size_t)q * ex.n_qlab + s];
-        any |= ql >= 0;
+        any |= ql != -1;  // -1 = empty slot; any other value (incl. an unknown id mapped to -2) restricts the query
         ok |= ql == lab;
     }
     return ok || !any;

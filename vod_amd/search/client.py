@@ -28,10 +28,13 @@ class HipMipsClient(base.SearchClient):
 
     requires_vectors = True
 
-    def __init__(self, host: str = "http://localhost", port: int = 7678, binary: bool = False):
+    def __init__(self, host: str = "http://localhost", port: int = 7678, binary: bool = False, forward_subset_ids: bool = False):
         self.host = host
         self.port = port
         self.binary = binary  # use the raw-bytes route (`/raw-search`) instead of base64-in-JSON (`/fast-search`)
+        # The reference's faiss client drops `subset_ids`; set this to let the GPU index honour them (the server must
+        # have been started with `--subset-ids-path`).
+        self.forward_subset_ids = forward_subset_ids
 
     def __repr__(self) -> str:
         return f"{type(self).__name__}[{self.url}](requires_vectors={self.requires_vectors})"
@@ -60,16 +63,18 @@ class HipMipsClient(base.SearchClient):
         *,
         vector: np.ndarray,
         text: None | list[str] = None,  # noqa: ARG002
-        subset_ids: None | list[list[base.SubsetId]] = None,  # noqa: ARG002
+        subset_ids: None | list[list[base.SubsetId]] = None,
         ids: None | list[list[base.SectionId]] = None,  # noqa: ARG002
         shard: None | list[base.ShardName] = None,  # noqa: ARG002
         top_k: int = 3,
         timeout: float = 120,
     ) -> vt.RetrievalBatch:
         start = time.time()
-        if self.binary:
+        if self.binary and not (self.forward_subset_ids and subset_ids is not None):
             return self._search_binary(np.asarray(vector), top_k, timeout, start)
         payload = {"vectors": io.serialize_np_array(np.asarray(vector)), "top_k": top_k}
+        if self.forward_subset_ids and subset_ids is not None:
+            payload["subset_ids"] = [list(map(str, s)) for s in subset_ids]
         response = requests.post(f"{self.url}/fast-search", json=payload, timeout=timeout)
         try:
             response.raise_for_status()

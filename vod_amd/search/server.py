@@ -36,6 +36,8 @@ class FastSearchQuery(pydantic.BaseModel):
     model_config = pydantic.ConfigDict(extra="forbid")
     vectors: str = pydantic.Field(..., description="A batch of vectors, np.save bytes in urlsafe base64.")
     top_k: int = 3
+    # extension (absent in the reference's model, whose faiss client drops `subset_ids`): per-query allowed subset ids
+    subset_ids: None | list[list[str]] = None
 
 
 class SearchResponse(pydantic.BaseModel):
@@ -56,11 +58,16 @@ def create_app(engine) -> FastAPI:
     app = FastAPI()
     lock = threading.Lock()
 
-    def _search(query_vec: np.ndarray, top_k: int) -> tuple[np.ndarray, np.ndarray]:
+    def _search(query_vec: np.ndarray, top_k: int, subset_ids=None) -> tuple[np.ndarray, np.ndarray]:
         if query_vec.ndim != 2:
             raise ValueError(f"Expected 2D array, got {query_vec.ndim}D array")
         with lock:
-            scores, indices = engine.search(query_vec, top_k)
+            if subset_ids is not None and any(len(s) for s in subset_ids):
+                if len(subset_ids) != len(query_vec):
+                    raise ValueError("`subset_ids` must have one list per query")
+                scores, indices = engine.search(query_vec, top_k, subset_ids=subset_ids)
+            else:
+                scores, indices = engine.search(query_vec, top_k)
         return np.asarray(scores, dtype=np.float32), np.asarray(indices, dtype=np.int64)
 
     @app.get("/")
@@ -81,7 +88,7 @@ def create_app(engine) -> FastAPI:
     @app.post("/fast-search")
     def fast_search(query: FastSearchQuery) -> FastSearchResponse:
         try:
-            scores, indices = _search(io.deserialize_np_array(query.vectors), query.top_k)
+            scores, indices = _search(io.deserialize_np_array(query.vectors), query.top_k, query.subset_ids)
             return FastSearchResponse(scores=io.serialize_np_array(scores), indices=io.serialize_np_array(indices))
         except Exception as exc:
             raise HTTPException(status_code=500, detail=traceback.format_exc()) from exc
@@ -109,7 +116,7 @@ def create_app(engine) -> FastAPI:
 class HipEngine:
     """The production engine: a `HipFlatIndex` fed from a vector file, searched on the GPU."""
 
-    def __init__(self, vectors_path: str, dtype: str = "float16", device: int = 0):
+    def __init__(self, vectors_path: str, dtype: str = "float16", device: int = 0, subset_ids_path: str | None = None):
         import torch
 
         from vod_amd import store
@@ -122,15 +129,32 @@ class HipEngine:
         step = 262144
         for lo in range(0, n, step):  # H2D in slices; the store converts to fp16/bf16 on the device
             self.index.add(np.ascontiguousarray(vectors[lo : lo + step]))
+        self.vocab: dict[str, int] = {}
+        if subset_ids_path:  # one subset id (string) per stored row -> int32 labels on the device
+            ids = np.load(subset_ids_path, allow_pickle=False)
+            if len(ids) != n:
+                raise ValueError(f"{subset_ids_path}: {len(ids)} subset ids for {n} vectors")
+            uniq, codes = np.unique(ids.astype(str), return_inverse=True)
+            self.vocab = {str(u): i for i, u in enumerate(uniq)}
+            self.index.set_row_labels(codes.astype(np.int32))
 
     @property
     def ntotal(self) -> int:
         return self.index.ntotal
 
-    def search(self, query_vec: np.ndarray, top_k: int) -> tuple[np.ndarray, np.ndarray]:
+    def search(self, query_vec: np.ndarray, top_k: int, subset_ids: list[list[str]] | None = None) -> tuple[np.ndarray, np.ndarray]:
         if query_vec.shape[1] != self.index.dim:
             raise ValueError(f"query dimension {query_vec.shape[1]} != index dimension {self.index.dim}")
-        scores, ids = self.index.search(query_vec, top_k)
+        subset = None
+        if subset_ids is not None:
+            if not self.vocab:
+                raise ValueError("the server was started without --subset-ids-path: cannot filter by subset id")
+            width = max(1, max(len(s) for s in subset_ids))
+            subset = np.full((len(subset_ids), width), -1, dtype=np.int32)
+            for r, names in enumerate(subset_ids):
+                # an unknown subset id matches no row: -2 keeps the query restricted (and empty) instead of unrestricted
+                subset[r, : len(names)] = [self.vocab.get(str(nm), -2) for nm in names]
+        scores, ids = self.index.search(query_vec, top_k, subset=subset)
         return scores.cpu().numpy(), ids.cpu().numpy()
 
 
@@ -142,6 +166,7 @@ def parse_args() -> argparse.Namespace:
     p.add_argument("--logging-level", type=str, default="INFO")
     p.add_argument("--dtype", type=str, default="float16", choices=["float16", "bfloat16"])
     p.add_argument("--device", type=int, default=0)
+    p.add_argument("--subset-ids-path", type=str, default=None, help=".npy with one subset id (string) per vector")
     return p.parse_args()
 
 
@@ -149,7 +174,7 @@ def main() -> None:
     import uvicorn
 
     args = parse_args()
-    engine = HipEngine(args.vectors_path, dtype=args.dtype, device=args.device)
+    engine = HipEngine(args.vectors_path, dtype=args.dtype, device=args.device, subset_ids_path=args.subset_ids_path)
     host = re.sub(r"^(http|https)://", "", args.host)
     uvicorn.run(create_app(engine), host=host, port=args.port, workers=1, log_level=args.logging_level.lower())
 
