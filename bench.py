@@ -44,6 +44,7 @@ def parse_args() -> argparse.Namespace:
     p.add_argument("--dtype", choices=["f16", "bf16"], default="f16")
     p.add_argument("--tile", type=int, default=0)
     p.add_argument("--growth", type=int, default=0, help="chunk growth factor x100 (0 = library default)")
+    p.add_argument("--small-chunk-tiles", type=int, default=-1)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -87,6 +88,8 @@ def main() -> None:
         index.set_param("tile", args.tile)
     if args.growth:
         index.set_param("growth", args.growth)
+    if args.small_chunk_tiles >= 0:
+        index.set_param("small_chunk_tiles", args.small_chunk_tiles)
     t_build0 = time.perf_counter()
     for c in range(c_lo, c_hi):
         g = torch.Generator(device=dev).manual_seed(1234 + c)

@@ -74,6 +74,7 @@ struct vodhip_index {
     int64_t force_safe = 0;
     int64_t tile = 0;
     int64_t krot = 0;
+    int64_t small_chunk_tiles = 1024;  // launches with fewer 256x256 tiles than this use the 128x128 kernel
     int64_t profile = 0;  // 1: bracket every filter launch with HIP events (bench / roofline accounting)
     // stats
     int64_t last_overflow = 0, last_chunks = 0, last_safe_reruns = 0;
@@ -164,6 +165,7 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
 
     const int q_es = elem_size(ps.q_dtype);
     int tile = (int)ix->tile;
+    const bool tile_auto = tile == 0;
     // auto: 128x128 tile (2 workgroups / CU) up to 128 queries; persistent 256x256 tile on v_mfma_f32_16x16x32 above,
     // with the corpus operand fetched two slices ahead (3 + 2 LDS slots) when ONE q-tile makes every corpus read an HBM miss
     if (tile == 0) tile = ps.nq > 256 ? 9 : (ps.nq > 128 ? 10 : 1);
@@ -196,7 +198,14 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
                 ev1 = ix->ev_pool[ix->ev_used++];
                 HIP_OK(hipEventRecord(ev0, stream));
             }
-            HIP_OK(launch_filter(ix->dtype, tile, dense[c], ix->data, ws.q_pad, ix->dim_pad, chunks[c].first,
+            // short warm-up chunks do not fill 256 CUs with 256x256 tiles (a few tiles per workgroup at most, and their
+            // epilogues are heavy with survivors): run those launches on 128x128 tiles, 2 workgroups per CU
+            int tile_c = tile;
+            if (tile_auto && tile != 1) {
+                const int64_t tiles256 = ((chunks[c].second - chunks[c].first + 255) / 256) * (nq_pad / 256);
+                if (tiles256 < ix->small_chunk_tiles) tile_c = 1;
+            }
+            HIP_OK(launch_filter(ix->dtype, tile_c, dense[c], ix->data, ws.q_pad, ix->dim_pad, chunks[c].first,
                                  chunks[c].second, nq, nq_pad, ws, stream));
             if (ix->profile) HIP_OK(hipEventRecord(ev1, stream));
             HIP_OK(launch_select(ws, nq, k, dense[c] ? chunks[c].second - chunks[c].first : -1, c + 1 == chunks.size(), stream));
@@ -432,6 +441,8 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
         ix->growth_x100 = value;  // growth factor * 100; 0 = derive from k
     } else if (!strcmp(key, "force_safe")) {
         ix->force_safe = value;
+    } else if (!strcmp(key, "small_chunk_tiles")) {
+        ix->small_chunk_tiles = value;
     } else if (!strcmp(key, "krot")) {
         ix->krot = value;
     } else if (!strcmp(key, "profile")) {
