@@ -243,3 +243,47 @@ def test_store_roundtrip_and_factory_protocol(tmp_path):
         factory.build_hip_mips_index(x + 2, config={"port": 23456}, cache_dir=tmp_path / "other", skip_setup=True)
     with pytest.raises(ValueError):
         factory.build_hip_mips_index(x, config={"factory": "IVF100,Flat"}, cache_dir=tmp_path)
+
+
+def test_micro_batcher_fuses_concurrent_requests_and_splits_results():
+    import threading
+
+    from vod_amd.search.server import MicroBatcher
+
+    rng = np.random.default_rng(2)
+    x = rng.integers(-4, 5, size=(500, 8)).astype(np.float32)
+
+    class Counting(_OracleEngine):
+        calls = 0
+        sizes: list = []
+
+        def search(self, q, k):
+            Counting.calls += 1
+            Counting.sizes.append((len(q), k))
+            return super().search(q, k)
+
+    eng = Counting(x)
+    mb = MicroBatcher(eng, max_wait_s=0.25)
+    qs = [rng.integers(-4, 5, size=(n, 8)).astype(np.float32) for n in (3, 1, 5, 2)]
+    ks = [4, 9, 2, 9]
+    out = [None] * 4
+
+    def work(i):
+        out[i] = mb.search(qs[i], ks[i])
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=20)
+    assert Counting.calls < 4 and sum(n for n, _ in Counting.sizes) == 11      # fused into fewer scans
+    assert all(k == 9 for n, k in Counting.sizes if n > 5) or Counting.calls >= 1
+    from oracle.flat_ip import flat_ip_topk
+
+    for i in range(4):
+        rs, ri = flat_ip_topk(qs[i], x, ks[i])
+        np.testing.assert_array_equal(out[i][1], ri)                               # identical to separate searches
+        np.testing.assert_array_equal(out[i][0], rs)
+    # errors reach every waiting caller
+    with pytest.raises(ValueError):
+        mb.search(np.zeros((1, 5), dtype=np.float32), 3)

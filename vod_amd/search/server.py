@@ -52,21 +52,89 @@ class FastSearchResponse(pydantic.BaseModel):
     indices: str
 
 
-def create_app(engine) -> FastAPI:
+class MicroBatcher:
+    """Fuse concurrent requests into one GPU batch.
+
+    Every dataloader worker of every trainer rank sends its own small batch (the reference serialises them on one
+    uvicorn worker, server.py:69,78,98).  A brute-force scan reads the whole corpus per batch whatever its size, so
+    answering R waiting requests with ONE scan costs about as much as answering one.  Requests wait at most
+    `max_wait_s` for company; the fused batch runs with k = max(k_i) and each caller gets its own rows and columns
+    (a top-k prefix of a top-k' list is the top-k, so results are identical to separate searches).
+    """
+
+    def __init__(self, engine, max_wait_s: float = 0.001, max_queries: int = 2048):
+        import queue
+
+        self.engine = engine
+        self.max_wait_s = max_wait_s
+        self.max_queries = max_queries
+        self._q: "queue.Queue" = queue.Queue()
+        self._thread = threading.Thread(target=self._run, daemon=True, name="vodhip-microbatch")
+        self._thread.start()
+
+    def search(self, query_vec: np.ndarray, top_k: int) -> tuple[np.ndarray, np.ndarray]:
+        import concurrent.futures
+
+        fut: "concurrent.futures.Future" = concurrent.futures.Future()
+        self._q.put((query_vec, top_k, fut))
+        return fut.result()
+
+    def _run(self) -> None:
+        import queue
+        import time
+
+        while True:
+            batch = [self._q.get()]
+            deadline = time.monotonic() + self.max_wait_s
+            n = len(batch[0][0])
+            while n < self.max_queries:
+                remaining = deadline - time.monotonic()
+                if remaining <= 0:
+                    break
+                try:
+                    item = self._q.get(timeout=remaining)
+                except queue.Empty:
+                    break
+                batch.append(item)
+                n += len(item[0])
+            try:
+                dims = {b[0].shape[1] for b in batch}
+                if len(dims) != 1:
+                    raise ValueError(f"queries of different dimensions in one batch: {sorted(dims)}")
+                k_max = max(b[1] for b in batch)
+                fused = np.concatenate([np.asarray(b[0], dtype=np.float32) for b in batch], axis=0)
+                scores, indices = self.engine.search(fused, k_max)
+                lo = 0
+                for vec, k, fut in batch:
+                    hi = lo + len(vec)
+                    fut.set_result((np.asarray(scores[lo:hi, :k]), np.asarray(indices[lo:hi, :k])))
+                    lo = hi
+            except Exception as exc:  # every waiting caller gets the error (HTTP 500 with the trace)
+                for _, _, fut in batch:
+                    if not fut.done():
+                        fut.set_exception(exc)
+
+
+def create_app(engine, micro_batch_wait_ms: float = 0.0) -> FastAPI:
     """Build the FastAPI app around a search engine.  Requests are serialised (one GPU stream, like the
-    reference's single uvicorn worker running faiss synchronously, server.py:69,78,98)."""
+    reference's single uvicorn worker running faiss synchronously, server.py:69,78,98) or, with
+    `micro_batch_wait_ms > 0`, fused into shared GPU batches by `MicroBatcher`."""
     app = FastAPI()
     lock = threading.Lock()
+    batcher = MicroBatcher(engine, max_wait_s=micro_batch_wait_ms / 1e3) if micro_batch_wait_ms > 0 else None
 
     def _search(query_vec: np.ndarray, top_k: int, subset_ids=None) -> tuple[np.ndarray, np.ndarray]:
         if query_vec.ndim != 2:
             raise ValueError(f"Expected 2D array, got {query_vec.ndim}D array")
-        with lock:
-            if subset_ids is not None and any(len(s) for s in subset_ids):
-                if len(subset_ids) != len(query_vec):
-                    raise ValueError("`subset_ids` must have one list per query")
+        if subset_ids is not None and any(len(s) for s in subset_ids):
+            if len(subset_ids) != len(query_vec):
+                raise ValueError("`subset_ids` must have one list per query")
+            with lock:
                 scores, indices = engine.search(query_vec, top_k, subset_ids=subset_ids)
-            else:
+        elif batcher is not None:
+            scores, indices = batcher.search(query_vec, top_k)
+        else:
+            with lock:
                 scores, indices = engine.search(query_vec, top_k)
         return np.asarray(scores, dtype=np.float32), np.asarray(indices, dtype=np.int64)
 
@@ -167,6 +235,8 @@ def parse_args() -> argparse.Namespace:
     p.add_argument("--dtype", type=str, default="float16", choices=["float16", "bfloat16"])
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--subset-ids-path", type=str, default=None, help=".npy with one subset id (string) per vector")
+    p.add_argument("--micro-batch-wait-ms", type=float, default=0.0,
+                   help="> 0: fuse requests that arrive within this window into one GPU batch (default: serialise, as the reference)")
     return p.parse_args()
 
 
@@ -176,7 +246,8 @@ def main() -> None:
     args = parse_args()
     engine = HipEngine(args.vectors_path, dtype=args.dtype, device=args.device, subset_ids_path=args.subset_ids_path)
     host = re.sub(r"^(http|https)://", "", args.host)
-    uvicorn.run(create_app(engine), host=host, port=args.port, workers=1, log_level=args.logging_level.lower())
+    uvicorn.run(create_app(engine, micro_batch_wait_ms=args.micro_batch_wait_ms), host=host, port=args.port, workers=1,
+                log_level=args.logging_level.lower())
 
 
 if __name__ == "__main__":
