@@ -354,3 +354,25 @@ def test_subset_filtered_search(tile):
     assert np.all(ri[5] == -1)
     us, ui = topk_desc_tiebreak(full, k)
     np.testing.assert_array_equal(i2.cpu().numpy(), ui)
+
+
+def test_error_behaviour_is_loud():
+    from vod_amd._native import NativeLibraryError
+
+    q, x = _int_data(3, 100, 64, 4)
+    with _index(x, capacity=100) as ix:
+        with pytest.raises(NativeLibraryError, match="index full"):
+            ix.add(x[:1])
+        with pytest.raises(ValueError):
+            ix.add(np.zeros((2, 63), dtype=np.float16))            # wrong dimension
+        with pytest.raises(ValueError):
+            ix.search(torch.zeros((2, 65), device="cuda"), 3)      # wrong query dimension
+        with pytest.raises(NativeLibraryError, match="out of range"):
+            ix.search(torch.from_numpy(q).cuda(), 0)
+        with pytest.raises(NativeLibraryError, match="out of range"):
+            ix.search(torch.from_numpy(q).cuda(), 4096)
+        with pytest.raises(NativeLibraryError, match="row labels first"):
+            ix.search(torch.from_numpy(q).cuda(), 3, subset=np.zeros((4, 1), dtype=np.int32))
+        with pytest.raises(NativeLibraryError, match="unknown parameter"):
+            ix.set_param("nope", 1)
+        _assert_exact(ix, q, x, 5)                                 # the handle is still usable after the errors

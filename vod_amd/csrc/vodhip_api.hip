@@ -373,8 +373,8 @@ int vodhip_index_set_query_labels(vodhip_index_t* ix, const int32_t* q_labels_de
 int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dtype, int64_t nq, int k, int64_t id_base,
                               float* out_scores, int64_t* out_ids, void* stream_) {
     if (!ix) return fail("index is NULL");
-    if (nq < 0 || (nq > 0 && (!queries || !out_scores || !out_ids))) return fail("invalid query / output pointers");
     if (k < 1 || k > VODHIP_MAX_K) return fail("k=%d out of range [1, %d]", k, VODHIP_MAX_K);
+    if (nq < 0 || (nq > 0 && (!queries || !out_scores || !out_ids))) return fail("invalid query / output pointers");
     if (q_dtype < 0 || q_dtype > 2) return fail("invalid q_dtype %d", q_dtype);
     if (ix->cand_cap < ROW_ALIGN || ix->cand_cap < k) return fail("cand_cap too small");
     HIP_OK(hipSetDevice(ix->device));
