@@ -82,14 +82,25 @@ __device__ __forceinline__ void append_survivors(float thr, int q, int row_end, 
     const key_t64 tk = thr_key[q];
     if constexpr (!SUBSET) {
         unsigned n_hit = 0;
+        key_t64 key1 = 0;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const float sc = val(i);
             const int rw = row(i);
-            n_hit += (sc >= thr && rw < row_end && make_key(sc, (unsigned)rw) > tk) ? 1u : 0u;
+            const key_t64 key = make_key(sc, (unsigned)rw);
+            const bool p = sc >= thr && rw < row_end && key > tk;
+            n_hit += p ? 1u : 0u;
+            key1 = p ? key : key1;
         }
         if (n_hit == 0) return;
         unsigned slot = atomicAdd(&cnt[q], n_hit);
+        if (n_hit == 1) {  // the common case once the threshold is tight: no walk through NV predicated stores
+            if (slot < (unsigned)cap)
+                cand[(size_t)q * cap + slot] = key1;
+            else
+                atomicOr(overflow, 1u);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const float sc = val(i);
@@ -902,7 +913,10 @@ __global__ __launch_bounds__(512, 2) void mips_filter16_kernel(
 // during the current tile's last slice, so its HBM latency hides behind that slice's MFMAs and the threshold-filter
 // epilogue instead of opening every tile with an idle matrix pipe (measured prologue: ~2,200 cycles of a 48,000
 // cycle tile), and there is no per-tile workgroup launch / drain.
-template <int DT, bool A3 = false, bool SUBSET = false>
+constexpr int PSTG_CAP = 1024;    // records in the LDS survivor list of the persistent kernel
+constexpr int PSTG_FLUSH = 384;   // flush when at least this many are pending (checked once per tile)
+constexpr int PSTG_BYTES = PSTG_CAP * 12 + 16;
+template <int DT, bool A3 = false, bool SUBSET = false, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
     int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
@@ -913,8 +927,17 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
     constexpr int ROW_BYTES = BK * 2, RPI = 8;
     constexpr int A_BYTES = BM * ROW_BYTES, STAGE_BYTES = (BM + BN) * ROW_BYTES;
     constexpr int NA = BM / RPI / NWAVES, NBI = BN / RPI / NWAVES, G = NA + NBI;
+    // Survivor staging (two-slot layout only; the A3 layout has no LDS to spare): a lane that finds survivors appends
+    // (key, query) records to a workgroup list in LDS with ONE LDS atomic - no global round trip, and no vmcnt wait
+    // that would drain the LDS-DMAs in flight across the epilogue.  The list is flushed to the global candidate
+    // lists (exact-key test, subset test, one global atomic per record, all records in parallel) when it holds
+    // PSTG_FLUSH records and at the end of the kernel.  A lane whose reservation does not fit takes the direct path.
+    constexpr bool STAGED = !A3;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    key_t64* const stg_key = (key_t64*)(smem + NSTAGE * STAGE_BYTES);
+    int* const stg_q = (int*)(smem + NSTAGE * STAGE_BYTES + PSTG_CAP * 8);
+    unsigned* const stg_cnt = (unsigned*)(smem + NSTAGE * STAGE_BYTES + PSTG_CAP * 12);
     const int bid = blockIdx.x;
     const int xcd = bid & 7, jj = bid >> 3;
     const int qt = jj % n_qtiles;
@@ -983,6 +1006,13 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
         const int q = q0 + wn * TN + j * 16 + fr;
         thr[j] = (q < nq) ? thr_s[q] : __builtin_inff();
     }
+#ifdef VODHIP_ABLATION
+    if constexpr (STAMP) {  // bit 1 of the flags: no survivors at all (epilogue floor)
+        if (ex.flags & 2)
+#pragma unroll
+            for (int j = 0; j < NB16; ++j) thr[j] = __builtin_inff();
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < NB16; ++j) asm volatile("" : "+v"(thr[j]));
     // stream state of the A3 variant: next slice to fetch for each operand (global slice index, tile-local k index)
@@ -1014,8 +1044,41 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
         stage_part(0, 0, 0, 1);
     }
 
+    if constexpr (STAGED) {
+        for (int e = tid; e < PSTG_CAP; e += 512) stg_key[e] = 0;  // key 0 = empty record
+        if (tid == 0) *stg_cnt = 0;
+        // made visible by the barrier of the first K slice (which every wave passes before its first epilogue)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    auto flush_staged = [&](unsigned c) {  // called by all 512 threads with the same c
+        if (c > (unsigned)PSTG_CAP) c = PSTG_CAP;
+        for (unsigned e = tid; e < c; e += 512) {
+            const key_t64 key = stg_key[e];
+            const int q = stg_q[e];
+            stg_key[e] = 0;
+            if (key == 0) continue;  // reserved by a lane that then took the direct path
+            bool ok = key > thr_key[q];
+            if constexpr (SUBSET) ok = ok && subset_allows(ex, q, (int)(0xFFFFFFFFu - (unsigned)key));
+            if (ok) {
+                const unsigned slot = atomicAdd(&cnt[q], 1u);
+                if (slot < (unsigned)cap)
+                    cand[(size_t)q * cap + slot] = key;
+                else
+                    atomicOr(overflow, 1u);
+            }
+        }
+    };
+
     int g = 0;  // global slice counter of this workgroup: LDS slot = g & 1
+#ifdef VODHIP_ABLATION
+    unsigned long long st_k = 0, st_e = 0, st_t0 = 0, st_e1 = 0, st_e2 = 0, st_nhit = 0;
+    if constexpr (STAMP) st_t0 = stamp_now();
+#endif
     for (int it = 0; it < n_my; ++it) {
+#ifdef VODHIP_ABLATION
+        unsigned long long st_a = 0, st_b = 0;
+        if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_a = stamp_now(); }
+#endif
         const int x0 = row_begin + (xt0 + it * xt_step) * BM;
         f32x4 acc[MB][NB16];
 #pragma unroll
@@ -1080,6 +1143,9 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
             }
         }
 
+#ifdef VODHIP_ABLATION
+        if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_b = stamp_now(); st_k += st_b - st_a; }
+#endif
         // threshold filter of this tile (the next tile's first slice is already in flight)
 #pragma unroll
         for (int j = 0; j < NB16; ++j) {
@@ -1091,13 +1157,105 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
                 for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[i][j][r]);
             const bool hit = m >= thr[j];
             if (__any(hit)) {
-                if (hit)
-                    append_survivors<MB * 4, SUBSET>(
-                        thr[j], q, row_end, [&](int v) { return acc[v >> 2][j][v & 3]; },
-                        [&](int v) { return x0 + wm * TM + (v >> 2) * 16 + 4 * fq + (v & 3); }, thr_key, cand, cnt, cap, overflow, ex);
+#ifdef VODHIP_ABLATION
+                if constexpr (STAMP) ++st_nhit;
+#endif
+                if (hit) {
+                    auto val = [&](int v) { return acc[v >> 2][j][v & 3]; };
+                    auto row = [&](int v) { return x0 + wm * TM + (v >> 2) * 16 + 4 * fq + (v & 3); };
+                    if constexpr (STAGED) {
+                        static_assert(MB * 4 <= 32, "survivor mask is 32 bits");
+                        // the common case - ONE score of the lane passes, and it is the lane maximum m - runs through
+                        // short straight-line code; several survivors in one lane take the general path below
+                        unsigned n1 = 0;
+                        int off1 = 0;
+#pragma unroll
+                        for (int v = 0; v < MB * 4; ++v) {
+                            const bool p = val(v) >= thr[j];
+                            n1 += p ? 1u : 0u;
+                            off1 = p ? (v >> 2) * 16 + (v & 3) : off1;
+                        }
+                        if (n1 == 1) {
+                            const int rw = x0 + wm * TM + 4 * fq + off1;
+                            if (rw < row_end) {
+                                const unsigned pos1 = atomicAdd(stg_cnt, 1u);
+                                const key_t64 key = make_key(m, (unsigned)rw);
+                                if (pos1 < (unsigned)PSTG_CAP) {
+                                    stg_key[pos1] = key;
+                                    stg_q[pos1] = q;
+                                } else {
+                                    bool ok = key > thr_key[q];
+                                    if constexpr (SUBSET) ok = ok && subset_allows(ex, q, rw);
+                                    if (ok) {
+                                        const unsigned slot = atomicAdd(&cnt[q], 1u);
+                                        if (slot < (unsigned)cap)
+                                            cand[(size_t)q * cap + slot] = key;
+                                        else
+                                            atomicOr(overflow, 1u);
+                                    }
+                                }
+                            }
+                        } else {
+                            unsigned mask = 0;
+#pragma unroll
+                            for (int v = 0; v < MB * 4; ++v) mask |= (val(v) >= thr[j] && row(v) < row_end) ? (1u << v) : 0u;
+                            const unsigned n = (unsigned)__builtin_popcount(mask);
+                            unsigned pos = atomicAdd(stg_cnt, n);
+                            if (pos + n <= (unsigned)PSTG_CAP) {
+#pragma unroll
+                                for (int v = 0; v < MB * 4; ++v) {
+                                    if (mask & (1u << v)) {
+                                        stg_key[pos] = make_key(val(v), (unsigned)row(v));
+                                        stg_q[pos] = q;
+                                        ++pos;
+                                    }
+                                }
+                            } else {
+                                append_survivors<MB * 4, SUBSET>(thr[j], q, row_end, val, row, thr_key, cand, cnt, cap, overflow, ex);
+                            }
+                        }
+                    } else {
+                        append_survivors<MB * 4, SUBSET>(thr[j], q, row_end, val, row, thr_key, cand, cnt, cap, overflow, ex);
+                    }
+                }
             }
         }
+#ifdef VODHIP_ABLATION
+        unsigned long long st_c = 0, st_d = 0;
+        if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_c = stamp_now(); st_e1 += st_c - st_b; }
+#endif
+        if constexpr (STAGED) {
+            // every wave's records of this tile are in the list; the decision to flush is workgroup-uniform
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const unsigned c = *(volatile unsigned*)stg_cnt;
+#ifdef VODHIP_ABLATION
+            if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_d = stamp_now(); st_e2 += st_d - st_c; }
+#endif
+            if (c >= (unsigned)PSTG_FLUSH) {
+                flush_staged(c);
+                __syncthreads();  // everyone has read c and its records
+                if (tid == 0) *stg_cnt = 0;
+                // the reset is ordered before the next appends by the barrier of the next K slice
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+#ifdef VODHIP_ABLATION
+        if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_e += stamp_now() - st_b; }
+#endif
     }
+    if constexpr (STAGED) {
+        __syncthreads();
+        flush_staged(*(volatile unsigned*)stg_cnt);
+    }
+#ifdef VODHIP_ABLATION
+    if constexpr (STAMP) {
+        if (gridDim.x == 256 && n_my > 100 && lane == 0 && bid < 64) {
+            unsigned long long* out = g_stamps + ((size_t)bid * 8 + wave) * 16 * 6;
+            out[0] = st_k; out[1] = st_e; out[2] = stamp_now() - st_t0; out[3] = (unsigned long long)n_my; out[4] = st_e1; out[5] = st_e2; out[6] = st_nhit;
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1414,7 +1572,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         int grid = (n_cu / unit) * unit;
         if (grid < unit) grid = unit;
         if (grid > total) grid = total;
-        const size_t lds = tile == 10 ? 160 * 1024 : 128 * 1024;
+        const size_t lds = tile == 10 ? 160 * 1024 : 128 * 1024 + PSTG_BYTES;
 #define VOD_K16P(DT)                                                                                                   \
     {                                                                                                                  \
         auto kern = tile == 10 ? (subset ? mips_filter16p_kernel<DT, true, true> : mips_filter16p_kernel<DT, true, false>)  \
@@ -1507,6 +1665,20 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
     VOD_KNOB(27, 14)  // corpus operand always L2-hot (timing only)
     VOD_KNOB(28, 15)  // L2 touch-prefetch of the next corpus tile (results stay exact)
 #undef VOD_KNOB
+    if (store_dtype == 0 && tile == 29 && !dense) {  // stamped persistent kernel
+        const int n_xtiles = (int)((row_end - row_begin + 255) / 256);
+        const int n_qtiles = (int)(nq_pad / 256);
+        const int unit = 8 * n_qtiles, total = ((n_xtiles + 7) / 8) * unit;
+        int grid = (256 / unit) * unit;
+        if (grid > total) grid = total;
+        auto kern = mips_filter16p_kernel<0, false, false, true>;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + PSTG_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 128 * 1024 + PSTG_BYTES, stream, (const uint16_t*)store, (const uint16_t*)q_pad,
+                           (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s, ws.thr_key, ws.cand,
+                           ws.cnt, (int)ws.cap, ws.overflow, ws.extra);
+        return hipGetLastError();
+    }
     if (store_dtype == 0 && tile == 20 && !dense)  // DMA-only, corpus operand only
         return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 7>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
     if (store_dtype == 0 && tile == 21 && !dense)  // DMA-only, query operand only
@@ -1532,7 +1704,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
     if (store_dtype == 0 && tile == 14 && !dense) {
         return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 4>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
     }
-    if (store_dtype == 0 && tile >= 11 && tile <= 24 && dense)
+    if (store_dtype == 0 && ((tile >= 11 && tile <= 24) || tile == 29) && dense)
         return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, true>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
 #endif
 #undef VOD_FILTER

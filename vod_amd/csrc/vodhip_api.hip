@@ -171,7 +171,7 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
     if (tile == 0) tile = ps.nq > 256 ? 9 : (ps.nq > 128 ? 10 : 1);
     const int64_t bn = filter_tile_cols(tile);
     if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
-    ix->ws.extra.flags = ix->krot ? 1 : 0;
+    ix->ws.extra.flags = (int)ix->krot;  // bit 0: K rotation; bit 1 (ablation builds): no survivors
     ix->ws.extra.row_label = (ix->row_label && ix->q_label) ? ix->row_label : nullptr;
     ix->ws.extra.q_label = ix->q_label;
     ix->ws.extra.n_qlab = ix->n_qlab;
