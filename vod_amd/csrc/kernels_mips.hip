@@ -80,13 +80,18 @@ __device__ __forceinline__ void append_survivors(float thr, int q, int row_end, 
                                                  unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow,
                                                  const FilterExtra& ex) {
     const key_t64 tk = thr_key[q];
+    // opaque zero added to every row index: without it the compiler hoists the NV row keys and row-bound compares
+    // (the same for every query block of the caller) out of this cold path into the caller's per-tile fast path and
+    // spills them - measured at ~1,000 cycles of every 256x256 tile
+    int z = 0;
+    asm volatile("" : "+s"(z));
     if constexpr (!SUBSET) {
         unsigned n_hit = 0;
         key_t64 key1 = 0;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const float sc = val(i);
-            const int rw = row(i);
+            const int rw = (row(i) + z);
             const key_t64 key = make_key(sc, (unsigned)rw);
             const bool p = sc >= thr && rw < row_end && key > tk;
             n_hit += p ? 1u : 0u;
@@ -104,7 +109,7 @@ __device__ __forceinline__ void append_survivors(float thr, int q, int row_end, 
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const float sc = val(i);
-            const int rw = row(i);
+            const int rw = (row(i) + z);
             if (sc >= thr && rw < row_end) {
                 const key_t64 key = make_key(sc, (unsigned)rw);
                 if (key > tk) {
@@ -124,14 +129,14 @@ __device__ __forceinline__ void append_survivors(float thr, int q, int row_end, 
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const float sc = val(i);
-            const int rw = row(i);
+            const int rw = (row(i) + z);
             mask |= (sc >= thr && rw < row_end && make_key(sc, (unsigned)rw) > tk) ? (1u << i) : 0u;
         }
         unsigned m2 = mask;
         while (m2) {
             const int i = __builtin_ctz(m2);
             m2 &= m2 - 1;
-            if (!subset_allows(ex, q, row(i))) mask &= ~(1u << i);
+            if (!subset_allows(ex, q, (row(i) + z))) mask &= ~(1u << i);
         }
         if (mask == 0) return;
         unsigned slot = atomicAdd(&cnt[q], (unsigned)__builtin_popcount(mask));
@@ -139,7 +144,7 @@ __device__ __forceinline__ void append_survivors(float thr, int q, int row_end, 
         for (int i = 0; i < NV; ++i) {
             if (mask & (1u << i)) {
                 if (slot < (unsigned)cap)
-                    cand[(size_t)q * cap + slot] = make_key(val(i), (unsigned)row(i));
+                    cand[(size_t)q * cap + slot] = make_key(val(i), (unsigned)(row(i) + z));
                 else
                     atomicOr(overflow, 1u);
                 ++slot;
@@ -1080,13 +1085,10 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
         if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_a = stamp_now(); }
 #endif
         const int x0 = row_begin + (xt0 + it * xt_step) * BM;
+        // no zero fill (128 v_mov per tile): the first k32 step of the tile's first slice multiplies into a constant-0 C
         f32x4 acc[MB][NB16];
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int j = 0; j < NB16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        for (int t = 0; t < nk; ++t, ++g) {
+        auto do_slice = [&](int t, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             if constexpr (A3) {
                 // everything but the 4 youngest LDS-DMAs (= the corpus slice g+1, if it exists) has landed
                 if (g + 1 < S) wait_vmcnt<NA>(); else wait_vmcnt<0>();
@@ -1127,10 +1129,11 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a1[i] = *(const u32x4*)(base_a + a_row_off + (4 + i) * 16 * ROW_BYTES + slot_off);
+                const bool zero_c = FIRST && ks == 0;  // compile-time after unrolling
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < NB16; ++j) acc[i][j] = mfma16<DT>(a0[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < NB16; ++j) acc[i][j] = mfma16<DT>(a0[i], bf[j], zero_c ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j]);
                 if constexpr (A3) {
                     if (ks == 0) { if (pre_b) issue_b(1); } else { if (pre_a) issue_a(1); }
                 } else {
@@ -1139,9 +1142,13 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < NB16; ++j) acc[4 + i][j] = mfma16<DT>(a1[i], bf[j], acc[4 + i][j]);
+                    for (int j = 0; j < NB16; ++j)
+                        acc[4 + i][j] = mfma16<DT>(a1[i], bf[j], zero_c ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[4 + i][j]);
             }
-        }
+        };
+        do_slice(0, std::true_type{});
+        ++g;
+        for (int t = 1; t < nk; ++t, ++g) do_slice(t, std::false_type{});
 
 #ifdef VODHIP_ABLATION
         if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); st_b = stamp_now(); st_k += st_b - st_a; }
@@ -1161,12 +1168,16 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
                 if constexpr (STAMP) ++st_nhit;
 #endif
                 if (hit) {
+                    // opaque copies: everything derived from the tile's row base and bound stays INSIDE this cold
+                    // path (the compiler otherwise hoists the 32 row keys / bound compares, which do not depend on
+                    // j, into the per-tile fast path and spills them)
+                    int x0_o = x0, row_end_o = row_end;
+                    asm volatile("" : "+s"(x0_o), "+s"(row_end_o));
                     auto val = [&](int v) { return acc[v >> 2][j][v & 3]; };
-                    auto row = [&](int v) { return x0 + wm * TM + (v >> 2) * 16 + 4 * fq + (v & 3); };
+                    auto row = [&](int v) { return x0_o + wm * TM + (v >> 2) * 16 + 4 * fq + (v & 3); };
                     if constexpr (STAGED) {
-                        static_assert(MB * 4 <= 32, "survivor mask is 32 bits");
                         // the common case - ONE score of the lane passes, and it is the lane maximum m - runs through
-                        // short straight-line code; several survivors in one lane take the general path below
+                        // short straight-line code into the LDS list
                         unsigned n1 = 0;
                         int off1 = 0;
 #pragma unroll
@@ -1176,8 +1187,8 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
                             off1 = p ? (v >> 2) * 16 + (v & 3) : off1;
                         }
                         if (n1 == 1) {
-                            const int rw = x0 + wm * TM + 4 * fq + off1;
-                            if (rw < row_end) {
+                            const int rw = x0_o + wm * TM + 4 * fq + off1;
+                            if (rw < row_end_o) {
                                 const unsigned pos1 = atomicAdd(stg_cnt, 1u);
                                 const key_t64 key = make_key(m, (unsigned)rw);
                                 if (pos1 < (unsigned)PSTG_CAP) {
@@ -1195,27 +1206,11 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
                                     }
                                 }
                             }
-                        } else {
-                            unsigned mask = 0;
-#pragma unroll
-                            for (int v = 0; v < MB * 4; ++v) mask |= (val(v) >= thr[j] && row(v) < row_end) ? (1u << v) : 0u;
-                            const unsigned n = (unsigned)__builtin_popcount(mask);
-                            unsigned pos = atomicAdd(stg_cnt, n);
-                            if (pos + n <= (unsigned)PSTG_CAP) {
-#pragma unroll
-                                for (int v = 0; v < MB * 4; ++v) {
-                                    if (mask & (1u << v)) {
-                                        stg_key[pos] = make_key(val(v), (unsigned)row(v));
-                                        stg_q[pos] = q;
-                                        ++pos;
-                                    }
-                                }
-                            } else {
-                                append_survivors<MB * 4, SUBSET>(thr[j], q, row_end, val, row, thr_key, cand, cnt, cap, overflow, ex);
-                            }
+                        } else {  // several survivors in one lane (rare once the threshold is tight): direct path
+                            append_survivors<MB * 4, SUBSET>(thr[j], q, row_end_o, val, row, thr_key, cand, cnt, cap, overflow, ex);
                         }
                     } else {
-                        append_survivors<MB * 4, SUBSET>(thr[j], q, row_end, val, row, thr_key, cand, cnt, cap, overflow, ex);
+                        append_survivors<MB * 4, SUBSET>(thr[j], q, row_end_o, val, row, thr_key, cand, cnt, cap, overflow, ex);
                     }
                 }
             }
