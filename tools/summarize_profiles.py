@@ -10,6 +10,7 @@ for r in list(csv.DictReader(open(st)))[:4]:
     print(r["Name"][:60], r["Calls"], r["AverageNs"], r["Percentage"])
 tot = collections.defaultdict(float)
 per_step = 0
+launches_per_batch = int(json.loads(open(f"gpurun_out/bench_c3_{tag}.json").read().strip().split("\n")[-1])["roofline"]["launches_per_step"])
 for d in ["sq1", "tcc1", "tcc2"]:
     rows = list(csv.DictReader(open(glob.glob(f"gpurun_out/pmc_{tag}/{d}/*/*_counter_collection.csv")[0])))
     per = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -17,7 +18,7 @@ for d in ["sq1", "tcc1", "tcc2"]:
         if "mips_filter" in r["Kernel_Name"]:
             per[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
     ids = sorted(per)
-    per_step = len(ids) // 3  # bench ran warmup 1 + steps 2
+    per_step = launches_per_batch  # the filter launches of the last batch
     for i in ids[-per_step:]:
         for k, v in per[i].items():
             tot[k] += v
