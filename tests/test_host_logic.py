@@ -287,3 +287,103 @@ def test_micro_batcher_fuses_concurrent_requests_and_splits_results():
     # errors reach every waiting caller
     with pytest.raises(ValueError):
         mb.search(np.zeros((1, 5), dtype=np.float32), 3)
+
+
+# ---- zarr v2 vector store (the reference's tensorstore hand-off format, ts_factory.py:57-92) ----
+def _blosc1_frame(data: bytes, typesize: int, blocksize: int, cname: str, shuffle: bool, dont_split: bool) -> bytes:
+    """Assemble a blosc-1 frame from its published layout (header, block starts, split streams), test side only."""
+    import struct
+    import zlib
+
+    import pyarrow as pa
+
+    fmt = {"lz4": 1, "zlib": 3, "zstd": 4}[cname]
+
+    def comp(b: bytes) -> bytes:
+        if cname == "lz4":
+            return pa.Codec("lz4_raw").compress(b).to_pybytes()
+        if cname == "zstd":
+            return pa.Codec("zstd").compress(b).to_pybytes()
+        return zlib.compress(b)
+
+    nbytes = len(data)
+    nblocks = (nbytes + blocksize - 1) // blocksize
+    flags = (1 if shuffle else 0) | (0x10 if dont_split else 0) | (fmt << 5)
+    body, starts = b"", []
+    base = 16 + 4 * nblocks
+    for b in range(nblocks):
+        blk = data[b * blocksize : (b + 1) * blocksize]
+        if shuffle and typesize > 1:
+            nel = len(blk) // typesize
+            arr = np.frombuffer(blk, dtype=np.uint8, count=nel * typesize).reshape(nel, typesize).T
+            blk = np.ascontiguousarray(arr).tobytes() + blk[nel * typesize :]
+        leftover = len(blk) != blocksize
+        split = (not dont_split) and typesize <= 16 and blocksize // typesize >= 128 and not leftover
+        nstreams = typesize if split else 1
+        ssize = len(blk) // nstreams
+        starts.append(base + len(body))
+        for s in range(nstreams):
+            piece = blk[s * ssize : (s + 1) * ssize]
+            c = comp(piece)
+            if len(c) >= len(piece):  # incompressible: stored raw, size == expected size
+                c = piece
+            body += struct.pack("<i", len(c)) + c
+    head = struct.pack("<BBBBIII", 2, 1, flags, typesize, nbytes, blocksize, base + len(body))
+    return head + struct.pack(f"<{nblocks}i", *starts) + body
+
+
+@pytest.mark.parametrize("cname,shuffle,dont_split", [("lz4", True, False), ("lz4", False, False), ("zstd", True, True), ("zlib", True, False)])
+def test_blosc1_container_decoder(cname, shuffle, dont_split):
+    from vod_amd.zarr_store import blosc1_decompress
+
+    rng = np.random.default_rng(3)
+    x = np.round(rng.standard_normal(2500), 1).astype(np.float32)  # compressible, 10,000 bytes: 2 full blocks + leftover
+    raw = x.tobytes()
+    frame = _blosc1_frame(raw, 4, 4096, cname, shuffle, dont_split)
+    assert blosc1_decompress(frame) == raw
+    # stored (memcpy) frames and the refusal of unsupported inner codecs
+    import struct
+
+    assert blosc1_decompress(struct.pack("<BBBBIII", 2, 1, 0x2, 4, len(raw), len(raw), 16 + len(raw)) + raw) == raw
+    bad = bytearray(frame)
+    bad[2] = (bad[2] & 0x1F) | (0 << 5)  # blosclz
+    with pytest.raises(NotImplementedError, match="blosclz"):
+        blosc1_decompress(bytes(bad))
+
+
+@pytest.mark.parametrize("dtype,compressor", [(np.float32, None), (np.float16, {"id": "zlib", "level": 1}), (np.float32, "blosc")])
+def test_zarr_vector_store_reads_what_the_reference_layout_declares(tmp_path, dtype, compressor):
+    from vod_amd import store
+    from vod_amd.zarr_store import ZarrVectors, write_zarr_vectors
+
+    rng = np.random.default_rng(7)
+    x = np.round(rng.standard_normal((1234, 48)), 2).astype(dtype)
+    path = tmp_path / "vectors"
+    if compressor == "blosc":  # tensorstore's default compressor: blosc / lz4 / byte shuffle
+        write_zarr_vectors(path, x, dtype=dtype, chunk_size=100)
+        meta = json.loads((path / ".zarray").read_text())
+        meta["compressor"] = {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}
+        (path / ".zarray").write_text(json.dumps(meta))
+        for f in path.iterdir():
+            if f.name[0].isdigit():
+                f.write_bytes(_blosc1_frame(f.read_bytes(), x.dtype.itemsize, 8192, "lz4", True, False))
+    else:
+        write_zarr_vectors(path, x, dtype=dtype, chunk_size=100, compressor=compressor)
+    assert json.loads((path / "factory.json").read_text())["driver"] == "zarr"
+    z = store.open_vectors(path)
+    assert isinstance(z, ZarrVectors) and z.shape == x.shape and len(z) == 1234 and z.dtype == x.dtype
+    np.testing.assert_array_equal(z[0:1234], x)
+    np.testing.assert_array_equal(z[95:305], x[95:305])  # crosses chunk boundaries
+    np.testing.assert_array_equal(z[1233], x[1233])
+    np.testing.assert_array_equal(z[-1], x[-1])
+    got = np.concatenate([rows for _lo, rows in z.iter_row_blocks(300)])
+    np.testing.assert_array_equal(got, x)
+    # a chunk that was never written reads as the fill value
+    (path / "3.0").unlink()
+    assert np.all(np.isnan(z[300:400])) and np.array_equal(z[200:300], x[200:300])
+    # the factory serves the zarr array in place (no npy copy), the npy hand-off accepts it as a row source
+    from vod_amd import factory
+
+    m = factory.build_hip_mips_index(ZarrVectors(path), config={"port": 23457}, cache_dir=tmp_path / "cache", skip_setup=True)
+    assert m.vectors_path == path and not (tmp_path / "cache" / "indices").exists()
+    np.testing.assert_array_equal(np.load(store.save_vectors(tmp_path / "v.npy", ZarrVectors(path)[0:300].astype(np.float16))), x[:300].astype(np.float16))

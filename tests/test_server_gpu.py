@@ -104,3 +104,23 @@ def test_server_subset_ids_roundtrip(tmp_path, monkeypatch):
     np.testing.assert_array_equal(res.indices, mi)
     np.testing.assert_array_equal(res.scores, ms)
     assert np.all(res.indices[2] == -1)
+
+
+def test_engine_ingests_the_reference_zarr_store_directly(tmp_path):
+    """the tensorstore/zarr array the predict loop writes (float32, 100-row chunks) goes to HBM
+    in one pass -- no float32 faiss copy, no index file."""
+    from oracle.flat_ip import flat_ip_topk
+    from vod_amd.search.server import HipEngine
+    from vod_amd.zarr_store import write_zarr_vectors
+
+    rng = np.random.default_rng(5)
+    n, d, nq, k = 20_050, 96, 17, 20
+    x = rng.integers(-8, 9, size=(n, d)).astype(np.float32)
+    q = rng.integers(-8, 9, size=(nq, d)).astype(np.float32)
+    path = write_zarr_vectors(tmp_path / "vectors", x, dtype=np.float32, chunk_size=100, compressor={"id": "zlib", "level": 1})
+    engine = HipEngine(str(path))
+    assert engine.ntotal == n
+    s, i = engine.search(q, k)
+    rs, ri = flat_ip_topk(q, x, k)
+    np.testing.assert_array_equal(i, ri)
+    np.testing.assert_array_equal(s, rs)

@@ -49,10 +49,17 @@ def build_hip_mips_index(
         config = HipMipsFactoryConfig(**config)
     if config.factory != "Flat" or config.metric != "inner_product":
         raise ValueError("the HIP MIPS engine is an exact inner-product index (factory='Flat', metric='inner_product')")
-    fp = store.fingerprint_vectors(vectors, config.fingerprint())
-    path = pathlib.Path(cache_dir, "indices", f"{fp}.npy")
-    path.parent.mkdir(parents=True, exist_ok=True)
-    if not skip_setup and not path.exists():
+    from vod_amd.zarr_store import ZarrVectors
+
+    if isinstance(vectors, ZarrVectors):
+        # the predict loop's tensorstore/zarr array is served as it lies: no float32 copy, no index file
+        # (the reference re-reads it, casts, adds, writes and re-reads a faiss file: build.py:51-81, factory.py:153-173)
+        path = vectors.path
+    else:
+        fp = store.fingerprint_vectors(vectors, config.fingerprint())
+        path = pathlib.Path(cache_dir, "indices", f"{fp}.npy")
+        path.parent.mkdir(parents=True, exist_ok=True)
+    if not isinstance(vectors, ZarrVectors) and not skip_setup and not path.exists():
         tmp = path.with_suffix(".tmp.npy")
         store.save_vectors(tmp, vectors, dtype=np.float16 if config.dtype == "float16" else np.float32)
         tmp.rename(path)

@@ -195,8 +195,12 @@ class HipEngine:
         n, d = vectors.shape
         self.index = HipFlatIndex(d, max(n, 1), dtype=getattr(torch, dtype), device=device)
         step = 262144
-        for lo in range(0, n, step):  # H2D in slices; the store converts to fp16/bf16 on the device
-            self.index.add(np.ascontiguousarray(vectors[lo : lo + step]))
+        if hasattr(vectors, "iter_row_blocks"):  # zarr store: blocks aligned to its chunk grid, each chunk decoded once
+            for _lo, rows in vectors.iter_row_blocks(step):
+                self.index.add(rows if rows.dtype != np.float64 else rows.astype(np.float32))
+        else:
+            for lo in range(0, n, step):  # H2D in slices; the store converts to fp16/bf16 on the device
+                self.index.add(np.ascontiguousarray(vectors[lo : lo + step]))
         self.vocab: dict[str, int] = {}
         if subset_ids_path:  # one subset id (string) per stored row -> int32 labels on the device
             ids = np.load(subset_ids_path, allow_pickle=False)

@@ -29,9 +29,17 @@ def save_vectors(path: str | pathlib.Path, vectors, dtype=np.float16, chunk: int
     return path
 
 
-def open_vectors(path: str | pathlib.Path) -> np.ndarray:
-    """Memory-map a vector file written by `save_vectors` (or any 2-D float16/float32 `.npy`)."""
+def open_vectors(path: str | pathlib.Path):
+    """Memory-map a vector file written by `save_vectors` (or any 2-D float16/float32 `.npy`).
+
+    A directory holding a zarr v2 array (the reference's tensorstore vector store, ts_factory.py:57-92) is opened
+    as `zarr_store.ZarrVectors` instead: same `.shape` / row-slice interface, chunks decoded on access.
+    """
     path = pathlib.Path(path)
+    if path.is_dir() and (path / ".zarray").exists():
+        from vod_amd.zarr_store import ZarrVectors
+
+        return ZarrVectors(path)
     if path.is_dir():
         path = path / "vectors.npy"
     arr = np.load(path, mmap_mode="r", allow_pickle=False)
