@@ -921,7 +921,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter16_kernel(
 constexpr int PSTG_CAP = 1024;    // records in the LDS survivor list of the persistent kernel
 constexpr int PSTG_FLUSH = 384;   // flush when at least this many are pending (checked once per tile)
 constexpr int PSTG_BYTES = PSTG_CAP * 12 + 16;
-template <int DT, bool A3 = false, bool SUBSET = false, bool STAMP = false>
+template <int DT, bool A3 = false, bool SUBSET = false, bool STAMP = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end,
     int n_xtiles, int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key,
@@ -1018,6 +1018,10 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
             for (int j = 0; j < NB16; ++j) thr[j] = __builtin_inff();
     }
 #endif
+    if constexpr (ABL != 0) {
+#pragma unroll
+        for (int j = 0; j < NB16; ++j) thr[j] = __builtin_inff();
+    }
 #pragma unroll
     for (int j = 0; j < NB16; ++j) asm volatile("" : "+v"(thr[j]));
     // stream state of the A3 variant: next slice to fetch for each operand (global slice index, tile-local k index)
@@ -1118,32 +1122,56 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
             for (int ks = 0; ks < 2; ++ks) {
                 const int slot_off = ((4 * ks + fq) ^ swz) << 4;
                 u32x4 bf[NB16], a0[4], a1[4];
+                if constexpr ((ABL & 2) != 0) {  // timing only: fragments made up in registers, no LDS reads
+#pragma unroll
+                    for (int j = 0; j < NB16; ++j) bf[j] = u32x4{(unsigned)(lane + j), (unsigned)g, 0x3c003c00u, (unsigned)t};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { a0[i] = u32x4{(unsigned)(lane ^ i), 0x3c003c00u, (unsigned)g, 1u}; a1[i] = a0[i]; }
+                }
+                if constexpr ((ABL & 2) == 0) {
 #pragma unroll
                 for (int j = 0; j < NB16; ++j) bf[j] = *(const u32x4*)(base_b + b_row_off + j * 16 * ROW_BYTES + slot_off);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a0[i] = *(const u32x4*)(base_a + a_row_off + i * 16 * ROW_BYTES + slot_off);
+                }
                 if constexpr (A3) {
                     if (ks == 0) { if (pre_b) issue_b(0); } else { if (pre_a) issue_a(0); }
                 } else {
-                    if (pre) stage_part(nslot, kbyte, 2 * ks, 4);
+                    if (pre && !(ABL & 1)) stage_part(nslot, kbyte, 2 * ks, 4);
                 }
+                if constexpr ((ABL & 2) == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a1[i] = *(const u32x4*)(base_a + a_row_off + (4 + i) * 16 * ROW_BYTES + slot_off);
+                }
                 const bool zero_c = FIRST && ks == 0;  // compile-time after unrolling
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < NB16; ++j) acc[i][j] = mfma16<DT>(a0[i], bf[j], zero_c ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j]);
+                    for (int j = 0; j < NB16; ++j) {
+                        if constexpr ((ABL & 4) != 0) {  // consume the fragments (forces the waits) without any instruction
+                            asm volatile("" ::"v"(a0[i]), "v"(bf[j]));
+                            if (zero_c) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        } else {
+                            acc[i][j] = mfma16<DT>(a0[i], bf[j], zero_c ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[i][j]);
+                        }
+                    }
                 if constexpr (A3) {
                     if (ks == 0) { if (pre_b) issue_b(1); } else { if (pre_a) issue_a(1); }
                 } else {
-                    if (pre) stage_part(nslot, kbyte, 2 * ks + 1, 4);
+                    if (pre && !(ABL & 1)) stage_part(nslot, kbyte, 2 * ks + 1, 4);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < NB16; ++j)
-                        acc[4 + i][j] = mfma16<DT>(a1[i], bf[j], zero_c ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[4 + i][j]);
+                    {
+                        if constexpr ((ABL & 4) != 0) {
+                            asm volatile("" ::"v"(a1[i]), "v"(bf[j]));
+                            if (zero_c) acc[4 + i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        } else {
+                            acc[4 + i][j] = mfma16<DT>(a1[i], bf[j], zero_c ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[4 + i][j]);
+                        }
+                    }
             }
         };
         do_slice(0, std::true_type{});
@@ -1660,6 +1688,30 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
     VOD_KNOB(27, 14)  // corpus operand always L2-hot (timing only)
     VOD_KNOB(28, 15)  // L2 touch-prefetch of the next corpus tile (results stay exact)
 #undef VOD_KNOB
+    if (store_dtype == 0 && tile >= 32 && tile <= 38 && !dense) {  // ablated persistent kernel: tile - 31 = bit mask (1 no LDS-DMA, 2 no ds_read, 4 no MFMA)
+        const int n_xtiles = (int)((row_end - row_begin + 255) / 256);
+        const int n_qtiles = (int)(nq_pad / 256);
+        const int unit = 8 * n_qtiles, total = ((n_xtiles + 7) / 8) * unit;
+        int grid = (256 / unit) * unit;
+        if (grid > total) grid = total;
+        void (*kern)(const uint16_t*, const uint16_t*, int, int, int, int, int, int, const float*, const key_t64*, key_t64*,
+                     unsigned int*, int, unsigned int*, FilterExtra) = nullptr;
+        switch (tile - 31) {
+            case 1: kern = mips_filter16p_kernel<0, false, false, false, 1>; break;
+            case 2: kern = mips_filter16p_kernel<0, false, false, false, 2>; break;
+            case 3: kern = mips_filter16p_kernel<0, false, false, false, 3>; break;
+            case 4: kern = mips_filter16p_kernel<0, false, false, false, 4>; break;
+            case 5: kern = mips_filter16p_kernel<0, false, false, false, 5>; break;
+            case 6: kern = mips_filter16p_kernel<0, false, false, false, 6>; break;
+            default: kern = mips_filter16p_kernel<0, false, false, false, 7>; break;
+        }
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + PSTG_BYTES);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 128 * 1024 + PSTG_BYTES, stream, (const uint16_t*)store, (const uint16_t*)q_pad,
+                           (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s, ws.thr_key, ws.cand,
+                           ws.cnt, (int)ws.cap, ws.overflow, ws.extra);
+        return hipGetLastError();
+    }
     if (store_dtype == 0 && tile == 29 && !dense) {  // stamped persistent kernel
         const int n_xtiles = (int)((row_end - row_begin + 255) / 256);
         const int n_qtiles = (int)(nq_pad / 256);
@@ -1699,7 +1751,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
     if (store_dtype == 0 && tile == 14 && !dense) {
         return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, false, 4>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
     }
-    if (store_dtype == 0 && ((tile >= 11 && tile <= 24) || tile == 29) && dense)
+    if (store_dtype == 0 && ((tile >= 11 && tile <= 24) || tile == 29 || (tile >= 32 && tile <= 38)) && dense)
         return launch_filter_cfg<0, 256, 256, 2, 4, 64, 2, true>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
 #endif
 #undef VOD_FILTER

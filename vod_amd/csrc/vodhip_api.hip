@@ -448,7 +448,7 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
     } else if (!strcmp(key, "profile")) {
         ix->profile = value;
     } else if (!strcmp(key, "tile")) {
-        if (value < 0 || value > 29) return fail("tile must be 0 (auto) or one of 1, 2, 3, 5");
+        if (value < 0 || value > 40) return fail("tile must be 0 (auto) or one of 1, 2, 3, 5");
         ix->tile = value;
     } else {
         return fail("unknown parameter '%s'", key);
