@@ -80,7 +80,11 @@ int vodhip_index_get_rows(const vodhip_index_t* index, int64_t row_begin, int64_
  * vodhip_index_search        enqueue + wait + exactness check (re-runs in the exhaustive-safe
  *                            schedule if a candidate buffer overflowed); results are final on return.
  * vodhip_index_search_async  enqueue only.  Must be followed by vodhip_index_search_finish on the
- *                            same index before the outputs are trusted.
+ *                            same index before the outputs are trusted.  Up to 4 searches may be in flight
+ *                            (same stream; they share the workspace in stream order); finish completes the
+ *                            OLDEST one and waits for it alone, so a caller that runs one search ahead never
+ *                            leaves the device idle while the host checks the exactness flag.  The query and
+ *                            output buffers of a search must stay valid and unmodified until its finish.
  * ------------------------------------------------------------------------------------------- */
 #define VODHIP_MAX_K 2048
 int vodhip_index_search(vodhip_index_t* index, const void* queries, int q_dtype, int64_t nq, int k,

@@ -376,3 +376,40 @@ def test_error_behaviour_is_loud():
         with pytest.raises(NativeLibraryError, match="unknown parameter"):
             ix.set_param("nope", 1)
         _assert_exact(ix, q, x, 5)                                 # the handle is still usable after the errors
+
+
+def test_pipelined_searches_finish_in_order_and_stay_exact():
+    """Up to 4 searches in flight on one index: `finish` completes the oldest; a 5th enqueue is refused; an
+    overflowing search in the middle of the pipeline is re-run in the exhaustive schedule without disturbing the others."""
+    n, d, k = 60000, 64, 20
+    q, x = _int_data(11, n, d, 300)
+    with _index(x) as ix:
+        outs = []
+        for j in range(4):
+            outs.append(ix.search_async(torch.from_numpy(q[j * 70 : j * 70 + 70]).cuda(), k))
+        with pytest.raises(RuntimeError, match="in flight"):
+            ix.search_async(torch.from_numpy(q[:8]).cuda(), k)
+        for j in range(4):
+            ix.finish()
+        from oracle.flat_ip import flat_ip_topk
+
+        for j, (s, i) in enumerate(outs):
+            rs, ri = flat_ip_topk(q[j * 70 : j * 70 + 70].astype(np.float32), x.astype(np.float32), k)
+            np.testing.assert_array_equal(i.cpu().numpy(), ri)
+            np.testing.assert_array_equal(s.cpu().numpy(), rs)
+        with pytest.raises(RuntimeError, match="no search is pending"):
+            ix.finish()
+    # rising scores along the row order overflow the candidate lists of the geometric schedule
+    xr = np.sort(np.random.default_rng(0).integers(-8, 9, size=(n, 1)), axis=0).astype(np.float16) * np.ones((1, d), np.float16)
+    qr = np.ones((40, d), dtype=np.float16)
+    with _index(xr) as ix:
+        ix.set_param("cand_cap", 256)
+        a = ix.search_async(torch.from_numpy(qr[:16]).cuda(), k)
+        b = ix.search_async(torch.from_numpy(qr[16:]).cuda(), k)
+        ix.finish()
+        assert ix.get_stat("last_overflow") == 1
+        ix.finish()
+        assert ix.get_stat("last_overflow") == 1
+        rs, ri = flat_ip_topk(qr.astype(np.float32), xr.astype(np.float32), k)
+        np.testing.assert_array_equal(torch.cat([a[1], b[1]]).cpu().numpy(), ri)
+        np.testing.assert_array_equal(torch.cat([a[0], b[0]]).cpu().numpy(), rs)

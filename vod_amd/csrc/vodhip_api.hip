@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "vodhip_internal.h"
@@ -49,7 +50,13 @@ struct PendingSearch {
     int64_t id_base = 0;
     float* out_scores = nullptr;
     int64_t* out_ids = nullptr;
+    const int* q_label = nullptr;  // subset labels in force when the search was enqueued
+    int n_qlab = 0;
+    int slot = 0;                  // overflow-flag word / completion event of this search
+    size_t ev_begin = 0, ev_end = 0;  // profile events of this search in ev_pool
 };
+
+constexpr int MAX_IN_FLIGHT = 4;  // searches that may be enqueued before the oldest is finished
 
 }  // namespace
 
@@ -65,8 +72,10 @@ struct vodhip_index {
     int n_qlab = 0;
     void* stage_dev = nullptr;  // raw-dtype staging for host ingest
     SearchWorkspace ws;
-    unsigned int* overflow_host = nullptr;  // pinned
-    PendingSearch pending;
+    unsigned int* overflow_host = nullptr;  // pinned, one word per in-flight slot
+    hipEvent_t done[MAX_IN_FLIGHT] = {};    // recorded after a search's overflow word is copied back
+    std::deque<PendingSearch> inflight;     // oldest first
+    int next_slot = 0;
     // tunables
     int64_t cand_cap = 4096;
     int64_t dense_rows = 1024;
@@ -173,8 +182,8 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
     if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
     ix->ws.extra.flags = (int)ix->krot;  // bit 0: K rotation; bit 1 (ablation builds): no survivors
     ix->ws.extra.row_label = (ix->row_label && ix->q_label) ? ix->row_label : nullptr;
-    ix->ws.extra.q_label = ix->q_label;
-    ix->ws.extra.n_qlab = ix->n_qlab;
+    ix->ws.extra.q_label = ps.q_label;
+    ix->ws.extra.n_qlab = ps.n_qlab;
     const SearchWorkspace& ws = ix->ws;
     HIP_OK(hipMemsetAsync(ws.overflow, 0, sizeof(unsigned int), stream));
     for (int64_t qb = 0; qb < ps.nq; qb += MAX_NQ_PER_PASS) {
@@ -184,7 +193,7 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
         HIP_OK(hipMemsetAsync(ws.q_pad, 0, (size_t)nq_pad * ix->dim_pad * 2, stream));
         HIP_OK(launch_convert_rows((const char*)ps.queries + (size_t)qb * ix->dim * q_es, ps.q_dtype, nq, ix->dim,
                                    ws.q_pad, ix->dtype, ix->dim_pad, stream));
-        ix->ws.extra.q_label = ix->q_label ? ix->q_label + (size_t)qb * ix->n_qlab : nullptr;
+        ix->ws.extra.q_label = ps.q_label ? ps.q_label + (size_t)qb * ps.n_qlab : nullptr;
         HIP_OK(launch_search_init(ws, nq_pad, stream));
         for (size_t c = 0; c < chunks.size(); ++c) {
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -212,7 +221,8 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
         }
         HIP_OK(launch_output(ws, nq, k, ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k, stream));
     }
-    HIP_OK(hipMemcpyAsync(ix->overflow_host, ws.overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(ix->overflow_host + ps.slot, ws.overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipEventRecord(ix->done[ps.slot], stream));
     return 0;
 }
 
@@ -243,13 +253,14 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
         return fail("hipMalloc of the %zu-byte vector store failed: %s", bytes, hipGetErrorString(e));
     }
     e = hipMemset(ix->data, 0, bytes);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ix->overflow_host, sizeof(unsigned int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ix->overflow_host, MAX_IN_FLIGHT * sizeof(unsigned int), hipHostMallocDefault);
+    for (int i = 0; i < MAX_IN_FLIGHT && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ix->done[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         (void)hipFree(ix->data);
         delete ix;
         return fail("store initialisation failed: %s", hipGetErrorString(e));
     }
-    *ix->overflow_host = 0;
+    for (int i = 0; i < MAX_IN_FLIGHT; ++i) ix->overflow_host[i] = 0;
     *out = ix;
     return 0;
 }
@@ -259,6 +270,8 @@ int vodhip_index_destroy(vodhip_index_t* ix) {
     (void)hipSetDevice(ix->device);
     free_workspace(ix);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < MAX_IN_FLIGHT; ++i)
+        if (ix->done[i]) (void)hipEventDestroy(ix->done[i]);
     (void)hipFree(ix->data);
     (void)hipFree(ix->stage_dev);
     (void)hipFree(ix->row_label);
@@ -377,6 +390,8 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
     if (nq < 0 || (nq > 0 && (!queries || !out_scores || !out_ids))) return fail("invalid query / output pointers");
     if (q_dtype < 0 || q_dtype > 2) return fail("invalid q_dtype %d", q_dtype);
     if (ix->cand_cap < ROW_ALIGN || ix->cand_cap < k) return fail("cand_cap too small");
+    if ((int)ix->inflight.size() >= MAX_IN_FLIGHT)
+        return fail("%d searches are already in flight on this index: call vodhip_index_search_finish first", MAX_IN_FLIGHT);
     HIP_OK(hipSetDevice(ix->device));
     PendingSearch ps;
     ps.active = true;
@@ -387,39 +402,48 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
     ps.id_base = id_base;
     ps.out_scores = out_scores;
     ps.out_ids = out_ids;
-    ix->pending = ps;
-    ix->last_overflow = 0;
-    ix->last_safe_reruns = 0;
-    ix->ev_used = 0;
-    if (nq == 0) return 0;
-    return enqueue_search(ix, ps, ix->force_safe != 0, (hipStream_t)stream_);
+    ps.q_label = ix->q_label;
+    ps.n_qlab = ix->n_qlab;
+    ps.slot = ix->next_slot;
+    if (ix->inflight.empty()) ix->ev_used = 0;  // profile events are recycled once nothing refers to them
+    ps.ev_begin = ix->ev_used;
+    if (nq > 0 && enqueue_search(ix, ps, ix->force_safe != 0, (hipStream_t)stream_)) return -1;
+    ps.ev_end = ix->ev_used;
+    ix->next_slot = (ix->next_slot + 1) % MAX_IN_FLIGHT;
+    ix->inflight.push_back(ps);
+    return 0;
 }
 
 int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
     if (!ix) return fail("index is NULL");
-    if (!ix->pending.active) return fail("no search is pending on this index");
+    if (ix->inflight.empty()) return fail("no search is pending on this index");
     hipStream_t stream = (hipStream_t)stream_;
     HIP_OK(hipSetDevice(ix->device));
-    if (ix->pending.nq > 0) {
-        HIP_OK(hipStreamSynchronize(stream));
-        if (*ix->overflow_host) {
+    PendingSearch ps = ix->inflight.front();
+    ix->inflight.pop_front();
+    ix->last_overflow = 0;
+    ix->last_safe_reruns = 0;
+    if (ps.nq > 0) {
+        HIP_OK(hipEventSynchronize(ix->done[ps.slot]));  // this search only: younger ones keep the device busy
+        if (ix->overflow_host[ps.slot]) {
             // A candidate list overflowed (scores that keep rising along the row order defeat the
             // geometric schedule).  Redo the batch with the exhaustive schedule, which cannot overflow.
             ix->last_overflow = 1;
             ix->last_safe_reruns = 1;
-            if (enqueue_search(ix, ix->pending, true, stream)) return -1;
+            const size_t ev_keep = ix->ev_used;
+            if (enqueue_search(ix, ps, true, stream)) return -1;
+            ix->ev_used = ev_keep;  // the re-run is not part of the launch accounting
             HIP_OK(hipStreamSynchronize(stream));
-            if (*ix->overflow_host) return fail("internal error: exhaustive schedule overflowed");
+            if (ix->overflow_host[ps.slot]) return fail("internal error: exhaustive schedule overflowed");
         }
     }
-    ix->last_filter_launches = (int64_t)(ix->ev_used / 2);
+    ix->last_filter_launches = (int64_t)((ps.ev_end - ps.ev_begin) / 2);
     ix->last_filter_ns = 0;
-    for (size_t e = 0; e + 1 < ix->ev_used; e += 2) {
+    for (size_t e = ps.ev_begin; e + 1 < ps.ev_end; e += 2) {
         float ms = 0.f;
         HIP_OK(hipEventElapsedTime(&ms, ix->ev_pool[e], ix->ev_pool[e + 1]));
         ix->last_filter_ns += (int64_t)((double)ms * 1e6);
     }
-    ix->pending.active = false;
     return 0;
 }
 

@@ -8,6 +8,7 @@ libvodhip.so.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 
 import numpy as np
@@ -36,6 +37,8 @@ class HipFlatIndex:
             )
         )
         self._h = handle
+        self._keep: collections.deque = collections.deque()
+        self._keep_subset = None
 
     # -- lifecycle ---------------------------------------------------------------------------------
     def close(self) -> None:
@@ -194,7 +197,7 @@ class HipFlatIndex:
             ids = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         else:
             scores, ids = out
-        self._keep = q  # keep the query buffer alive until finish()
+        self._keep.append((q, self._keep_subset, scores, ids))  # buffers of this search stay alive until its finish()
         _native.check(
             self._lib.vodhip_index_search_async(
                 self._h, q.data_ptr(), _native.torch_dtype_code(q.dtype), nq, int(k), int(id_base),
@@ -204,8 +207,12 @@ class HipFlatIndex:
         return scores, ids
 
     def finish(self) -> None:
+        """Complete the OLDEST enqueued search (up to 4 may be in flight): waits for it alone, re-runs it in the
+        exhaustive schedule if a candidate list overflowed.  Pipelined searches need their own `out` buffers if their
+        results are read after younger searches were enqueued."""
         _native.check(self._lib.vodhip_index_search_finish(self._h, _native.current_stream_ptr(self.device)))
-        self._keep = None
+        if self._keep:
+            self._keep.popleft()
 
     def search(self, queries, k: int, id_base: int = 0, out=None, subset=None) -> tuple[torch.Tensor, torch.Tensor]:
         """Exact top-k by inner product: (scores f32 [nq,k] desc, ids i64 [nq,k]); ties -> smaller id; pad -inf/-1."""
