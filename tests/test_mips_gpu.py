@@ -413,3 +413,25 @@ def test_pipelined_searches_finish_in_order_and_stay_exact():
         rs, ri = flat_ip_topk(qr.astype(np.float32), xr.astype(np.float32), k)
         np.testing.assert_array_equal(torch.cat([a[1], b[1]]).cpu().numpy(), ri)
         np.testing.assert_array_equal(torch.cat([a[0], b[0]]).cpu().numpy(), rs)
+
+
+def test_random_shapes_stay_exact():
+    """Seeded sweep over shapes the fixed cases do not name: every (n, d, nq, k) goes through the default kernel
+    selection and chunk schedule and must reproduce the oracle bit for bit (integer data, tie-heavy)."""
+    rng = np.random.default_rng(2026)
+    for trial in range(24):
+        n = int(rng.choice([1, 17, 300, 1023, 1025, 5000, 33000, 90001, 250000]))
+        d = int(rng.choice([8, 64, 72, 128, 200, 384, 768]))
+        nq = int(rng.choice([1, 2, 31, 64, 129, 256, 257, 513, 1024, 1500]))
+        k = int(rng.choice([1, 3, 10, 64, 100, 128, 130, 500]))
+        if n * d > 40_000_000:
+            n = 40_000_000 // d
+        dtype = torch.float16 if trial % 3 else torch.bfloat16
+        x = rng.integers(-8, 9, size=(n, d)).astype(np.float32)
+        q = rng.integers(-8, 9, size=(nq, d)).astype(np.float32)
+        with _index(x[:0].astype(np.float16), dtype=dtype, capacity=n) as ix:
+            ix.add(x)
+            s, i = ix.search(torch.from_numpy(q).cuda(), k)
+            rs, ri = _oracle(q, x, k)
+            np.testing.assert_array_equal(i.cpu().numpy(), ri, err_msg=f"trial {trial}: n={n} d={d} nq={nq} k={k} {dtype}")
+            np.testing.assert_array_equal(s.cpu().numpy(), rs, err_msg=f"trial {trial}: n={n} d={d} nq={nq} k={k} {dtype}")
