@@ -53,7 +53,7 @@ def _assert_exact(ix, q, x, k, **kw):
 MANIFEST = json.loads((GOLDEN / "manifest.json").read_text())
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 42, 46])
 @pytest.mark.parametrize("name", ["flat_ip_exact_small", "flat_ip_exact_768"])
 def test_golden_exact_fixtures(name, tile):
     p = MANIFEST[name]["params"]
@@ -66,7 +66,7 @@ def test_golden_exact_fixtures(name, tile):
         assert ix.get_stat("last_overflow") == 0
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 42, 46])
 @pytest.mark.parametrize(
     "n,d,nq,k",
     [
@@ -210,7 +210,7 @@ def _check_gaussian(q, x, s, i, k):
 
 
 @pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 42, 46])
 def test_gaussian_matches_fp64_oracle(dtype, tile):
     rng = np.random.default_rng(31)
     n, d, nq, k = 50000, 768, 64, 100
@@ -419,7 +419,7 @@ def test_random_shapes_stay_exact():
     """Seeded sweep over shapes the fixed cases do not name: every (n, d, nq, k) goes through the default kernel
     selection and chunk schedule and must reproduce the oracle bit for bit (integer data, tie-heavy)."""
     rng = np.random.default_rng(2026)
-    for trial in range(24):
+    for trial in range(16):
         n = int(rng.choice([1, 17, 300, 1023, 1025, 5000, 33000, 90001, 250000]))
         d = int(rng.choice([8, 64, 72, 128, 200, 384, 768]))
         nq = int(rng.choice([1, 2, 31, 64, 129, 256, 257, 513, 1024, 1500]))

@@ -179,6 +179,10 @@ __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else static_assert(N == 0, "add the literal");
@@ -1530,7 +1534,7 @@ extern "C" int vodhip_debug_read_stamps(unsigned long long* host_out, long long 
 #endif
 
 int filter_tile_rows(int tile) { return (tile == 1 || tile == 5) ? 128 : 256; }  // ablation ids 11..13 are 256
-int filter_tile_cols(int tile) { return (tile == 1 || tile == 5) ? 128 : 256; }
+int filter_tile_cols(int tile) { return tile == 42 ? 64 : tile == 46 ? 128 : (tile == 1 || tile == 5) ? 128 : 256; }
 
 template <int DT, int BM, int BN, int WM, int WN, int BK, int NSTAGE, bool DENSE, int ABLATE = 0, bool PINGPONG = false, bool SUBSET = false>
 static hipError_t launch_filter_cfg(const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin,
@@ -1584,6 +1588,8 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
     VOD_FILTER_DT(2, 256, 256, 2, 4, 64, 2)   // 128 KB LDS, drain-to-zero double buffer
     VOD_FILTER_DT(3, 256, 256, 2, 4, 32, 4)   // 128 KB LDS, 4-slot ring, 2 slices in flight across the barrier
     VOD_FILTER_DT(5, 128, 128, 2, 2, 32, 4)   // 64 KB LDS ring, 2 workgroups / CU
+    VOD_FILTER_DT(42, 256, 64, 4, 1, 64, 3)   // nq <= 64 (HBM-bound): 256 corpus rows x 64 queries, 4 waves, 3-slot ring (120 KB): a fifth of the LDS-DMA bytes are queries (half with the 128x128 tile)
+    VOD_FILTER_DT(46, 256, 128, 4, 2, 64, 3)  // 65..128 queries: 256 x 128, 8 waves, 3-slot ring (144 KB)
 #undef VOD_FILTER_DT
     if ((tile == 9 || tile == 10) && !dense) {  // persistent 256x256 / 16x16x32 (10: 3 corpus + 2 query LDS slots): one workgroup per CU streams its list of corpus tiles
         const int n_xtiles = (int)((row_end - row_begin + 255) / 256);

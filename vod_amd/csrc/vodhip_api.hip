@@ -175,9 +175,14 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
     const int q_es = elem_size(ps.q_dtype);
     int tile = (int)ix->tile;
     const bool tile_auto = tile == 0;
-    // auto: 128x128 tile (2 workgroups / CU) up to 128 queries; persistent 256x256 tile on v_mfma_f32_16x16x32 above,
-    // with the corpus operand fetched two slices ahead (3 + 2 LDS slots) when ONE q-tile makes every corpus read an HBM miss
-    if (tile == 0) tile = ps.nq > 256 ? 9 : (ps.nq > 128 ? 10 : 1);
+    // auto: up to 128 queries the search is HBM-bound: 256 corpus rows x 64 / 128 queries per workgroup on a 3-slot LDS
+    // ring (few query bytes per corpus byte through the LDS-DMA path); above, the persistent 256x256 tile on
+    // v_mfma_f32_16x16x32, with the corpus operand fetched two slices ahead (3 + 2 LDS slots) when ONE q-tile makes
+    // every corpus read an HBM miss
+    if (tile == 0) {
+        tile = ps.nq > 256 ? 9 : (ps.nq > 128 ? 10 : (ps.nq > 64 ? 46 : 42));
+        if (ix->row_label && ps.q_label && ps.nq <= 128) tile = 1;  // the subset filter is instantiated for 1 / 8 / 9 / 10
+    }
     const int64_t bn = filter_tile_cols(tile);
     if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
     ix->ws.extra.flags = (int)ix->krot;  // bit 0: K rotation; bit 1 (ablation builds): no survivors
@@ -210,7 +215,7 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
             // short warm-up chunks do not fill 256 CUs with 256x256 tiles (a few tiles per workgroup at most, and their
             // epilogues are heavy with survivors): run those launches on 128x128 tiles, 2 workgroups per CU
             int tile_c = tile;
-            if (tile_auto && tile != 1) {
+            if (tile_auto && (tile == 9 || tile == 10)) {  // (nq_pad is a multiple of 256 there, which the 128-wide tile divides)
                 const int64_t tiles256 = ((chunks[c].second - chunks[c].first + 255) / 256) * (nq_pad / 256);
                 if (tiles256 < ix->small_chunk_tiles) tile_c = 1;
             }
@@ -472,7 +477,7 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
     } else if (!strcmp(key, "profile")) {
         ix->profile = value;
     } else if (!strcmp(key, "tile")) {
-        if (value < 0 || value > 40) return fail("tile must be 0 (auto) or one of 1, 2, 3, 5");
+        if (value < 0 || value > 46) return fail("tile must be 0 (auto) or a filter-kernel variant id (DESIGN.md 4.1)");
         ix->tile = value;
     } else {
         return fail("unknown parameter '%s'", key);
