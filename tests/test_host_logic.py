@@ -104,6 +104,48 @@ def test_codec_is_string_identical_to_the_reference():
         assert back.dtype == g[key].dtype
 
 
+@pytest.mark.parametrize("native", [True, False])
+def test_codec_fast_paths_keep_the_reference_bytes(native, monkeypatch):
+    """The hand-written .npy header + base64 loops (libvodhip's host helper, or binascii without the library) must
+    emit exactly `urlsafe_b64encode(np.save(...))` (src/vod_search/io.py:17-22) for every layout and length mod 3."""
+    import base64
+    import io
+
+    if not native:
+        monkeypatch.setattr(vio, "_lib_state", [None])
+    else:
+        monkeypatch.setattr(vio, "_lib_state", [])
+        assert vio._codec_lib() is not None
+
+    def ref(a):
+        buf = io.BytesIO()
+        np.save(buf, np.asarray(a), allow_pickle=True)
+        return base64.urlsafe_b64encode(buf.getvalue()).decode("utf-8")
+
+    rng = np.random.default_rng(0)
+    cases = [rng.standard_normal((33, 70)).astype(np.float32), np.arange(12, dtype=np.int64).reshape(3, 4),
+             np.zeros((0, 5), np.float32), np.float32(3.0), np.asfortranarray(rng.standard_normal((4, 5))),
+             np.arange(24).reshape(2, 3, 4)[:, ::2], np.array([-np.inf, np.nan, 1.0], dtype=np.float32)]
+    cases += [rng.integers(0, 255, size=(n,), dtype=np.uint8) for n in range(0, 13)]
+    for a in cases:
+        enc = vio.serialize_np_array(a)
+        assert enc == ref(a)
+        back = vio.deserialize_np_array(enc)
+        assert back.dtype == np.asarray(a).dtype and back.shape == np.asarray(a).shape and back.flags.writeable
+        np.testing.assert_array_equal(back, a)
+        np.testing.assert_array_equal(vio.deserialize_np_array(enc.replace("-", "+").replace("_", "/")), a)  # std alphabet
+    big = vio.serialize_np_array(cases[0])
+    np.testing.assert_array_equal(vio.deserialize_np_array(big[:100] + "\n" + big[100:]), cases[0])  # lenient, like b64decode
+    # the JSON helpers produce / accept ordinary JSON
+    body = vio.json_body({"vectors": big}, {"top_k": 7, "subset_ids": [["a"], []]})
+    assert json.loads(body) == {"vectors": big, "top_k": 7, "subset_ids": [["a"], []]}
+    assert vio.parse_json_body(body, ("vectors",)) == json.loads(body)
+    assert vio.parse_json_body(json.dumps({"top_k": 1, "vectors": big}).encode(), ("vectors",)) == {"top_k": 1, "vectors": big}
+    assert vio.parse_json_body(b'{"top_k": 2}', ("vectors",)) == {"top_k": 2}
+    with pytest.raises(ValueError):
+        vio.parse_json_body(b'[1, 2]', ("vectors",))
+
+
 def test_codec_refuses_pickled_payloads():
     import base64
     import io

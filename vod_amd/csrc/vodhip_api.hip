@@ -600,4 +600,72 @@ int vodhip_priority_sample(const float* scores, const uint8_t* labels, const flo
     return 0;
 }
 
+// ---- wire codec helper (host only) ----
+static const char kB64Url[65] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789-_";
+
+int64_t vodhip_b64url_encode(const uint8_t* head, int64_t n_head, const uint8_t* data, int64_t n_data, char* out) {
+    if (n_head < 0 || n_data < 0 || !out || (n_head && !head) || (n_data && !data)) return -1;
+    const int64_t n = n_head + n_data;
+    auto at = [&](int64_t i) -> uint32_t { return i < n_head ? head[i] : data[i - n_head]; };
+    char* o = out;
+    int64_t i = 0;
+    // the head and the triple that straddles the head / data seam go through the generic accessor
+    const int64_t seam_end = n_head == 0 ? 0 : ((n_head + 2) / 3) * 3;
+    for (; i + 2 < n && i < seam_end; i += 3) {
+        const uint32_t v = (at(i) << 16) | (at(i + 1) << 8) | at(i + 2);
+        *o++ = kB64Url[v >> 18]; *o++ = kB64Url[(v >> 12) & 63]; *o++ = kB64Url[(v >> 6) & 63]; *o++ = kB64Url[v & 63];
+    }
+    if (i + 2 < n) {
+        const uint8_t* p = data + (i - n_head);  // i >= n_head here
+        for (; i + 2 < n; i += 3, p += 3) {
+            const uint32_t v = ((uint32_t)p[0] << 16) | ((uint32_t)p[1] << 8) | p[2];
+            o[0] = kB64Url[v >> 18]; o[1] = kB64Url[(v >> 12) & 63]; o[2] = kB64Url[(v >> 6) & 63]; o[3] = kB64Url[v & 63];
+            o += 4;
+        }
+    }
+    if (i < n) {
+        const uint32_t b0 = at(i), b1 = i + 1 < n ? at(i + 1) : 0;
+        *o++ = kB64Url[b0 >> 2];
+        *o++ = kB64Url[((b0 & 3) << 4) | (b1 >> 4)];
+        *o++ = i + 1 < n ? kB64Url[(b1 & 15) << 2] : '=';
+        *o++ = '=';
+    }
+    return (int64_t)(o - out);
+}
+
+int64_t vodhip_b64url_decode(const char* src, int64_t n, uint8_t* out) {
+    if (n < 0 || (n && (!src || !out))) return -1;
+    static int8_t table[256];
+    static bool ready = false;
+    if (!ready) {  // benign race: every thread writes the same values
+        for (int c = 0; c < 256; ++c) table[c] = -1;
+        for (int c = 0; c < 64; ++c) table[(unsigned char)kB64Url[c]] = (int8_t)c;
+        table[(unsigned char)'+'] = 62;
+        table[(unsigned char)'/'] = 63;
+        ready = true;
+    }
+    while (n > 0 && src[n - 1] == '=') --n;
+    uint8_t* o = out;
+    int64_t i = 0;
+    for (; i + 3 < n; i += 4) {
+        const int a = table[(unsigned char)src[i]], b = table[(unsigned char)src[i + 1]];
+        const int c = table[(unsigned char)src[i + 2]], d = table[(unsigned char)src[i + 3]];
+        if ((a | b | c | d) < 0) return -1;
+        const uint32_t v = ((uint32_t)a << 18) | ((uint32_t)b << 12) | ((uint32_t)c << 6) | (uint32_t)d;
+        o[0] = (uint8_t)(v >> 16); o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)v;
+        o += 3;
+    }
+    const int64_t rem = n - i;
+    if (rem == 1) return -1;
+    if (rem >= 2) {
+        const int a = table[(unsigned char)src[i]], b = table[(unsigned char)src[i + 1]];
+        const int c = rem == 3 ? table[(unsigned char)src[i + 2]] : 0;
+        if ((a | b | c) < 0) return -1;
+        *o++ = (uint8_t)((a << 2) | (b >> 4));
+        if (rem == 3) *o++ = (uint8_t)(((b & 15) << 4) | (c >> 2));
+    }
+    return (int64_t)(o - out);
+}
+
 }  // extern "C"
+

@@ -3,24 +3,125 @@
 String-compatible with the reference (/root/reference/src/vod_search/io.py:17-32): the payload is exactly
 `base64.urlsafe_b64encode(np.save(...))`.  Decoding refuses pickled object arrays (the reference passes
 `allow_pickle=True`; nothing on this path needs it and it would execute untrusted bytes).
+
+Same bytes, fewer passes: for a 1024 x 768 float32 batch (3 MB) `np.save` into a BytesIO, `getvalue()`,
+`urlsafe_b64encode` (encode + translate) and `np.load` of a second BytesIO cost 8-9 ms per direction; the
+`.npy` header is written/parsed here and the array bytes go through `binascii` once (~3 ms per direction).
+`json_body` / `parse_json_body` let client and server skip `json.dumps` / `json.loads` over the 4 MB string
+(the payload alphabet needs no escaping) while staying valid JSON for any other peer.
 """
 from __future__ import annotations
 
 import base64
+import binascii
+import ctypes
 import io
+import json
 
 import numpy as np
 
+_TO_URLSAFE = bytes.maketrans(b"+/", b"-_")
+_FROM_URLSAFE = bytes.maketrans(b"-_", b"+/")
+_lib_state: list = []  # [lib or None] once probed
+
+
+def _codec_lib():
+    """libvodhip's host-side base64 loops (3 MB in ~1.5 ms instead of ~7); `binascii` when the library cannot be
+    loaded in this process (a client box without ROCm).  This is the codec only - no search runs without the library."""
+    if not _lib_state:
+        try:
+            from vod_amd import _native
+
+            _lib_state.append(_native.load_library())
+        except Exception:
+            _lib_state.append(None)
+    return _lib_state[0]
+
+
+def _b64url_encode(head: bytes, arr: np.ndarray | None) -> str:
+    lib = _codec_lib()
+    n_data = 0 if arr is None else arr.nbytes
+    if lib is None:
+        raw = head if arr is None else head + arr.tobytes()
+        return binascii.b2a_base64(raw, newline=False).translate(_TO_URLSAFE).decode("ascii")
+    out = bytearray(4 * ((len(head) + n_data + 2) // 3))
+    dst = (ctypes.c_char * len(out)).from_buffer(out)
+    n = lib.vodhip_b64url_encode(head, len(head), arr.ctypes.data if n_data else None, n_data, ctypes.addressof(dst))
+    if n != len(out):
+        raise RuntimeError("base64 encoder returned an unexpected length")
+    del dst
+    return out.decode("ascii")
+
+
+def _b64url_decode(data: bytes) -> np.ndarray:
+    """Decoded bytes as a (writable, owned) uint8 array."""
+    lib = _codec_lib()
+    if lib is not None:
+        out = np.empty(3 * len(data) // 4 + 3, dtype=np.uint8)
+        n = lib.vodhip_b64url_decode(data, len(data), out.ctypes.data)
+        if n >= 0:
+            return out[:n]
+    return np.frombuffer(bytearray(binascii.a2b_base64(data.translate(_FROM_URLSAFE))), dtype=np.uint8)
+
 
 def serialize_np_array(array: np.ndarray) -> str:
-    buf = io.BytesIO()
-    np.save(buf, np.asarray(array), allow_pickle=False)
-    return base64.urlsafe_b64encode(buf.getvalue()).decode("utf-8")
+    arr = np.asarray(array)
+    if arr.dtype.hasobject or not arr.flags.c_contiguous or arr.ndim == 0:
+        buf = io.BytesIO()  # uncommon layouts: let NumPy decide (Fortran order flag, 0-d arrays, refusal of objects)
+        np.save(buf, arr, allow_pickle=False)
+        return _b64url_encode(buf.getvalue(), None)
+    head = io.BytesIO()
+    np.lib.format.write_array_header_1_0(head, np.lib.format.header_data_from_array_1_0(arr))
+    return _b64url_encode(head.getvalue(), arr)
 
 
-def deserialize_np_array(encoded: str, *, dtype=None) -> np.ndarray:
-    raw = base64.urlsafe_b64decode(encoded)
-    arr = np.load(io.BytesIO(raw), allow_pickle=False)
+def deserialize_np_array(encoded: str | bytes, *, dtype=None, writable: bool = True) -> np.ndarray:  # noqa: ARG001
+    """Inverse of `serialize_np_array` (`writable` is kept for callers; the result always owns writable memory)."""
+    data = encoded.encode("ascii") if isinstance(encoded, str) else bytes(encoded)
+    raw = _b64url_decode(data)
+    arr = None
+    if raw[:8].tobytes() == b"\x93NUMPY\x01\x00":
+        head = io.BytesIO(raw[:65546].tobytes())
+        head.seek(8)
+        shape, fortran, dt = np.lib.format.read_array_header_1_0(head)
+        if not dt.hasobject and not fortran:
+            count = int(np.prod(shape, dtype=np.int64))
+            off = head.tell()
+            if off + count * dt.itemsize > raw.size:
+                raise ValueError("truncated .npy payload")
+            arr = raw[off : off + count * dt.itemsize].view(dt).reshape(shape) if off % dt.itemsize == 0 or dt.itemsize == 1 \
+                else np.frombuffer(raw[off : off + count * dt.itemsize].tobytes(), dtype=dt).reshape(shape).copy()
+    if arr is None:
+        arr = np.load(io.BytesIO(raw.tobytes()), allow_pickle=False)
     if dtype is not None:
         arr = arr.astype(dtype)
     return arr
+
+
+def json_body(fields: dict[str, str], extra: dict | None = None) -> bytes:
+    """`{"k": "<payload>", ..., **extra}` as JSON bytes without running the payload strings through an encoder."""
+    parts = [json.dumps(k) + ': "' + v + '"' for k, v in fields.items()]
+    parts += [json.dumps(k) + ": " + json.dumps(v) for k, v in (extra or {}).items()]
+    return ("{" + ", ".join(parts) + "}").encode("ascii")
+
+
+def parse_json_body(body: bytes, payload_keys: tuple[str, ...]) -> dict:
+    """`json.loads` for bodies whose big fields are escape-free strings: those are sliced out, the rest is parsed."""
+    out: dict = {}
+    rest = body
+    for key in payload_keys:
+        tag = b'"' + key.encode("ascii") + b'"'
+        i = rest.find(tag)
+        if i < 0:
+            continue
+        j = rest.find(b'"', rest.find(b":", i + len(tag)) + 1)
+        k = rest.find(b'"', j + 1)
+        if j < 0 or k < 0 or b"\\" in rest[j + 1 : k]:
+            return json.loads(body)
+        out[key] = rest[j + 1 : k].decode("ascii")
+        rest = rest[:j] + b'""' + rest[k + 1 :]
+    small = json.loads(rest)
+    if not isinstance(small, dict):
+        raise ValueError("expected a JSON object")
+    small.update(out)
+    return small

@@ -72,10 +72,12 @@ class HipMipsClient(base.SearchClient):
         start = time.time()
         if self.binary and not (self.forward_subset_ids and subset_ids is not None):
             return self._search_binary(np.asarray(vector), top_k, timeout, start)
-        payload = {"vectors": io.serialize_np_array(np.asarray(vector)), "top_k": top_k}
+        extra: dict = {"top_k": top_k}
         if self.forward_subset_ids and subset_ids is not None:
-            payload["subset_ids"] = [list(map(str, s)) for s in subset_ids]
-        response = requests.post(f"{self.url}/fast-search", json=payload, timeout=timeout)
+            extra["subset_ids"] = [list(map(str, s)) for s in subset_ids]
+        # the same JSON document `requests.post(json=...)` would send, assembled without encoding the 4 MB field
+        body = io.json_body({"vectors": io.serialize_np_array(np.asarray(vector))}, extra)
+        response = requests.post(f"{self.url}/fast-search", data=body, headers={"content-type": "application/json"}, timeout=timeout)
         try:
             response.raise_for_status()
         except requests.exceptions.HTTPError:
@@ -84,7 +86,7 @@ class HipMipsClient(base.SearchClient):
             except Exception:
                 print(response.text, file=sys.stderr)
             raise
-        data = response.json()
+        data = io.parse_json_body(response.content, ("scores", "indices"))
         return vt.RetrievalBatch.cast(
             indices=io.deserialize_np_array(data["indices"]),
             scores=io.deserialize_np_array(data["scores"]),

@@ -22,6 +22,7 @@ import traceback
 import numpy as np
 import pydantic
 from fastapi import FastAPI, HTTPException, Request, Response
+from fastapi.concurrency import run_in_threadpool
 
 from vod_amd import io
 
@@ -153,11 +154,21 @@ def create_app(engine, micro_batch_wait_ms: float = 0.0) -> FastAPI:
         except Exception as exc:
             raise HTTPException(status_code=500, detail=traceback.format_exc()) from exc
 
-    @app.post("/fast-search")
-    def fast_search(query: FastSearchQuery) -> FastSearchResponse:
+    @app.post("/fast-search", response_model=FastSearchResponse)
+    async def fast_search(request: Request) -> Response:
+        """Same contract as the reference's route (JSON in, JSON out, `FastSearchQuery` / `FastSearchResponse`
+        validation incl. `extra="forbid"` -> 422), but the multi-megabyte base64 fields are sliced out of / pasted
+        into the JSON text instead of going through a JSON parser, pydantic and `jsonable_encoder`."""
         try:
-            scores, indices = _search(io.deserialize_np_array(query.vectors), query.top_k, query.subset_ids)
-            return FastSearchResponse(scores=io.serialize_np_array(scores), indices=io.serialize_np_array(indices))
+            query = FastSearchQuery(**io.parse_json_body(await request.body(), ("vectors",)))
+        except pydantic.ValidationError as exc:
+            raise HTTPException(status_code=422, detail=exc.errors(include_url=False, include_input=False)) from exc
+        except Exception as exc:
+            raise HTTPException(status_code=422, detail=f"invalid request body: {exc}") from exc
+        try:
+            scores, indices = await run_in_threadpool(_search, io.deserialize_np_array(query.vectors), query.top_k, query.subset_ids)
+            body = io.json_body({"scores": io.serialize_np_array(scores), "indices": io.serialize_np_array(indices)})
+            return Response(content=body, media_type="application/json")
         except Exception as exc:
             raise HTTPException(status_code=500, detail=traceback.format_exc()) from exc
 
