@@ -186,6 +186,20 @@ int vodhip_priority_sample(const float* scores, const uint8_t* labels, const flo
                            void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Gather by id: flattening of the sampled sections of a batch into ONE in-batch section set.
+ * Replaces: gather_values_by_indices / gather_values_2d / _nopy_gather_values_{1d,2d}
+ *           (src/vod_dataloaders/core/numpy_ops.py:24-143) as called by flatten_samples
+ *           (src/vod_dataloaders/core/in_batch_negatives.py:10-52) for the scores, labels, log-weights and every
+ *           raw engine score.
+ * DEVICE pointers.  queries int64 [n_queries] (one id list shared by all rows: the sorted unique ids of the batch,
+ * padded as the reference pads it); keys int64 [n_rows, n_keys] (n_keys <= 4096); `values` / `outs` are HOST arrays
+ * of n_values (<= 8) DEVICE pointers to float32 [n_rows, n_keys] / [n_rows, n_queries]; fill[v] is written where
+ * the id does not occur in the row (NaN for scores, 0 for labels in the reference).  First occurrence wins.
+ * ------------------------------------------------------------------------------------------- */
+int vodhip_gather_by_id(const int64_t* queries, int64_t n_queries, const int64_t* keys, int64_t n_rows, int n_keys,
+                        int n_values, const float* const* values, const float* fill, float* const* outs, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Wire codec helper (HOST memory, no device work): urlsafe base64 of `head || data` and back.
  * Replaces the inner loops of: serialize_np_array / deserialize_np_array (src/vod_search/io.py:17-32:
  *   base64.urlsafe_b64encode(np.save(...)) / np.load(base64.urlsafe_b64decode(...))), which cost ~9 ms per

@@ -101,3 +101,53 @@ def test_sample_search_results_wrapper_contract():
         for grp in (pos, ~pos):                                            # self-normalised weights per label
             if grp.any():
                 np.testing.assert_allclose(np.exp(out.log_weights[r][grp]).sum(), 1.0, rtol=1e-4)
+
+
+def test_flatten_samples_matches_reference_golden():
+    """`flatten_samples` (in_batch_negatives.py:10-52) through `vodhip_gather_by_id`, against the vectors produced by
+    the reference's own function (tests/golden/make_golden.py) - bit for bit, NaN positions included."""
+    from vod_amd import types as vt
+    from vod_amd.core.in_batch_negatives import flatten_samples
+    from vod_amd.core.sample import PrioritySampledSections
+
+    g = np.load(GOLDEN / "flatten_inbatch.npz")
+    ps = PrioritySampledSections(
+        batch=vt.RetrievalBatch(indices=g["idx"], scores=g["scr"], labels=g["lbl"]),
+        log_weights=g["logw"], max_sampling_id=np.zeros(4), lse_pos=np.zeros(4), lse_neg=np.zeros(4),
+        raw_scores={"dense": g["raw_dense"], "sparse": g["raw_sparse"]},
+    )
+    out = flatten_samples(ps, padding=True)
+    np.testing.assert_array_equal(out.batch.indices, g["out_idx"])
+    np.testing.assert_array_equal(out.batch.scores, g["out_scr"])
+    np.testing.assert_array_equal(out.batch.labels, g["out_lbl"])
+    assert out.batch.labels.dtype == np.bool_
+    np.testing.assert_array_equal(out.log_weights, g["out_logw"])
+    np.testing.assert_array_equal(out.raw_scores["dense"], g["out_raw_dense"])
+    np.testing.assert_array_equal(out.raw_scores["sparse"], g["out_raw_sparse"])
+
+
+@pytest.mark.parametrize("b,n,pool", [(64, 32, 3000), (7, 130, 200), (1, 1, 5), (16, 512, 100000)])
+def test_flatten_samples_matches_oracle_random(b, n, pool):
+    from oracle import sampling as osmp
+    from vod_amd import types as vt
+    from vod_amd.core.in_batch_negatives import flatten_samples
+    from vod_amd.core.sample import PrioritySampledSections
+
+    rng = np.random.default_rng(b * 1000 + n)
+    idx = rng.integers(-1, pool, size=(b, n)).astype(np.int64)  # duplicates inside a row and -1 pads occur
+    scr = rng.standard_normal((b, n)).astype(np.float32)
+    scr[idx < 0] = -np.inf
+    lbl = rng.random((b, n)) < 0.2
+    logw = rng.standard_normal((b, n)).astype(np.float32)
+    raw = {"dense": rng.standard_normal((b, n)).astype(np.float32), "sparse": np.where(rng.random((b, n)) < 0.3, np.nan, 1.0).astype(np.float32)}
+    ps = PrioritySampledSections(batch=vt.RetrievalBatch(indices=idx, scores=scr, labels=lbl), log_weights=logw,
+                                 max_sampling_id=np.zeros(b), lse_pos=np.zeros(b), lse_neg=np.zeros(b), raw_scores=raw)
+    for padding in (True, False):
+        out = flatten_samples(ps, padding=padding)
+        ref = osmp.flatten_samples(idx, scr, lbl, logw, raw, padding=padding)
+        np.testing.assert_array_equal(out.batch.indices, ref["indices"])
+        np.testing.assert_array_equal(out.batch.scores, ref["scores"])
+        np.testing.assert_array_equal(out.batch.labels, ref["labels"])
+        np.testing.assert_array_equal(out.log_weights, ref["log_weights"])
+        for key in raw:
+            np.testing.assert_array_equal(out.raw_scores[key], ref["raw"][key])

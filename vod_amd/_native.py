@@ -69,6 +69,7 @@ SIGNATURES: dict[str, tuple] = {
         _i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _c.c_float, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     ),
     "vodhip_retrieval_backward": (_i32, [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "vodhip_gather_by_id": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vodhip_b64url_encode": (_i64, [_vp, _i64, _vp, _i64, _vp]),
     "vodhip_b64url_decode": (_i64, [_vp, _i64, _vp]),
 }

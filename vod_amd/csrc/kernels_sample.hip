@@ -220,4 +220,53 @@ hipError_t launch_priority_sample(const float* scores, const uint8_t* labels, co
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// gather by id: the flattening of the sampled sections into one in-batch section set
+// ------------------------------------------------------------------------------------------------
+// Replaces gather_values_by_indices / _nopy_gather_values_{1d,2d} (numpy_ops.py:24-143) as used by flatten_samples
+// (in_batch_negatives.py:10-52): for every row b and every query id u of a list shared by all rows, the value at
+// the FIRST position j with keys[b, j] == u, or the fill value.  One workgroup per row; the row's keys and up to 8
+// value arrays are read from LDS; integer compares, a few KB per row - latency-bound, no MFMA.
+struct GatherArgs {
+    const float* values[8];
+    float* outs[8];
+    float fill[8];
+};
+
+__global__ __launch_bounds__(256) void gather_by_id_kernel(const int64_t* __restrict__ queries, int n_queries,
+                                                           const int64_t* __restrict__ keys, int n_keys, int n_values,
+                                                           GatherArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char g_smem[];
+    int64_t* k_lds = (int64_t*)g_smem;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < n_keys; j += 256) k_lds[j] = keys[(size_t)row * n_keys + j];
+    __syncthreads();
+    for (int u = tid; u < n_queries; u += 256) {
+        const int64_t want = queries[u];
+        int pos = -1;
+        for (int j = 0; j < n_keys; ++j) {
+            if (k_lds[j] == want) {
+                pos = j;
+                break;
+            }
+        }
+        for (int v = 0; v < n_values; ++v)
+            args.outs[v][(size_t)row * n_queries + u] = pos >= 0 ? args.values[v][(size_t)row * n_keys + pos] : args.fill[v];
+    }
+}
+
+hipError_t launch_gather_by_id(const int64_t* queries, int64_t n_queries, const int64_t* keys, int64_t n_rows, int n_keys,
+                               int n_values, const float* const* values, const float* fill, float* const* outs,
+                               hipStream_t stream) {
+    GatherArgs args{};
+    for (int v = 0; v < n_values; ++v) {
+        args.values[v] = values[v];
+        args.outs[v] = outs[v];
+        args.fill[v] = fill[v];
+    }
+    hipLaunchKernelGGL(gather_by_id_kernel, dim3((unsigned)n_rows), dim3(256), (size_t)n_keys * 8, stream, queries,
+                       (int)n_queries, keys, n_keys, n_values, args);
+    return hipGetLastError();
+}
+
 }  // namespace vodhip

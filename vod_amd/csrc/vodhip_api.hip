@@ -600,6 +600,19 @@ int vodhip_priority_sample(const float* scores, const uint8_t* labels, const flo
     return 0;
 }
 
+int vodhip_gather_by_id(const int64_t* queries, int64_t n_queries, const int64_t* keys, int64_t n_rows, int n_keys,
+                        int n_values, const float* const* values, const float* fill, float* const* outs, void* stream) {
+    if (n_queries < 0 || n_rows < 0 || n_keys < 0 || n_values < 1 || n_values > 8) return fail("invalid sizes (1 <= n_values <= 8)");
+    if (n_keys > 4096) return fail("n_keys=%d exceeds 4096 candidates per row", n_keys);
+    if (n_queries >= (1ll << 31)) return fail("too many query ids");
+    if (n_queries == 0 || n_rows == 0) return 0;
+    if (!queries || !values || !fill || !outs || (n_keys && !keys)) return fail("NULL argument");
+    for (int v = 0; v < n_values; ++v)
+        if (!outs[v] || (n_keys && !values[v])) return fail("NULL value / output array %d", v);
+    HIP_OK(launch_gather_by_id(queries, n_queries, keys, n_rows, n_keys, n_values, values, fill, outs, (hipStream_t)stream));
+    return 0;
+}
+
 // ---- wire codec helper (host only) ----
 static const char kB64Url[65] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789-_";
 

@@ -83,4 +83,8 @@ hipError_t launch_priority_sample(const float* scores, const uint8_t* labels, co
                                   int64_t* out_samples, float* out_log_weights, uint8_t* out_labels, float* out_lse,
                                   hipStream_t stream);
 
+hipError_t launch_gather_by_id(const int64_t* queries, int64_t n_queries, const int64_t* keys, int64_t n_rows, int n_keys,
+                               int n_values, const float* const* values, const float* fill, float* const* outs,
+                               hipStream_t stream);
+
 }  // namespace vodhip
