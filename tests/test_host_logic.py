@@ -429,3 +429,28 @@ def test_zarr_vector_store_reads_what_the_reference_layout_declares(tmp_path, dt
     m = factory.build_hip_mips_index(ZarrVectors(path), config={"port": 23457}, cache_dir=tmp_path / "cache", skip_setup=True)
     assert m.vectors_path == path and not (tmp_path / "cache" / "indices").exists()
     np.testing.assert_array_equal(np.load(store.save_vectors(tmp_path / "v.npy", ZarrVectors(path)[0:300].astype(np.float16))), x[:300].astype(np.float16))
+
+
+def test_samples_to_dict_has_the_collate_field_contract():
+    """Keys / dtypes of `_samples_to_dict` (realm_collate.py:247-278), the hand-off to RetrievalGradients."""
+    torch = pytest.importorskip("torch")
+    from vod_amd.core.sample import PrioritySampledSections, samples_to_dict
+
+    b, n = 3, 4
+    ps = PrioritySampledSections(
+        batch=vt.RetrievalBatch(indices=np.arange(b * n).reshape(b, n), scores=np.ones((b, n), np.float64), labels=np.eye(b, n, dtype=np.int64)),
+        log_weights=np.zeros((b, n), np.float32), max_sampling_id=np.zeros(b), lse_pos=np.zeros(b, np.float32),
+        lse_neg=np.ones(b, np.float32), raw_scores={"dense": np.full((b, n), np.nan, np.float32)},
+    )
+    rel = [[1.0, 0.0, 0.0, 0.0]] * b
+    d = samples_to_dict(ps, rel, prefix="section__")
+    assert set(d) == {f"section__{k}" for k in ("idx", "score", "label", "relevance", "log_weight", "lse_pos", "lse_neg", "dense")}
+    assert d["section__label"].dtype == np.bool_ and d["section__relevance"] is rel
+    t = samples_to_dict(ps, rel, prefix="section__", as_torch=True)
+    assert t["section__score"].dtype == torch.float32 and t["section__label"].dtype == torch.bool
+    assert t["section__relevance"].dtype == torch.float32 and t["section__idx"].dtype == torch.int64
+    assert t["section__lse_neg"].shape == (b,) and torch.isnan(t["section__dense"]).all()
+    ps_nolabel = PrioritySampledSections(batch=vt.RetrievalBatch(indices=np.zeros((1, 1), np.int64), scores=np.zeros((1, 1))),
+                                         log_weights=np.zeros((1, 1)), max_sampling_id=np.zeros(1), lse_pos=np.zeros(1), lse_neg=np.zeros(1), raw_scores={})
+    with pytest.raises(ValueError):
+        samples_to_dict(ps_nolabel, [[0.0]])

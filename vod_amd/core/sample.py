@@ -108,3 +108,32 @@ def sample_search_results(
         log_weights=logw.cpu().numpy(),
         raw_scores=sampled_raw,
     )
+
+
+def samples_to_dict(samples: PrioritySampledSections, relevances, prefix: str = "", as_torch: bool = False) -> dict:
+    """The `section__*` fields the collate hands to the model, from the sampled (or flattened) sections.
+
+    Mirror of `_samples_to_dict` (/root/reference/src/vod_dataloaders/realm_collate.py:247-278): keys
+    `{prefix}idx | score | label | relevance | log_weight | lse_pos | lse_neg` plus one per raw engine score; with
+    `as_torch` the score is float32, the label bool, the relevance a float32 tensor, the rest `torch.from_numpy`.
+    """
+    if samples.batch.labels is None:
+        raise ValueError("The sections must have labels.")
+    out = {
+        f"{prefix}idx": samples.batch.indices,
+        f"{prefix}score": samples.batch.scores,
+        f"{prefix}label": samples.batch.labels > 0,
+        f"{prefix}relevance": relevances,
+        f"{prefix}log_weight": samples.log_weights,
+        f"{prefix}lse_pos": samples.lse_pos,
+        f"{prefix}lse_neg": samples.lse_neg,
+        **{f"{prefix}{k}": v for k, v in samples.raw_scores.items()},
+    }
+    if as_torch:
+        special = {
+            f"{prefix}score": lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(torch.float32),
+            f"{prefix}label": lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(torch.bool),
+            f"{prefix}relevance": lambda x: torch.tensor(x, dtype=torch.float32),
+        }
+        out = {k: special.get(k, lambda x: torch.from_numpy(np.ascontiguousarray(x)))(v) for k, v in out.items()}
+    return out
