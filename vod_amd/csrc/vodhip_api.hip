@@ -648,15 +648,17 @@ int64_t vodhip_b64url_encode(const uint8_t* head, int64_t n_head, const uint8_t*
 
 int64_t vodhip_b64url_decode(const char* src, int64_t n, uint8_t* out) {
     if (n < 0 || (n && (!src || !out))) return -1;
-    static int8_t table[256];
-    static bool ready = false;
-    if (!ready) {  // benign race: every thread writes the same values
-        for (int c = 0; c < 256; ++c) table[c] = -1;
-        for (int c = 0; c < 64; ++c) table[(unsigned char)kB64Url[c]] = (int8_t)c;
-        table[(unsigned char)'+'] = 62;
-        table[(unsigned char)'/'] = 63;
-        ready = true;
-    }
+    struct Table {
+        int8_t v[256];
+        Table() {
+            for (int c = 0; c < 256; ++c) v[c] = -1;
+            for (int c = 0; c < 64; ++c) v[(unsigned char)kB64Url[c]] = (int8_t)c;
+            v[(unsigned char)'+'] = 62;
+            v[(unsigned char)'/'] = 63;
+        }
+    };
+    static const Table tbl;  // thread-safe initialisation (C++11 magic static)
+    const int8_t* table = tbl.v;
     while (n > 0 && src[n - 1] == '=') --n;
     uint8_t* o = out;
     int64_t i = 0;
