@@ -44,6 +44,8 @@ def parse_args() -> argparse.Namespace:
     p.add_argument("--dtype", choices=["f16", "bf16"], default="f16")
     p.add_argument("--tile", type=int, default=0)
     p.add_argument("--growth", type=int, default=0, help="chunk growth factor x100 (0 = library default)")
+    p.add_argument("--force-collective", action="store_true",
+                   help="run the multi-GPU step (RCCL all-gather of the packed top-k + merge) even with one rank: exercises the N > 1 code on a 1-GPU box")
     p.add_argument("--small-chunk-tiles", type=int, default=-1)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
@@ -65,11 +67,15 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_collective  # the exchange step runs (with one rank it gathers from itself)
+    if rank != 0:  # only rank 0 reports: keep the other ranks' library banners out of the launcher's merged stdout
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    if multi:
         import torch.distributed as dist  # noqa: PLC0415
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from vod_amd.index import HipFlatIndex, PackedTopk, merge_topk
 
@@ -103,7 +109,7 @@ def main() -> None:
 
     packed = PackedTopk(nq, k, dev)  # [scores | ids] record of this rank: the exchange is ONE all-gather of 12*nq*k bytes
     out_s, out_i = packed.scores, packed.ids
-    if world > 1:
+    if multi:
         gathered = torch.empty((world * packed.nbytes,), dtype=torch.uint8, device=dev)
 
     # One step = one batch through the hot path.  The host runs ONE step ahead of the device: step i+1 is enqueued
@@ -116,7 +122,7 @@ def main() -> None:
         index.search_async(queries, k, id_base=row_lo, out=(out_s, out_i))
         in_flight += 1
         res_ = (out_s, out_i)
-        if world > 1:
+        if multi:
             dist.all_gather_into_tensor(gathered, packed.buffer)
             res_ = packed.merge_gathered(gathered, world)
         while in_flight > 1:
@@ -137,7 +143,7 @@ def main() -> None:
             finish_one()
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -155,7 +161,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     filter_ns, filter_launches = stats["ns"], stats["launches"]
     index.set_param("profile", 0)
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -175,7 +181,7 @@ def main() -> None:
         ls, li = torch.topk(full, min(k, n_local), dim=1)
         li = li + row_lo
         del full
-        if world > 1:
+        if multi:
             pad_s = torch.full((len(sample), k), float("-inf"), device=dev)
             pad_i = torch.full((len(sample), k), -1, dtype=torch.int64, device=dev)
             pad_s[:, : ls.shape[1]] = ls
@@ -224,7 +230,7 @@ def main() -> None:
             "config": {
                 "workload": f"{n_total} sections x {d} {args.dtype}, batch {nq} queries, top-{k}, exact brute force",
                 "rows_per_gpu": n_local,
-                "parallelism": f"row-sharded x{world} + RCCL all-gather of per-shard top-k" if world > 1 else "single GPU",
+                "parallelism": f"row-sharded x{world} + RCCL all-gather of per-shard top-k" if multi else "single GPU",
                 "index_build_s": round(t_build, 3),
             },
             "roofline": {
@@ -249,12 +255,17 @@ def main() -> None:
 
             line["cpu_baseline"] = time_cpu_baseline(d, nq, k, n_total, target_seconds=args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = qps / line["cpu_baseline"]["value"]
-        print(json.dumps(line), flush=True)
-
     index.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio (block-buffered when stdout is a pipe): flush it first so that
+        # the JSON line is the LAST line of rank 0's stdout
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
