@@ -389,6 +389,8 @@ def test_pipelined_searches_finish_in_order_and_stay_exact():
             outs.append(ix.search_async(torch.from_numpy(q[j * 70 : j * 70 + 70]).cuda(), k))
         with pytest.raises(RuntimeError, match="in flight"):
             ix.search_async(torch.from_numpy(q[:8]).cuda(), k)
+        with pytest.raises(RuntimeError, match="in flight"):
+            ix.add(x[:10])  # the store may not change under enqueued searches
         for j in range(4):
             ix.finish()
         from oracle.flat_ip import flat_ip_topk

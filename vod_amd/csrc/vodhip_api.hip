@@ -273,6 +273,7 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
 int vodhip_index_destroy(vodhip_index_t* ix) {
     if (!ix) return 0;
     (void)hipSetDevice(ix->device);
+    if (!ix->inflight.empty()) (void)hipDeviceSynchronize();  // enqueued searches still use the store and the workspace
     free_workspace(ix);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < MAX_IN_FLIGHT; ++i)
@@ -291,6 +292,7 @@ int vodhip_index_add(vodhip_index_t* ix, const void* rows, int64_t n_rows, int s
     if (src_dtype < 0 || src_dtype > 2) return fail("invalid src_dtype %d", src_dtype);
     if (ix->ntotal + n_rows > ix->capacity)
         return fail("index full: ntotal=%lld + %lld > capacity=%lld", (long long)ix->ntotal, (long long)n_rows, (long long)ix->capacity);
+    if (!ix->inflight.empty()) return fail("%d searches are in flight: finish them before adding rows", (int)ix->inflight.size());
     hipStream_t stream = (hipStream_t)stream_;
     HIP_OK(hipSetDevice(ix->device));
     const int es = elem_size(src_dtype);
@@ -317,6 +319,7 @@ int vodhip_index_add(vodhip_index_t* ix, const void* rows, int64_t n_rows, int s
 
 int vodhip_index_reset(vodhip_index_t* ix) {
     if (!ix) return fail("index is NULL");
+    if (!ix->inflight.empty()) return fail("%d searches are in flight: finish them before resetting the index", (int)ix->inflight.size());
     ix->ntotal = 0;
     return 0;
 }
