@@ -383,7 +383,7 @@ def test_pipelined_searches_finish_in_order_and_stay_exact():
     overflowing search in the middle of the pipeline is re-run in the exhaustive schedule without disturbing the others."""
     n, d, k = 60000, 64, 20
     q, x = _int_data(11, n, d, 300)
-    with _index(x) as ix:
+    with _index(x, capacity=n + 100) as ix:
         outs = []
         for j in range(4):
             outs.append(ix.search_async(torch.from_numpy(q[j * 70 : j * 70 + 70]).cuda(), k))
