@@ -20,6 +20,7 @@
 // Roofline: 2*nq*N*D flop per batch on MFMA vs N*D*2 bytes of HBM; arithmetic intensity = nq flop/B.
 #include "vodhip_internal.h"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace vodhip {
@@ -1434,17 +1435,6 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
     }
 }
 
-__global__ void mips_init_kernel(key_t64* topk, int64_t n_topk, unsigned int* cnt, float* thr_s, key_t64* thr_key,
-                                 int64_t nq_pad) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_topk) topk[i] = 0;
-    if (i < nq_pad) {
-        cnt[i] = 0;
-        thr_s[i] = -__builtin_inff();
-        thr_key[i] = 0;
-    }
-}
-
 __global__ void mips_output_kernel(const key_t64* __restrict__ topk, int kp, int k, int64_t nq, int64_t id_base,
                                    float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1518,12 +1508,59 @@ hipError_t launch_convert_rows(const void* src, int src_dtype, int64_t n_rows, i
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_search_init(const SearchWorkspace& ws, int64_t nq_pad, hipStream_t stream) {
+// One launch at the head of every search pass: stage the queries (convert to the store dtype, zero the padded columns
+// and rows), clear the running top-k / counters / thresholds and the overflow word.  Replaces two fills, the query
+// conversion and the init kernel (4 launches and their gaps: ~20 us of a 0.8-2 ms small search).
+__global__ void mips_prepare_kernel(const void* __restrict__ q_src, int q_dtype, int64_t nq, int64_t dim,
+                                    uint16_t* __restrict__ q_pad, int store_dtype, int64_t nq_pad, int64_t dim_pad,
+                                    key_t64* __restrict__ topk, int64_t n_topk, unsigned int* __restrict__ cnt,
+                                    float* __restrict__ thr_s, key_t64* __restrict__ thr_key,
+                                    unsigned int* __restrict__ overflow, int clear_overflow) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t chunks_per_row = dim_pad / 8;
+    if (i < nq_pad * chunks_per_row) {
+        const int64_t row = i / chunks_per_row;
+        const int64_t c0 = (i % chunks_per_row) * 8;
+        uint16_t out[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t c = c0 + e;
+            uint16_t v = 0;
+            if (row < nq && c < dim) {
+                float f;
+                if (q_dtype == 2) f = ((const float*)q_src)[row * dim + c];
+                else if (q_dtype == 0) f = (float)(((const _Float16*)q_src)[row * dim + c]);
+                else f = (float)(((const __bf16*)q_src)[row * dim + c]);
+                if (store_dtype == 0) {
+                    const _Float16 h = (_Float16)f;
+                    v = __builtin_bit_cast(uint16_t, h);
+                } else {
+                    const __bf16 h = (__bf16)f;
+                    v = __builtin_bit_cast(uint16_t, h);
+                }
+            }
+            out[e] = v;
+        }
+        *(uint4*)(q_pad + row * dim_pad + c0) = *(const uint4*)out;
+    }
+    if (i < n_topk) topk[i] = 0;
+    if (i < nq_pad) {
+        cnt[i] = 0;
+        thr_s[i] = -__builtin_inff();
+        thr_key[i] = 0;
+    }
+    if (i == 0 && clear_overflow) *overflow = 0u;
+}
+
+hipError_t launch_search_prepare(const SearchWorkspace& ws, const void* q_src, int q_dtype, int64_t nq, int64_t dim,
+                                 int store_dtype, int64_t nq_pad, int64_t dim_pad, bool clear_overflow, hipStream_t stream) {
     const int64_t n_topk = nq_pad * ws.kp;
+    const int64_t n = std::max(n_topk, nq_pad * (dim_pad / 8));
     const int threads = 256;
-    const unsigned blocks = (unsigned)((n_topk + threads - 1) / threads);
-    hipLaunchKernelGGL(mips_init_kernel, dim3(blocks), dim3(threads), 0, stream, ws.topk, n_topk, ws.cnt, ws.thr_s,
-                       ws.thr_key, nq_pad);
+    const unsigned blocks = (unsigned)((n + threads - 1) / threads);
+    hipLaunchKernelGGL(mips_prepare_kernel, dim3(blocks), dim3(threads), 0, stream, q_src, q_dtype, nq, dim,
+                       (uint16_t*)ws.q_pad, store_dtype, nq_pad, dim_pad, ws.topk, n_topk, ws.cnt, ws.thr_s, ws.thr_key,
+                       ws.overflow, clear_overflow ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -190,16 +190,14 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
     ix->ws.extra.q_label = ps.q_label;
     ix->ws.extra.n_qlab = ps.n_qlab;
     const SearchWorkspace& ws = ix->ws;
-    HIP_OK(hipMemsetAsync(ws.overflow, 0, sizeof(unsigned int), stream));
     for (int64_t qb = 0; qb < ps.nq; qb += MAX_NQ_PER_PASS) {
         const int64_t nq = std::min(MAX_NQ_PER_PASS, ps.nq - qb);
         const int64_t nq_pad = round_up(nq, bn);
-        // queries -> store dtype, zero padded rows/cols
-        HIP_OK(hipMemsetAsync(ws.q_pad, 0, (size_t)nq_pad * ix->dim_pad * 2, stream));
-        HIP_OK(launch_convert_rows((const char*)ps.queries + (size_t)qb * ix->dim * q_es, ps.q_dtype, nq, ix->dim,
-                                   ws.q_pad, ix->dtype, ix->dim_pad, stream));
+        // one launch: queries -> store dtype with zero padded rows / columns, running top-k, counters and thresholds
+        // cleared, overflow word cleared at the first pass
+        HIP_OK(launch_search_prepare(ws, (const char*)ps.queries + (size_t)qb * ix->dim * q_es, ps.q_dtype, nq, ix->dim,
+                                     ix->dtype, nq_pad, ix->dim_pad, qb == 0, stream));
         ix->ws.extra.q_label = ps.q_label ? ps.q_label + (size_t)qb * ps.n_qlab : nullptr;
-        HIP_OK(launch_search_init(ws, nq_pad, stream));
         for (size_t c = 0; c < chunks.size(); ++c) {
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             if (ix->profile) {

@@ -36,7 +36,8 @@ struct SearchWorkspace {
 // store_dtype: 0 = f16, 1 = bf16.  tile: 1 = 128x128 (256 threads), 2 = 256x256 (512 threads).
 hipError_t launch_convert_rows(const void* src, int src_dtype, int64_t n_rows, int64_t dim, void* dst, int dst_dtype,
                                int64_t dst_stride, hipStream_t stream);
-hipError_t launch_search_init(const SearchWorkspace& ws, int64_t nq_pad, hipStream_t stream);
+hipError_t launch_search_prepare(const SearchWorkspace& ws, const void* q_src, int q_dtype, int64_t nq, int64_t dim,
+                                 int store_dtype, int64_t nq_pad, int64_t dim_pad, bool clear_overflow, hipStream_t stream);
 hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* store, const void* q_pad, int64_t dim_pad,
                          int64_t row_begin, int64_t row_end, int64_t nq, int64_t nq_pad, const SearchWorkspace& ws,
                          hipStream_t stream);
