@@ -1378,7 +1378,9 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
                                                           const key_t64* __restrict__ cand,
                                                           unsigned int* __restrict__ cnt, int cap, int dense_n,
                                                           float* __restrict__ thr_s, key_t64* __restrict__ thr_key,
-                                                          unsigned int* __restrict__ overflow, int final_sort) {
+                                                          unsigned int* __restrict__ overflow, int final_sort,
+                                                          int64_t id_base, float* __restrict__ out_scores,
+                                                          int64_t* __restrict__ out_ids) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     key_t64* keys = (key_t64*)smem;
     int* hist = (int*)(keys + sb);  // [256 + 2] + compaction counter at [258]
@@ -1428,6 +1430,13 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
         done += take;
     } while (done < (int)n);
     for (int i = tid; i < kp; i += 256) topk[(size_t)q * kp + i] = keys[i];
+    if (out_scores != nullptr) {  // last select of a search: the sorted keys leave as (float32 score, int64 id) rows
+        for (int c = tid; c < k; c += 256) {
+            const key_t64 key = keys[c];
+            out_scores[(size_t)q * k + c] = key ? unflip_f32((unsigned)(key >> 32)) : -__builtin_inff();
+            out_ids[(size_t)q * k + c] = key ? id_base + (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)) : -1;
+        }
+    }
     if (tid == 0) {
         thr_key[q] = kth;
         thr_s[q] = kth ? unflip_f32((unsigned)(kth >> 32)) : -__builtin_inff();
@@ -1801,12 +1810,14 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, bool final_sort, hipStream_t stream) {
+hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, bool final_sort, hipStream_t stream,
+                         int64_t id_base, float* out_scores, int64_t* out_ids) {
     int sb = 2048;  // keys per workgroup buffer: 16 KB -> 8 workgroups per CU
     while (sb < 2 * ws.kp) sb <<= 1;
     const size_t lds = (size_t)sb * sizeof(key_t64) + 260 * sizeof(int);
     hipLaunchKernelGGL(mips_select_kernel, dim3((unsigned)nq), dim3(256), lds, stream, ws.topk, (int)ws.kp, k, sb, ws.cand,
-                       ws.cnt, (int)ws.cap, (int)dense_n, ws.thr_s, ws.thr_key, ws.overflow, final_sort ? 1 : 0);
+                       ws.cnt, (int)ws.cap, (int)dense_n, ws.thr_s, ws.thr_key, ws.overflow, final_sort ? 1 : 0, id_base,
+                       final_sort ? out_scores : nullptr, final_sort ? out_ids : nullptr);
     return hipGetLastError();
 }
 

@@ -220,9 +220,11 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
             HIP_OK(launch_filter(ix->dtype, tile_c, dense[c], ix->data, ws.q_pad, ix->dim_pad, chunks[c].first,
                                  chunks[c].second, nq, nq_pad, ws, stream));
             if (ix->profile) HIP_OK(hipEventRecord(ev1, stream));
-            HIP_OK(launch_select(ws, nq, k, dense[c] ? chunks[c].second - chunks[c].first : -1, c + 1 == chunks.size(), stream));
+            HIP_OK(launch_select(ws, nq, k, dense[c] ? chunks[c].second - chunks[c].first : -1, c + 1 == chunks.size(), stream,
+                                 ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k));
         }
-        HIP_OK(launch_output(ws, nq, k, ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k, stream));
+        if (chunks.empty())  // empty index: nothing was selected, the cleared top-k leaves as pads
+            HIP_OK(launch_output(ws, nq, k, ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k, stream));
     }
     HIP_OK(hipMemcpyAsync(ix->overflow_host + ps.slot, ws.overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipEventRecord(ix->done[ps.slot], stream));

@@ -41,7 +41,9 @@ hipError_t launch_search_prepare(const SearchWorkspace& ws, const void* q_src, i
 hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* store, const void* q_pad, int64_t dim_pad,
                          int64_t row_begin, int64_t row_end, int64_t nq, int64_t nq_pad, const SearchWorkspace& ws,
                          hipStream_t stream);
-hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, bool final_sort, hipStream_t stream);
+// with `final_sort` the sorted top-k also leaves as float32 scores / int64 ids (+ id_base) in out_scores / out_ids [nq, k]
+hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, bool final_sort, hipStream_t stream,
+                         int64_t id_base = 0, float* out_scores = nullptr, int64_t* out_ids = nullptr);
 hipError_t launch_output(const SearchWorkspace& ws, int64_t nq, int k, int64_t id_base, float* out_scores,
                          int64_t* out_ids, hipStream_t stream);
 hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int64_t stride_s, int64_t stride_i, int n_shards,
