@@ -174,16 +174,21 @@ def test_all_equal_scores_tie_break_by_id():
         assert torch.all(s == 64.0)
 
 
-def test_nan_and_inf_rows_never_win():
-    q, x = _int_data(13, 5000, 64, 6)
+@pytest.mark.parametrize("n,nq", [(5000, 6), (150000, 700), (150000, 200), (150000, 100)])
+def test_nan_and_inf_rows_never_win(n, nq):
+    """All kernel families (small-batch ring, 3+2-slot persistent, persistent with the LDS survivor list) and both the
+    dense and the filtered chunks see NaN / inf rows."""
+    q, x = _int_data(13, n, 64, nq)
     x = x.copy()
     x[17, 3] = np.nan
     x[4000, 5] = np.inf   # +inf * 0 -> nan for queries with a zero there, +-inf otherwise
+    x[n - 3, 7] = np.nan
+    x[n // 2, 9] = -np.inf
     with _index(x) as ix:
         s, i = ix.search(torch.from_numpy(q).cuda(), 10)
         s, i = s.cpu().numpy(), i.cpu().numpy()
         assert not np.isnan(s).any()
-        assert not (i == 17).any()
+        assert not (i == 17).any() and not (i == n - 3).any()
         with np.errstate(all="ignore"):
             full = q.astype(np.float64) @ x.astype(np.float64).T
         from oracle.flat_ip import topk_desc_tiebreak
