@@ -95,8 +95,9 @@ def test_empty_index_and_empty_query():
         assert s.shape == (0, 4) and i.shape == (0, 4)
 
 
-def test_k_max_and_large_k():
-    q, x = _int_data(5, 9000, 64, 5)
+@pytest.mark.parametrize("n,nq", [(9000, 5), (40000, 300), (40000, 130)])
+def test_k_max_and_large_k(n, nq):
+    q, x = _int_data(5, n, 64, nq)
     with _index(x) as ix:
         _assert_exact(ix, q, x, 2048)
         _assert_exact(ix, q, x, 1000)
