@@ -139,16 +139,18 @@ def test_add_from_device_and_f32_rounding():
         np.testing.assert_allclose(s.cpu().numpy(), rs, atol=SCORE_TOL, rtol=0)
 
 
-def test_overflow_falls_back_to_exhaustive_schedule():
-    """Scores that rise along the row order defeat the geometric schedule; the safe re-run must stay exact."""
+@pytest.mark.parametrize("nq", [4, 100, 200, 300])
+def test_overflow_falls_back_to_exhaustive_schedule(nq):
+    """Scores that rise along the row order defeat the geometric schedule; the safe re-run must stay exact
+    (nq selects the kernel family: small-batch rings, 3+2-slot persistent, persistent with the LDS survivor list)."""
     n, d = 60000, 64
     x = np.zeros((n, d), dtype=np.float16)
     x[:, 0] = (np.arange(n) // 32).astype(np.float16)  # non-decreasing, exactly representable (< 2048)
     x[:, 1] = 1
-    q = np.zeros((4, d), dtype=np.float16)
+    q = np.zeros((nq, d), dtype=np.float16)
     q[:, 0] = 1
-    q[1, 0] = -1
-    q[2, 1] = 3
+    q[1::4, 0] = -1
+    q[2::4, 1] = 3
     with _index(x, cand_cap=512, dense_rows=256) as ix:
         _assert_exact(ix, q, x, 40)
         assert ix.get_stat("last_overflow") == 1 and ix.get_stat("last_safe_reruns") == 1
@@ -156,8 +158,9 @@ def test_overflow_falls_back_to_exhaustive_schedule():
         _assert_exact(ix, q, x, 40)
 
 
-def test_force_safe_equals_default_schedule():
-    q, x = _int_data(12, 40000, 128, 50)
+@pytest.mark.parametrize("nq", [50, 300])
+def test_force_safe_equals_default_schedule(nq):
+    q, x = _int_data(12, 40000, 128, nq)
     with _index(x) as ix:
         a = [t.cpu().numpy() for t in ix.search(torch.from_numpy(q).cuda(), 100)]
         ix.set_param("force_safe", 1)
@@ -166,12 +169,13 @@ def test_force_safe_equals_default_schedule():
     np.testing.assert_array_equal(a[1], b[1])
 
 
-def test_all_equal_scores_tie_break_by_id():
+@pytest.mark.parametrize("nq", [3, 400])
+def test_all_equal_scores_tie_break_by_id(nq):
     x = np.ones((20000, 64), dtype=np.float16)
-    q = np.ones((3, 64), dtype=np.float16)
+    q = np.ones((nq, 64), dtype=np.float16)
     with _index(x) as ix:
         s, i = ix.search(torch.from_numpy(q).cuda(), 100)
-        np.testing.assert_array_equal(i.cpu().numpy(), np.tile(np.arange(100), (3, 1)))
+        np.testing.assert_array_equal(i.cpu().numpy(), np.tile(np.arange(100), (nq, 1)))
         assert torch.all(s == 64.0)
 
 
