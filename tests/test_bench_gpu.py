@@ -40,3 +40,39 @@ def test_multi_gpu_step_runs_with_one_rank():
     line = _run("--force-collective", "--no-cpu-baseline")
     assert "all-gather" in line["config"]["parallelism"]
     assert line["verify"]["recall_at_k_vs_torch_fp32"] == 1.0
+
+
+def test_sharded_index_exchange_on_rccl_with_one_rank(tmp_path):
+    """`ShardedFlatIndex`'s native path (HIP search -> ONE packed RCCL all-gather -> HIP merge) on a real RCCL
+    communicator; a single rank gathers from itself, so the result must equal the plain search."""
+    script = tmp_path / "one_rank.py"
+    script.write_text(f"""
+import sys
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, {str(ROOT)!r})
+from vod_amd.distributed import ShardedFlatIndex
+from vod_amd.index import HipFlatIndex
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+rng = np.random.default_rng(0)
+x = rng.integers(-8, 9, size=(50000, 96)).astype(np.float16)
+q = rng.integers(-8, 9, size=(300, 96)).astype(np.float16)
+ix = HipFlatIndex(96, 50000)
+ix.add(x)
+tq = torch.from_numpy(q).cuda()
+s0, i0 = ix.search(tq, 50, id_base=7000)
+sh = ShardedFlatIndex(ix, row_offset=7000, always_exchange=True)
+for _ in range(3):
+    s1, i1 = sh.search(tq, 50)
+assert torch.equal(s0, s1) and torch.equal(i0, i1)
+dist.destroy_process_group()
+print("sharded exchange ok")
+""")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "sharded exchange ok" in out.stdout

@@ -29,10 +29,11 @@ class ShardedFlatIndex:
     """The corpus row-sharded over `group`; every rank gets the full merged result."""
 
     def __init__(self, local_index: typ.Any, row_offset: int, group: dist.ProcessGroup | None = None,
-                 local_search: typ.Callable | None = None, merge: typ.Callable | None = None):
+                 local_search: typ.Callable | None = None, merge: typ.Callable | None = None, always_exchange: bool = False):
         self.local_index = local_index
         self.row_offset = int(row_offset)
         self.group = group
+        self.always_exchange = always_exchange  # run the all-gather + merge even with one rank (exercises RCCL on a 1-GPU box)
         self._native_path = local_search is None and merge is None  # HIP search + ONE packed all-gather + HIP merge
         self._local_search = local_search or (lambda q, k, base: local_index.search(q, k, id_base=base))
         if merge is None:
@@ -47,7 +48,7 @@ class ShardedFlatIndex:
     def search(self, queries: torch.Tensor, k: int) -> tuple[torch.Tensor, torch.Tensor]:
         """queries [nq, d], identical on every rank.  Returns (scores f32 [nq, k], global ids i64 [nq, k])."""
         world = self.world
-        if self._native_path and world > 1:
+        if self._native_path and (world > 1 or (self.always_exchange and dist.is_initialized())):
             from vod_amd.index import PackedTopk
 
             nq = int(queries.shape[0])
