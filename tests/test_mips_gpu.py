@@ -334,13 +334,13 @@ def test_persistent_kernel_odd_qtile_counts(nq, tile):
         _assert_exact(ix, q, x, 10)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 8, 9, 42, 46])
 def test_subset_filtered_search(tile):
     """per-row labels + per-query allowed labels; exact top-k over the eligible rows only."""
     from oracle.flat_ip import topk_desc_tiebreak
 
     rng = np.random.default_rng(77)
-    n, d, nq, k = 40000, 64, 300 if tile != 1 else 100, 50
+    n, d, nq, k = 40000, 64, {1: 100, 42: 50, 46: 100}.get(tile, 300), 50
     q, x = _int_data(78, n, d, nq)
     labels = rng.integers(0, 12, size=n).astype(np.int32)
     subset = np.full((nq, 3), -1, dtype=np.int32)

@@ -1611,8 +1611,22 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
     if (row_end <= row_begin) return hipSuccess;
     const bool subset = ws.extra.row_label != nullptr;
     if (subset) {
-        // the subset filter is instantiated for the production variants only (1: 128x128, 8/9/10: 256x256 16x16x32)
-        if (tile != 1 && tile != 8 && tile != 9 && tile != 10) return hipErrorNotSupported;
+        // the subset filter is instantiated for the production variants only (1, 42, 46: small batches; 8/9/10: 256x256 16x16x32)
+        if (tile != 1 && tile != 8 && tile != 9 && tile != 10 && tile != 42 && tile != 46) return hipErrorNotSupported;
+#define VOD_SUBN(DT, DENSE, BN_, WM_, WN_) return launch_filter_cfg<DT, 256, BN_, WM_, WN_, 64, 3, DENSE, 0, false, true>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream)
+        if (tile == 42) {
+            if (store_dtype == 0 && dense) VOD_SUBN(0, true, 64, 4, 1);
+            if (store_dtype == 0 && !dense) VOD_SUBN(0, false, 64, 4, 1);
+            if (store_dtype == 1 && dense) VOD_SUBN(1, true, 64, 4, 1);
+            if (store_dtype == 1 && !dense) VOD_SUBN(1, false, 64, 4, 1);
+        }
+        if (tile == 46) {
+            if (store_dtype == 0 && dense) VOD_SUBN(0, true, 128, 4, 2);
+            if (store_dtype == 0 && !dense) VOD_SUBN(0, false, 128, 4, 2);
+            if (store_dtype == 1 && dense) VOD_SUBN(1, true, 128, 4, 2);
+            if (store_dtype == 1 && !dense) VOD_SUBN(1, false, 128, 4, 2);
+        }
+#undef VOD_SUBN
         if (tile == 1) {
 #define VOD_SUB1(DT, DENSE) return launch_filter_cfg<DT, 128, 128, 2, 2, 64, 2, DENSE, 0, false, true>(store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream)
             if (store_dtype == 0 && dense) VOD_SUB1(0, true);

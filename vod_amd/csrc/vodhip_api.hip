@@ -181,7 +181,6 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
     // every corpus read an HBM miss
     if (tile == 0) {
         tile = ps.nq > 256 ? 9 : (ps.nq > 128 ? 10 : (ps.nq > 64 ? 46 : 42));
-        if (ix->row_label && ps.q_label && ps.nq <= 128) tile = 1;  // the subset filter is instantiated for 1 / 8 / 9 / 10
     }
     const int64_t bn = filter_tile_cols(tile);
     if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
