@@ -21,6 +21,9 @@
 #include "vodhip_internal.h"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <type_traits>
 
 namespace vodhip {
@@ -1582,6 +1585,22 @@ extern "C" int vodhip_debug_read_stamps(unsigned long long* host_out, long long 
 int filter_tile_rows(int tile) { return (tile == 1 || tile == 5) ? 128 : 256; }  // ablation ids 11..13 are 256
 int filter_tile_cols(int tile) { return tile == 42 ? 64 : tile == 46 ? 128 : (tile == 1 || tile == 5) ? 128 : 256; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel): it is a driver call on the launch path
+// (three persistent launches per batch otherwise pay it every time).
+static hipError_t allow_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, int> granted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = granted.find({dev, kernel});
+    if (it != granted.end() && it->second >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) granted[{dev, kernel}] = bytes;
+    return e;
+}
+
 template <int DT, int BM, int BN, int WM, int WN, int BK, int NSTAGE, bool DENSE, int ABLATE = 0, bool PINGPONG = false, bool SUBSET = false>
 static hipError_t launch_filter_cfg(const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin,
                                     int64_t row_end, int64_t nq, int64_t nq_pad, const SearchWorkspace& ws,
@@ -1593,12 +1612,7 @@ static hipError_t launch_filter_cfg(const void* store, const void* q_pad, int64_
     constexpr int threads = WM * WN * 64;
     constexpr size_t lds = (size_t)NSTAGE * (BM + BN) * BK * 2 + (ABLATE == 15 ? 2048 : 0);
     auto kern = mips_filter_kernel<DT, BM, BN, WM, WN, BK, NSTAGE, DENSE, ABLATE, PINGPONG, SUBSET>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_dynamic_lds((const void*)kern, (int)lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, (const uint16_t*)store, (const uint16_t*)q_pad,
                        (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s, ws.thr_key,
                        ws.cand, ws.cnt, (int)ws.cap, ws.overflow, ws.extra);
@@ -1667,7 +1681,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         auto kern = tile == 10 ? (subset ? mips_filter16p_kernel<DT, true, true> : mips_filter16p_kernel<DT, true, false>)  \
                                : (subset ? mips_filter16p_kernel<DT, false, true> : mips_filter16p_kernel<DT, false, false>); \
         (void)0;                                                                      \
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        hipError_t e = allow_dynamic_lds((const void*)kern, (int)lds);   \
         if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, (const uint16_t*)store,                 \
                            (const uint16_t*)q_pad, (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles,     \
@@ -1686,7 +1700,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
 #define VOD_K16(DT, DENSE)                                                                                             \
     {                                                                                                                  \
         auto kern = subset ? mips_filter16_kernel<DT, DENSE, true> : mips_filter16_kernel<DT, DENSE, false>;           \
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        hipError_t e = allow_dynamic_lds((const void*)kern, (int)lds);   \
         if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, (const uint16_t*)store, (const uint16_t*)q_pad,   \
                            (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s,          \
@@ -1707,7 +1721,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
 #define VOD_SPEC(DT, BKK, NS, DENSE)                                                                                   \
     {                                                                                                                  \
         auto kern = mips_filter_spec_kernel<DT, BKK, NS, 4, DENSE>;                                                    \
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        hipError_t e = allow_dynamic_lds((const void*)kern, (int)lds);   \
         if (e != hipSuccess) return e;                                                                                 \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, stream, (const uint16_t*)store, (const uint16_t*)q_pad,   \
                            (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s,          \
@@ -1771,7 +1785,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
             case 6: kern = mips_filter16p_kernel<0, false, false, false, 6>; break;
             default: kern = mips_filter16p_kernel<0, false, false, false, 7>; break;
         }
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + PSTG_BYTES);
+        hipError_t e = allow_dynamic_lds((const void*)kern, 128 * 1024 + PSTG_BYTES);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 128 * 1024 + PSTG_BYTES, stream, (const uint16_t*)store, (const uint16_t*)q_pad,
                            (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s, ws.thr_key, ws.cand,
@@ -1785,7 +1799,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         int grid = (256 / unit) * unit;
         if (grid > total) grid = total;
         auto kern = mips_filter16p_kernel<0, false, false, true>;
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + PSTG_BYTES);
+        hipError_t e = allow_dynamic_lds((const void*)kern, 128 * 1024 + PSTG_BYTES);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 128 * 1024 + PSTG_BYTES, stream, (const uint16_t*)store, (const uint16_t*)q_pad,
                            (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s, ws.thr_key, ws.cand,
@@ -1805,7 +1819,7 @@ hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* stor
         auto kern = mips_filter_spec_kernel<0, 32, 4, 4, false, true>;
         if (tile == 23) kern = mips_filter_spec_kernel<0, 32, 4, 4, false, true, 1>;
         if (tile == 24) kern = mips_filter_spec_kernel<0, 32, 4, 4, false, true, 2>;
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipError_t e = allow_dynamic_lds((const void*)kern, 128 * 1024);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(768), 128 * 1024, stream, (const uint16_t*)store, (const uint16_t*)q_pad,
                            (int)dim_pad, (int)row_begin, (int)row_end, n_xtiles, n_qtiles, (int)nq, ws.thr_s, ws.thr_key,
@@ -1923,13 +1937,7 @@ hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int64_t st
     while ((int)P < total) P <<= 1;
     const size_t lds = P * 12;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)merge_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = allow_dynamic_lds((const void*)merge_topk_kernel, 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(256), lds, stream, scores, ids, stride_s, stride_i, n_shards, nq, k, k_out,
                        out_scores, out_ids);
     return hipGetLastError();
