@@ -78,12 +78,52 @@ def flat_ip_topk_cpu(q: torch.Tensor, x: torch.Tensor, k: int, block: int = 1638
     return ts, torch.gather(cand_i, 1, to)
 
 
-def time_cpu_baseline(dim: int, nq: int, k: int, n_full: int, target_seconds: float = 15.0, max_rows: int = 2_000_000,
+def effective_cpus() -> int:
+    """CPUs this process may actually use: the scheduler affinity capped by the cgroup CPU quota (a container that
+    sees 256 logical CPUs but is limited to 16 runs a 128-thread sgemm three times slower than a 16-thread one)."""
+    import math
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, math.ceil(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def _pick_threads(q: torch.Tensor, xp: torch.Tensor) -> int:
+    """The thread count (quota, 2 x quota or torch's default) with the fastest sgemm on a small probe."""
+    base = effective_cpus()
+    best, best_t = torch.get_num_threads(), float("inf")
+    for t in sorted({base, 2 * base, torch.get_num_threads()}):
+        torch.set_num_threads(t)
+        _ = q @ xp[:16384].T
+        t0 = time.perf_counter()
+        for lo in range(0, xp.shape[0], 16384):
+            _ = q @ xp[lo : lo + 16384].T
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best, best_t = t, dt
+    return best
+
+
+def time_cpu_baseline(dim: int, nq: int, k: int, n_full: int, target_seconds: float = 15.0, max_rows: int = 4_000_000,
                       seed: int = 1234) -> dict:
     """Time the port on a bounded sample of the workload; extrapolate linearly in N to `n_full` rows."""
-    threads = torch.get_num_threads()
     g = torch.Generator().manual_seed(seed)
     q = torch.randn(nq, dim, generator=g)
+    default_threads = torch.get_num_threads()
+    threads = _pick_threads(q, torch.randn(65536, dim, generator=g))
+    torch.set_num_threads(threads)
     probe_rows = 65536
     xp = torch.randn(probe_rows, dim, generator=g)
     flat_ip_topk_cpu(q, xp[:16384], k)  # warm-up (thread pool, MKL)
@@ -107,13 +147,15 @@ def time_cpu_baseline(dim: int, nq: int, k: int, n_full: int, target_seconds: fl
         _ = q @ xs[lo : lo + 16384].T
     t_mm = (time.perf_counter() - t0) * (n_full / xs.shape[0])
     gflops = 2.0 * nq * rows * dim / t / 1e9
+    torch.set_num_threads(default_threads)
     return {
         "value": nq / t_full,
         "unit": "queries/s",
         "cores": threads,
         "kind": "port",
         "sample": f"faiss-CPU restated (MKL sgemm + threshold-filtered k-best buffer, fp32): {nq} queries x {rows} of {n_full} rows x {dim}, "
-                  f"top-{k}, {t:.2f} s measured ({gflops:.0f} GFLOP/s end to end), scaled linearly in N",
+                  f"top-{k}, {t:.2f} s measured ({gflops:.0f} GFLOP/s end to end) on {threads} threads "
+                  f"(usable CPUs {effective_cpus()}: affinity capped by the cgroup quota), scaled linearly in N",
         "sgemm_only_value": nq / t_mm,
         "sgemm_only_note": "queries/s if the host spent time on the fp32 Q.X^T product only (no top-k): bound for any BLAS-based CPU path here",
     }
