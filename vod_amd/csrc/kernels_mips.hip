@@ -1333,8 +1333,12 @@ __device__ __forceinline__ void bitonic_sort_desc_lds(key_t64* keys, int P, int 
 // k-th largest of `total` DISTINCT-or-zero 64-bit keys in LDS (zeros = padding, `total` >= k): MSB-first radix select,
 // 8 passes of one byte with a 256-bin LDS histogram.  Returns the key on every thread.  `hist` = 256 ints + 2 scratch.
 __device__ key_t64 radix_select_kth_lds(const key_t64* keys, int total, int k, int* hist, int tid) {
+    // hist: [0..255] bins | 256 digit / key low | 257 rank / key high | 258 (caller's compaction counter) | 259 bin count
+    //       | 260..263 per-wave totals.  MSB-first byte passes; as soon as the bin that holds the k-th key holds ONE key
+    //       (typically after 3-4 of the 8 bytes: distinct float scores) that key is looked up directly.
     key_t64 prefix = 0, mask = 0;
     int rank = k;  // 1-based rank from the top among the keys that match the prefix
+    const int lane = tid & 63, wave = tid >> 6;
     for (int byte = 7; byte >= 0; --byte) {
         hist[tid] = 0;
         __syncthreads();
@@ -1345,30 +1349,43 @@ __device__ key_t64 radix_select_kth_lds(const key_t64* keys, int total, int k, i
         }
         __syncthreads();
         // suffix sums over the 256 bins: thread t learns above(t) = #keys in bins > t; exactly one t has
-        // above(t) < rank <= above(t) + hist[t]
-        int mine = hist[tid];
-        int above = 0;
-        {   // inclusive suffix scan through LDS (4 waves): Hillis-Steele on 256 entries
-            int v = mine;
-            for (int off = 1; off < 256; off <<= 1) {
-                __syncthreads();
-                hist[tid] = v;
-                __syncthreads();
-                if (tid + off < 256) v += hist[tid + off];
-            }
-            above = v - mine;
-            __syncthreads();
+        // above(t) < rank <= above(t) + hist[t].  Wave-level shuffle scan + 4 wave totals through LDS.
+        const int mine = hist[tid];
+        int v = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_down(v, off);
+            if (lane + off < 64) v += u;
         }
+        if (lane == 0) hist[260 + wave] = v;
+        __syncthreads();
+        int above = v - mine;
+        for (int w = wave + 1; w < 4; ++w) above += hist[260 + w];
         if (above < rank && rank <= above + mine) {
             hist[256] = tid;
             hist[257] = rank - above;
+            hist[259] = mine;
         }
         __syncthreads();
         const int digit = hist[256];
         rank = hist[257];
+        const int in_bin = hist[259];
         prefix |= (key_t64)digit << sh;
         mask |= 255ull << sh;
         __syncthreads();
+        if (in_bin == 1 && byte > 0) {  // workgroup-uniform: the k-th key is the only one with this prefix
+            for (int i = tid; i < total; i += 256) {
+                const key_t64 e = keys[i];
+                if ((e & mask) == prefix) {
+                    hist[256] = (int)(unsigned)(e & 0xFFFFFFFFull);
+                    hist[257] = (int)(unsigned)(e >> 32);
+                }
+            }
+            __syncthreads();
+            const key_t64 kth = ((key_t64)(unsigned)hist[257] << 32) | (key_t64)(unsigned)hist[256];
+            __syncthreads();
+            return kth;
+        }
     }
     return prefix;
 }
@@ -1386,7 +1403,7 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
                                                           int64_t* __restrict__ out_ids) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     key_t64* keys = (key_t64*)smem;
-    int* hist = (int*)(keys + sb);  // [256 + 2] + compaction counter at [258]
+    int* hist = (int*)(keys + sb);  // 264 ints: bins, scratch words, compaction counter at [258] (see radix_select_kth_lds)
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     unsigned n = dense_n >= 0 ? (unsigned)dense_n : cnt[q];
@@ -1842,7 +1859,7 @@ hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t d
                          int64_t id_base, float* out_scores, int64_t* out_ids) {
     int sb = 2048;  // keys per workgroup buffer: 16 KB -> 8 workgroups per CU
     while (sb < 2 * ws.kp) sb <<= 1;
-    const size_t lds = (size_t)sb * sizeof(key_t64) + 260 * sizeof(int);
+    const size_t lds = (size_t)sb * sizeof(key_t64) + 264 * sizeof(int);
     hipLaunchKernelGGL(mips_select_kernel, dim3((unsigned)nq), dim3(256), lds, stream, ws.topk, (int)ws.kp, k, sb, ws.cand,
                        ws.cnt, (int)ws.cap, (int)dense_n, ws.thr_s, ws.thr_key, ws.overflow, final_sort ? 1 : 0, id_base,
                        final_sort ? out_scores : nullptr, final_sort ? out_ids : nullptr);
