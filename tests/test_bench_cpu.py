@@ -1,0 +1,40 @@
+"""bench.py's own launcher (`python bench.py --gpus N` without torchrun), checked on CPU.
+
+`--launch-check` makes every spawned rank join a gloo process group, all-reduce its rank and exit before any GPU
+call, so the N = 2 path - fresh child per rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* exported, rank 0's stdout
+is the command's stdout, a failing rank fails the command - is proven to reach `init_process_group` here."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _bench(*args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=300, env=env, cwd=str(ROOT))
+
+
+def test_self_launch_two_ranks_reaches_the_process_group():
+    out = _bench("--gpus", "2", "--launch-check")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1  # only rank 0 reports
+    rec = json.loads(lines[0])
+    assert rec == {"launch_check": "ok", "world": 2, "rank_sum": 1.0}
+
+
+def test_external_launcher_world_size_mismatch_is_refused():
+    out = _bench("--gpus", "2", "--launch-check", env_extra={"WORLD_SIZE": "3", "RANK": "0"})
+    assert out.returncode != 0 and "WORLD_SIZE=3" in (out.stderr + out.stdout)
+
+
+def test_single_gpu_without_a_gpu_fails_loudly():
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    out = _bench("--steps", "1", "--warmup", "0")
+    assert out.returncode != 0 and "needs a GPU" in (out.stderr + out.stdout)

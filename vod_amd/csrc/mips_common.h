@@ -1,0 +1,140 @@
+// Device helpers shared by the MIPS kernels (kernels_mips.hip): result-key packing, LDS-DMA, counted waits,
+// MFMA wrappers, the subset predicate and the direct (global-atomic) survivor append.
+#pragma once
+#include "vodhip_internal.h"
+
+namespace vodhip {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define VOD_AS1 __attribute__((address_space(1)))
+#define VOD_AS3 __attribute__((address_space(3)))
+
+// ---- key packing --------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int flip_f32(float s) {
+    unsigned int u = __float_as_uint(s + 0.0f);  // -0.0 -> +0.0 so that equal floats get equal keys
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unflip_f32(unsigned int u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ key_t64 make_key(float s, unsigned int local_row) {
+    return ((key_t64)flip_f32(s) << 32) | (key_t64)(0xFFFFFFFFu - local_row);
+}
+
+template <int DT>
+__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (DT == 0) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+}
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (DT == 0) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+}
+
+// 16 bytes per lane HBM/L2 -> LDS without a VGPR round trip; the LDS address is wave-uniform base + lane * 16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const VOD_AS1 void*)gsrc, (VOD_AS3 void*)lds_dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    // counted wait: all but the N youngest vector-memory operations of this wave are complete
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else static_assert(N == 0, "add the literal");
+}
+
+// Subset filter (the `subset_ids` of the reference's SearchClient.search, honoured by its Elasticsearch / Qdrant engines,
+// src/vod_search/es_search/client.py:185-191, qdrant_search/client.py:124-136, and ignored by its faiss client,
+// faiss_search/client.py:67-72): a row is eligible for query q when q lists no label or lists the row's label.
+__device__ __forceinline__ bool subset_allows(const FilterExtra& ex, int q, int row) {
+    if (ex.row_label == nullptr) return true;
+    const int lab = ex.row_label[row];
+    bool any = false, ok = false;
+#pragma unroll 1
+    for (int s = 0; s < ex.n_qlab; ++s) {
+        const int ql = ex.q_label[(size_t)q * ex.n_qlab + s];
+        any |= ql != -1;  // -1 = empty slot; any other value (incl. an unknown id mapped to -2) restricts the query
+        ok |= ql == lab;
+    }
+    return ok || !any;
+}
+
+// one survivor -> the query's global candidate list (exact-key test against the running k-th best, subset test)
+template <bool SUBSET>
+__device__ __forceinline__ void emit_candidate(key_t64 key, int q, const key_t64* __restrict__ thr_key,
+                                               key_t64* __restrict__ cand, unsigned int* __restrict__ cnt, int cap,
+                                               unsigned int* __restrict__ overflow, const FilterExtra& ex) {
+    bool ok = key > thr_key[q];
+    if constexpr (SUBSET) ok = ok && subset_allows(ex, q, (int)(0xFFFFFFFFu - (unsigned)key));
+    if (ok) {
+        const unsigned slot = atomicAdd(&cnt[q], 1u);
+        if (slot < (unsigned)cap)
+            cand[(size_t)q * cap + slot] = key;
+        else
+            atomicOr(overflow, 1u);
+    }
+}
+
+// Append the survivors among NV scores of ONE query held by this lane: count first, reserve the slots with ONE
+// returning atomic, then write the keys (a chain of per-hit atomics costs a memory round trip each).
+// val(i) / row(i) must be compile-time indexable.
+template <int NV, bool SUBSET, typename ValFn, typename RowFn>
+__device__ __forceinline__ void append_survivors(float thr, int q, int row_end, ValFn val, RowFn row,
+                                                 const key_t64* __restrict__ thr_key, key_t64* __restrict__ cand,
+                                                 unsigned int* __restrict__ cnt, int cap, unsigned int* __restrict__ overflow,
+                                                 const FilterExtra& ex) {
+    const key_t64 tk = thr_key[q];
+    // opaque zero added to every row index: without it the compiler hoists the NV row keys and row-bound compares
+    // (the same for every query block of the caller) out of this cold path into the caller's per-tile fast path
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    static_assert(NV <= 32, "survivor mask is 32 bits");
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float sc = val(i);
+        const int rw = (row(i) + z);
+        mask |= (sc >= thr && rw < row_end && make_key(sc, (unsigned)rw) > tk) ? (1u << i) : 0u;
+    }
+    if constexpr (SUBSET) {  // rolled loop over the threshold survivors (this instantiation only runs with row labels set)
+        unsigned m2 = mask;
+        while (m2) {
+            const int i = __builtin_ctz(m2);
+            m2 &= m2 - 1;
+            if (!subset_allows(ex, q, (row(i) + z))) mask &= ~(1u << i);
+        }
+    }
+    if (mask == 0) return;
+    unsigned slot = atomicAdd(&cnt[q], (unsigned)__builtin_popcount(mask));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (mask & (1u << i)) {
+            if (slot < (unsigned)cap)
+                cand[(size_t)q * cap + slot] = make_key(val(i), (unsigned)(row(i) + z));
+            else
+                atomicOr(overflow, 1u);
+            ++slot;
+        }
+    }
+}
+
+}  // namespace vodhip

@@ -77,12 +77,12 @@ struct vodhip_index {
     std::deque<PendingSearch> inflight;     // oldest first
     int next_slot = 0;
     // tunables
-    int64_t cand_cap = 4096;
-    int64_t dense_rows = 1024;
-    int64_t growth_x100 = 0;  // 0 = derive from k
+    int64_t cand_cap = 8192;
+    int64_t dense_rows = 2048;   // indexes up to this many rows are scored densely in one launch
+    int64_t growth_x100 = 0;     // FILTER stage = growth x the rows its threshold was calibrated on; 0 = 8
+    int64_t sample_div = 48;     // GMAX bootstrap scores ~ ntotal / sample_div sampled rows
     int64_t force_safe = 0;
     int64_t tile = 0;
-    int64_t krot = 0;
     int64_t small_chunk_tiles = 1024;  // launches with fewer 256x256 tiles than this use the 128x128 kernel
     int64_t profile = 0;  // 1: bracket every filter launch with HIP events (bench / roofline accounting)
     // stats
@@ -127,77 +127,126 @@ int ensure_workspace(vodhip_index* ix, int64_t nq_pad, int64_t cap, int64_t kp) 
     return 0;
 }
 
-// chunk schedule: [0, c0) scored densely (every score becomes a candidate: the threshold is still
-// -inf), then geometrically growing chunks filtered against the threshold of everything before them.
-void make_schedule(int64_t n, int64_t dense_rows, double growth, bool safe, int64_t cap,
-                   std::vector<std::pair<int64_t, int64_t>>& chunks, std::vector<bool>& dense) {
-    chunks.clear();
-    dense.clear();
+// ---- stage schedule ------------------------------------------------------------------------------------------
+// A search is a list of stages, each one filter launch + one select launch:
+//   GMAX    threshold bootstrap.  S sampled rows (8-row groups spread evenly over the whole store) are scored and every
+//           lane writes the maximum of its group of 16 / 32 rows; the k-th largest group maximum is a lower bound of the
+//           k-th best score (k distinct rows reach it) however the rows are ordered.  Emits no candidates.
+//   FILTER  rows [b, e) filtered against the running threshold; survivors -> candidate lists -> running top-k.
+//           Stage i covers `growth` x the rows the threshold was calibrated on, so it emits ~ growth * k survivors per
+//           query for exchangeable row order, and never more than the GMAX bound allows (~ k * rows / S) for any order.
+//   DENSE   every score of <= cap rows becomes a candidate (indexes of a few thousand rows; the exhaustive fallback).
+enum : int { ST_FILTER = 0, ST_DENSE = 1, ST_GMAX = 2 };
+struct Stage {
+    int kind;
+    int64_t b, e;        // rows (FILTER / DENSE)
+    int64_t n_tiles;     // sampled tiles (GMAX)
+    int64_t rstride;     // store rows between consecutive sampled rows (GMAX)
+    int64_t n_groups;    // lane groups of the sample = candidate slots per query (GMAX)
+};
+
+void make_safe_schedule(int64_t n, int64_t cap, std::vector<Stage>& st) {
+    const int64_t step = std::max<int64_t>(ROW_ALIGN, cap / ROW_ALIGN * ROW_ALIGN);
+    for (int64_t b = 0; b < n; b += step) st.push_back({ST_DENSE, b, std::min(n, b + step), 0, 0, 0});
+}
+
+// `recovery` > 0: pass number after a candidate-list overflow - no bootstrap (the thresholds are seeded from the previous
+// result), 2^(recovery-1) equal FILTER stages, and the exhaustive schedule once a stage would be <= cap rows.
+void make_schedule(const vodhip_index* ix, int k, int gmax_tile, bool safe, int recovery, std::vector<Stage>& st) {
+    st.clear();
+    const int64_t n = ix->ntotal, cap = ix->cand_cap;
     if (n <= 0) return;
-    if (safe) {
-        const int64_t step = std::max<int64_t>(ROW_ALIGN, cap / ROW_ALIGN * ROW_ALIGN);
-        for (int64_t b = 0; b < n; b += step) {
-            chunks.emplace_back(b, std::min(n, b + step));
-            dense.push_back(true);
-        }
+    int64_t dense_limit = std::max(ix->dense_rows, round_up(k, ROW_ALIGN));
+    dense_limit = std::min(dense_limit, cap / ROW_ALIGN * ROW_ALIGN);
+    if (safe || n <= dense_limit) return make_safe_schedule(n, cap, st);
+    if (recovery > 0) {
+        const int64_t n_st = 1ll << std::min(recovery - 1, 30);
+        const int64_t rows = round_up((n + n_st - 1) / n_st, ROW_ALIGN);
+        if (rows <= cap) return make_safe_schedule(n, cap, st);
+        for (int64_t b = 0; b < n; b += rows) st.push_back({ST_FILTER, b, std::min(n, b + rows), 0, 0, 0});
         return;
     }
-    int64_t b = std::min(n, dense_rows);
-    chunks.emplace_back(0, b);
-    dense.push_back(true);
+    const int64_t bm = filter_tile_rows(gmax_tile), rg = filter_group_rows(gmax_tile);
+    // at least 4k groups: the k-th largest of G group maxima is exceeded by a fraction -ln(1 - k/G) / rg of the rows,
+    // which is ~ 1.15 k/S at G = 4k and blows up as G approaches k
+    const int64_t s_min = round_up(std::max<int64_t>(4 * rg * (int64_t)k, 2048), bm);
+    const int64_t s_max = std::min(rg * cap, n / 2) / bm * bm;
+    if (s_max < s_min) return make_safe_schedule(n, cap, st);  // too few rows for k group maxima: short, all dense
+    const int64_t s = std::min(s_max, std::max(s_min, round_up(n / std::max<int64_t>(ix->sample_div, 2), bm)));
+    // S sampled rows at stride (n-1)/(S-1): the last one is row (S-1)*rstride <= n-1, all distinct (S <= n/2)
+    st.push_back({ST_GMAX, 0, 0, s / bm, (n - 1) / (s - 1), s / rg});
+    const double growth = std::min(256.0, std::max(1.25, ix->growth_x100 > 0 ? ix->growth_x100 / 100.0 : 8.0));
+    // however the rows are ordered, rows [b, e) hold about k * (e - b) / S scores above the bootstrap bound (the sample is
+    // stratified over the whole store): a stage never covers more rows than the candidate lists can take with 60 % headroom
+    const int64_t rows_safe = std::max<int64_t>(ROW_ALIGN, (int64_t)((double)cap * (double)s / (1.6 * (double)k)) / ROW_ALIGN * ROW_ALIGN);
+    int64_t b = 0, calibrated = s;
     while (b < n) {
-        int64_t e = (int64_t)((double)b * growth);
-        e = std::max(e, b + ROW_ALIGN);
-        e = round_up(e, ROW_ALIGN);
-        e = std::min(e, n);
-        chunks.emplace_back(b, e);
-        dense.push_back(false);
+        const int64_t rows = std::min(rows_safe, round_up((int64_t)((double)calibrated * growth), ROW_ALIGN));
+        int64_t e = std::min(n, b + rows);
+        if (n - e < rows / 4 && n - b <= rows_safe) e = n;  // no short tail stage
+        st.push_back({ST_FILTER, b, e, 0, 0, 0});
         b = e;
+        calibrated = e;
     }
 }
 
-int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStream_t stream) {
+int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, int recovery, hipStream_t stream) {
     const int k = ps.k;
     int64_t kp = 64;
     while (kp < k) kp <<= 1;
     const int64_t cap = ix->cand_cap;
-    int64_t dense_rows = std::max(ix->dense_rows, round_up(k, ROW_ALIGN));
-    dense_rows = std::min(dense_rows, cap / ROW_ALIGN * ROW_ALIGN);
-    if (dense_rows < k) return fail("cand_cap=%lld is too small for k=%d", (long long)cap, k);
-    double growth = ix->growth_x100 > 0 ? ix->growth_x100 / 100.0 : 1.0 + (double)cap / (4.0 * k);
-    growth = std::min(8.0, std::max(1.25, growth));
+    if (cap / ROW_ALIGN * ROW_ALIGN < k) return fail("cand_cap=%lld is too small for k=%d", (long long)cap, k);
 
-    std::vector<std::pair<int64_t, int64_t>> chunks;
-    std::vector<bool> dense;
-    make_schedule(ix->ntotal, dense_rows, growth, safe, cap, chunks, dense);
-    ix->last_chunks = (int64_t)chunks.size();
-
-    const int q_es = elem_size(ps.q_dtype);
     int tile = (int)ix->tile;
-    const bool tile_auto = tile == 0;
     // auto: up to 128 queries the search is HBM-bound: 256 corpus rows x 64 / 128 queries per workgroup on a 3-slot LDS
     // ring (few query bytes per corpus byte through the LDS-DMA path); above, the persistent 256x256 tile on
-    // v_mfma_f32_16x16x32, with the corpus operand fetched two slices ahead (3 + 2 LDS slots) when ONE q-tile makes
-    // every corpus read an HBM miss
-    if (tile == 0) {
-        tile = ps.nq > 256 ? 9 : (ps.nq > 128 ? 10 : (ps.nq > 64 ? 46 : 42));
-    }
+    // v_mfma_f32_16x16x32 with the two waves of every SIMD staggered by one k-step
+    if (tile == 0) tile = ps.nq > 128 ? 9 : (ps.nq > 64 ? 46 : 42);
+    const bool persistent = tile == 8 || tile == 9;
     const int64_t bn = filter_tile_cols(tile);
+
+    std::vector<Stage> stages;
+    make_schedule(ix, k, tile, safe, recovery, stages);
+    ix->last_chunks = (int64_t)stages.size();
+
+    const int q_es = elem_size(ps.q_dtype);
     if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
-    ix->ws.extra.flags = (int)ix->krot;  // bit 0: K rotation; bit 1 (ablation builds): no survivors
-    ix->ws.extra.row_label = (ix->row_label && ix->q_label) ? ix->row_label : nullptr;
-    ix->ws.extra.q_label = ps.q_label;
+    ix->ws.extra.flags = 0;
+    // the subset labels in force when THIS search was enqueued (a recovery pass may run after younger searches changed them)
+    ix->ws.extra.row_label = (ix->row_label && ps.q_label) ? ix->row_label : nullptr;
     ix->ws.extra.n_qlab = ps.n_qlab;
+    const bool subset = ix->ws.extra.row_label != nullptr;
+    if (subset && !safe && recovery == 0) {
+        // group maxima would include ineligible rows: a subset search runs the exhaustive-free geometric schedule instead
+        // (dense head of <= cap rows, then FILTER stages growing by `growth`)
+        stages.clear();
+        const int64_t n = ix->ntotal;
+        int64_t b = std::min(n, std::max<int64_t>(ROW_ALIGN, std::min<int64_t>(cap, 2048) / ROW_ALIGN * ROW_ALIGN));
+        if (b >= k || b == n) {
+            stages.push_back({ST_DENSE, 0, b, 0, 0, 0});
+            const double growth = std::min(8.0, std::max(1.25, 1.0 + (double)cap / (4.0 * k)));
+            while (b < n) {
+                int64_t e = std::min(n, round_up(std::max((int64_t)((double)b * growth), b + ROW_ALIGN), ROW_ALIGN));
+                stages.push_back({ST_FILTER, b, e, 0, 0, 0});
+                b = e;
+            }
+        } else {
+            make_safe_schedule(n, cap, stages);
+        }
+        ix->last_chunks = (int64_t)stages.size();
+    }
     const SearchWorkspace& ws = ix->ws;
     for (int64_t qb = 0; qb < ps.nq; qb += MAX_NQ_PER_PASS) {
         const int64_t nq = std::min(MAX_NQ_PER_PASS, ps.nq - qb);
         const int64_t nq_pad = round_up(nq, bn);
-        // one launch: queries -> store dtype with zero padded rows / columns, running top-k, counters and thresholds
-        // cleared, overflow word cleared at the first pass
+        // one launch: queries -> store dtype with zero padded rows / columns, running top-k and counters cleared,
+        // thresholds -inf (or seeded from the previous result in a recovery pass), overflow word cleared at the first pass
         HIP_OK(launch_search_prepare(ws, (const char*)ps.queries + (size_t)qb * ix->dim * q_es, ps.q_dtype, nq, ix->dim,
-                                     ix->dtype, nq_pad, ix->dim_pad, qb == 0, stream));
+                                     ix->dtype, nq_pad, ix->dim_pad, qb == 0, recovery > 0 ? ps.out_scores + qb * k : nullptr,
+                                     recovery > 0 ? ps.out_ids + qb * k : nullptr, k, stream));
         ix->ws.extra.q_label = ps.q_label ? ps.q_label + (size_t)qb * ps.n_qlab : nullptr;
-        for (size_t c = 0; c < chunks.size(); ++c) {
+        for (size_t c = 0; c < stages.size(); ++c) {
+            const Stage& sg = stages[c];
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             if (ix->profile) {
                 while (ix->ev_pool.size() < ix->ev_used + 2) {
@@ -209,25 +258,40 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, hipStre
                 ev1 = ix->ev_pool[ix->ev_used++];
                 HIP_OK(hipEventRecord(ev0, stream));
             }
-            // short warm-up chunks do not fill 256 CUs with 256x256 tiles (a few tiles per workgroup at most, and their
-            // epilogues are heavy with survivors): run those launches on 128x128 tiles, 2 workgroups per CU
+            // short FILTER stages do not fill 256 CUs with 256x256 tiles: those launches run on 128x128 tiles, 2 workgroups per CU
             int tile_c = tile;
-            if (tile_auto && (tile == 9 || tile == 10)) {  // (nq_pad is a multiple of 256 there, which the 128-wide tile divides)
-                const int64_t tiles256 = ((chunks[c].second - chunks[c].first + 255) / 256) * (nq_pad / 256);
+            if (persistent && ix->tile == 0 && sg.kind == ST_FILTER) {  // (nq_pad is a multiple of 256 there, which the 128-wide tile divides)
+                const int64_t tiles256 = ((sg.e - sg.b + 255) / 256) * (nq_pad / 256);
                 if (tiles256 < ix->small_chunk_tiles) tile_c = 1;
             }
-            HIP_OK(launch_filter(ix->dtype, tile_c, dense[c], ix->data, ws.q_pad, ix->dim_pad, chunks[c].first,
-                                 chunks[c].second, nq, nq_pad, ws, stream));
+            ix->ws.extra.sample_rstride = (int)sg.rstride;
+            ix->ws.extra.sample_groups = (int)sg.n_groups;
+            const bool last = c + 1 == stages.size();
+            HIP_OK(launch_filter(ix->dtype, tile_c, sg.kind, ix->data, ws.q_pad, ix->dim_pad, sg.b, sg.e, sg.n_tiles, nq, nq_pad,
+                                 ws, stream));
             if (ix->profile) HIP_OK(hipEventRecord(ev1, stream));
-            HIP_OK(launch_select(ws, nq, k, dense[c] ? chunks[c].second - chunks[c].first : -1, c + 1 == chunks.size(), stream,
-                                 ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k));
+            int64_t dense_n = -1;
+            int flags = last ? 1 : 0;
+            if (sg.kind == ST_DENSE) dense_n = sg.e - sg.b;
+            if (sg.kind == ST_GMAX) {
+                dense_n = sg.n_groups;
+                flags |= 2;
+            }
+            HIP_OK(launch_select(ws, nq, k, dense_n, flags, stream, ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k));
         }
-        if (chunks.empty())  // empty index: nothing was selected, the cleared top-k leaves as pads
+        if (stages.empty())  // empty index: nothing was selected, the cleared top-k leaves as pads
             HIP_OK(launch_output(ws, nq, k, ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k, stream));
     }
     HIP_OK(hipMemcpyAsync(ix->overflow_host + ps.slot, ws.overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipEventRecord(ix->done[ps.slot], stream));
     return 0;
+}
+
+int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, int recovery, hipStream_t stream) {
+    const int rc = enqueue_search_impl(ix, ps, safe, recovery, stream);
+    // on failure some kernels of this search may already run on buffers the caller is about to release
+    if (rc) (void)hipStreamSynchronize(stream);
+    return rc;
 }
 
 }  // namespace
@@ -414,7 +478,7 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
     ps.slot = ix->next_slot;
     if (ix->inflight.empty()) ix->ev_used = 0;  // profile events are recycled once nothing refers to them
     ps.ev_begin = ix->ev_used;
-    if (nq > 0 && enqueue_search(ix, ps, ix->force_safe != 0, (hipStream_t)stream_)) return -1;
+    if (nq > 0 && enqueue_search(ix, ps, ix->force_safe != 0, 0, (hipStream_t)stream_)) return -1;
     ps.ev_end = ix->ev_used;
     ix->next_slot = (ix->next_slot + 1) % MAX_IN_FLIGHT;
     ix->inflight.push_back(ps);
@@ -432,16 +496,18 @@ int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
     ix->last_safe_reruns = 0;
     if (ps.nq > 0) {
         HIP_OK(hipEventSynchronize(ix->done[ps.slot]));  // this search only: younger ones keep the device busy
-        if (ix->overflow_host[ps.slot]) {
-            // A candidate list overflowed (scores that keep rising along the row order defeat the
-            // geometric schedule).  Redo the batch with the exhaustive schedule, which cannot overflow.
+        // A candidate list overflowed: the result is valid (real rows, real scores) but may miss hits.  Recovery
+        // passes re-scan the store against thresholds seeded from that result - its k-th score is a lower bound of the
+        // true k-th best, so few rows survive - in 1, 2, 4, ... FILTER stages, and in the exhaustive schedule (dense
+        // chunks of <= cap rows, cannot overflow) once the stages are that short.
+        for (int pass = 1; ix->overflow_host[ps.slot]; ++pass) {
+            if (pass > 40) return fail("internal error: the exhaustive schedule overflowed");
             ix->last_overflow = 1;
-            ix->last_safe_reruns = 1;
+            ix->last_safe_reruns = pass;
             const size_t ev_keep = ix->ev_used;
-            if (enqueue_search(ix, ps, true, stream)) return -1;
-            ix->ev_used = ev_keep;  // the re-run is not part of the launch accounting
+            if (enqueue_search(ix, ps, false, pass, stream)) return -1;
+            ix->ev_used = ev_keep;  // recovery passes are not part of the launch accounting
             HIP_OK(hipStreamSynchronize(stream));
-            if (ix->overflow_host[ps.slot]) return fail("internal error: exhaustive schedule overflowed");
         }
     }
     ix->last_filter_launches = (int64_t)((ps.ev_end - ps.ev_begin) / 2);
@@ -474,12 +540,14 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
         ix->force_safe = value;
     } else if (!strcmp(key, "small_chunk_tiles")) {
         ix->small_chunk_tiles = value;
-    } else if (!strcmp(key, "krot")) {
-        ix->krot = value;
+    } else if (!strcmp(key, "sample_div")) {
+        if (value < 2) return fail("sample_div must be >= 2");
+        ix->sample_div = value;
     } else if (!strcmp(key, "profile")) {
         ix->profile = value;
     } else if (!strcmp(key, "tile")) {
-        if (value < 0 || value > 46) return fail("tile must be 0 (auto) or a filter-kernel variant id (DESIGN.md 4.1)");
+        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 42 && value != 46)
+            return fail("tile must be 0 (auto) or a filter-kernel variant id: 1, 8, 9, 42, 46 (DESIGN.md 4.1)");
         ix->tile = value;
     } else {
         return fail("unknown parameter '%s'", key);
@@ -503,6 +571,8 @@ int vodhip_index_get_stat(const vodhip_index_t* ix, const char* key, int64_t* ou
         *out = ix->cand_cap;
     else if (!strcmp(key, "dense_rows"))
         *out = ix->dense_rows;
+    else if (!strcmp(key, "sample_div"))
+        *out = ix->sample_div;
     else if (!strcmp(key, "dim_pad"))
         *out = ix->dim_pad;
     else

@@ -16,6 +16,8 @@ struct FilterExtra {
     const int* row_label = nullptr;   // [ntotal] subset label of every stored row, or NULL (no subset filtering)
     const int* q_label = nullptr;     // [nq, n_qlab] allowed labels per query (-1 = empty slot; all -1 = unrestricted)
     int n_qlab = 0;
+    int sample_rstride = 0;           // GMAX launches: store rows between consecutive sampled rows (>= 1)
+    int sample_groups = 0;            // GMAX launches: number of lane groups of the sample (= candidate slots per query)
 };
 
 struct SearchWorkspace {
@@ -33,16 +35,21 @@ struct SearchWorkspace {
 };
 
 // ---- launchers (kernels_mips.hip) -------------------------------------------------------------
-// store_dtype: 0 = f16, 1 = bf16.  tile: 1 = 128x128 (256 threads), 2 = 256x256 (512 threads).
+// store_dtype: 0 = f16, 1 = bf16.  tile: filter-kernel variant (kernels_mips.hip: 1, 42, 46 generic; 8, 9 persistent).
+// mode: 0 = FILTER (threshold survivors -> candidate lists), 1 = DENSE (every score of rows [row_begin, row_end) is a
+// candidate), 2 = GMAX (threshold bootstrap: group maxima of `n_sample_tiles` sampled tiles, see FilterExtra::sample_rstride).
 hipError_t launch_convert_rows(const void* src, int src_dtype, int64_t n_rows, int64_t dim, void* dst, int dst_dtype,
                                int64_t dst_stride, hipStream_t stream);
+// seed_scores / seed_ids ([nq, k] device, or NULL): a previous valid-but-incomplete result whose k-th score seeds the thresholds
 hipError_t launch_search_prepare(const SearchWorkspace& ws, const void* q_src, int q_dtype, int64_t nq, int64_t dim,
-                                 int store_dtype, int64_t nq_pad, int64_t dim_pad, bool clear_overflow, hipStream_t stream);
-hipError_t launch_filter(int store_dtype, int tile, bool dense, const void* store, const void* q_pad, int64_t dim_pad,
-                         int64_t row_begin, int64_t row_end, int64_t nq, int64_t nq_pad, const SearchWorkspace& ws,
-                         hipStream_t stream);
-// with `final_sort` the sorted top-k also leaves as float32 scores / int64 ids (+ id_base) in out_scores / out_ids [nq, k]
-hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, bool final_sort, hipStream_t stream,
+                                 int store_dtype, int64_t nq_pad, int64_t dim_pad, bool clear_overflow,
+                                 const float* seed_scores, const int64_t* seed_ids, int k, hipStream_t stream);
+hipError_t launch_filter(int store_dtype, int tile, int mode, const void* store, const void* q_pad, int64_t dim_pad,
+                         int64_t row_begin, int64_t row_end, int64_t n_sample_tiles, int64_t nq, int64_t nq_pad,
+                         const SearchWorkspace& ws, hipStream_t stream);
+// flags: 1 = final (sort; the top-k also leaves as float32 scores / int64 ids (+ id_base) in out_scores / out_ids [nq, k]),
+//        2 = threshold only (the candidates are GMAX group maxima: nothing enters the running top-k)
+hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, int flags, hipStream_t stream,
                          int64_t id_base = 0, float* out_scores = nullptr, int64_t* out_ids = nullptr);
 hipError_t launch_output(const SearchWorkspace& ws, int64_t nq, int k, int64_t id_base, float* out_scores,
                          int64_t* out_ids, hipStream_t stream);
@@ -50,6 +57,7 @@ hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int64_t st
                              int64_t nq, int k, int k_out, float* out_scores, int64_t* out_ids, hipStream_t stream);
 int filter_tile_rows(int tile);  // BM of the tile config
 int filter_tile_cols(int tile);  // BN of the tile config
+int filter_group_rows(int tile); // rows per GMAX group (one lane's rows of one column block)
 
 // ---- launchers (kernels_hybrid.hip) -----------------------------------------------------------
 struct HybridArgs {

@@ -197,18 +197,20 @@ class HipFlatIndex:
             ids = torch.empty((nq, k), dtype=torch.int64, device=self.device)
         else:
             scores, ids = out
-        self._keep.append((q, self._keep_subset, scores, ids))  # buffers of this search stay alive until its finish()
         _native.check(
             self._lib.vodhip_index_search_async(
                 self._h, q.data_ptr(), _native.torch_dtype_code(q.dtype), nq, int(k), int(id_base),
                 scores.data_ptr(), ids.data_ptr(), _native.current_stream_ptr(self.device),
             )
         )
+        # only a search the library accepted is tracked (a refused one synchronised the stream before returning);
+        # its buffers stay alive until its finish()
+        self._keep.append((q, self._keep_subset, scores, ids))
         return scores, ids
 
     def finish(self) -> None:
-        """Complete the OLDEST enqueued search (up to 4 may be in flight): waits for it alone, re-runs it in the
-        exhaustive schedule if a candidate list overflowed.  Pipelined searches need their own `out` buffers if their
+        """Complete the OLDEST enqueued search (up to 4 may be in flight): waits for it alone and, if a candidate list
+        overflowed, runs recovery passes seeded from its incomplete result.  Pipelined searches need their own `out` buffers if their
         results are read after younger searches were enqueued."""
         _native.check(self._lib.vodhip_index_search_finish(self._h, _native.current_stream_ptr(self.device)))
         if self._keep:
