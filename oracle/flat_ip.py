@@ -29,6 +29,9 @@ from __future__ import annotations
 import numpy as np
 
 
+_NAN_ID = np.int64(1) << 62
+
+
 def flat_ip_scores(q: np.ndarray, x: np.ndarray) -> np.ndarray:
     """Full score matrix in float64 (small cases only)."""
     return np.asarray(q, dtype=np.float64) @ np.asarray(x, dtype=np.float64).T
@@ -71,7 +74,11 @@ def flat_ip_topk(q: np.ndarray, x: np.ndarray, k: int, block: int = 65536, id_ba
         ids = np.broadcast_to(np.arange(lo, hi, dtype=np.int64), s.shape)
         cs = np.concatenate([best_s, s], axis=1)
         ci = np.concatenate([best_i, ids], axis=1)
-        cs = np.where(np.isnan(cs), -np.inf, cs)
+        # a NaN score never enters the result (faiss: comparisons are false): it sinks below every real row, -inf ones
+        # included (sentinel id above every row id), and leaves as a pad
+        nan = np.isnan(cs)
+        ci = np.where(nan, _NAN_ID, ci)
+        cs = np.where(nan, -np.inf, cs)
         keep = min(k, cs.shape[1])
         new_s = np.empty((nq, keep), dtype=np.float64)
         new_i = np.empty((nq, keep), dtype=np.int64)
@@ -84,7 +91,7 @@ def flat_ip_topk(q: np.ndarray, x: np.ndarray, k: int, block: int = 65536, id_ba
     out_i = np.full((nq, k), -1, dtype=np.int64)
     kk = best_s.shape[1]
     out_s[:, :kk] = best_s.astype(np.float32)
-    out_i[:, :kk] = np.where(np.isneginf(best_s) & (best_i < 0), -1, best_i + id_base)
+    out_i[:, :kk] = np.where(best_i == _NAN_ID, -1, best_i + id_base)
     return out_s, out_i
 
 

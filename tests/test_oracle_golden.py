@@ -185,3 +185,54 @@ def test_cpu_baseline_port_is_an_exact_topk():
     s, i = flat_ip_topk_cpu(torch.from_numpy(q[:1]), torch.from_numpy(xs), 10, block=2048)
     rs, ri = flat_ip_topk(q[:1], xs, 10)
     assert np.array_equal(i.numpy(), ri)
+
+
+# ---- the second, independent restatement of IndexFlatIP (plain C, fp32 accumulation + bounded heap: the arithmetic the
+# ---- faiss CPU path uses) must agree with the NumPy fp64 oracle and with the committed flat_ip_exact_* outputs ----------
+
+
+def _c_oracle():
+    import ctypes
+
+    from vod_amd.build import build_oracle
+
+    lib = ctypes.CDLL(str(build_oracle()))
+    lib.oracle_flat_ip_f32.restype = ctypes.c_int
+    lib.oracle_flat_ip_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int64] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
+
+    def run(q, x, k, id_base=0):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        s = np.empty((len(q), k), dtype=np.float32)
+        i = np.empty((len(q), k), dtype=np.int64)
+        rc = lib.oracle_flat_ip_f32(q.ctypes.data, x.ctypes.data, len(q), len(x), q.shape[1], k, id_base, s.ctypes.data, i.ctypes.data)
+        assert rc == 0
+        return s, i
+
+    return run
+
+
+@pytest.mark.parametrize("name", ["flat_ip_exact_small", "flat_ip_exact_768"])
+def test_c_restatement_reproduces_the_flat_ip_fixtures(name):
+    p = MANIFEST[name]["params"]
+    g = _load(name)
+    rng = np.random.default_rng(p["seed"])
+    x = rng.integers(-8, 9, size=(p["n"], p["d"])).astype(np.float16)
+    q = rng.integers(-8, 9, size=(p["nq"], p["d"])).astype(np.float16)
+    s, i = _c_oracle()(q, x, p["k"])
+    _eq(i, g["out_ids"])
+    _eq(s, g["out_scores"])
+
+
+@pytest.mark.parametrize("n,d,nq,k,id_base", [(1, 8, 2, 3, 0), (257, 72, 9, 16, 1000), (5000, 64, 33, 100, 0), (300, 32, 5, 400, 7)])
+def test_c_restatement_agrees_with_the_numpy_oracle(n, d, nq, k, id_base):
+    """Integer-valued data (exact in fp32 and fp64, tie-heavy): the fp32 + heap restatement and the fp64 + lexsort one are
+    two independent routes to the same (score desc, id asc) answer, pads included."""
+    rng = np.random.default_rng(n + d)
+    x = rng.integers(-4, 5, size=(n, d)).astype(np.float32)
+    q = rng.integers(-4, 5, size=(nq, d)).astype(np.float32)
+    x[n // 2, 0] = np.nan  # a NaN score never enters either restatement
+    s, i = _c_oracle()(q, x, k, id_base)
+    rs, ri = flat_ip_topk(q, x, k, id_base=id_base)
+    _eq(i, ri)
+    _eq(s, rs)

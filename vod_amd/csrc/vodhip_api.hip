@@ -200,8 +200,8 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
     int tile = (int)ix->tile;
     // auto: up to 128 queries the search is HBM-bound: 256 corpus rows x 64 / 128 queries per workgroup on a 3-slot LDS
     // ring (few query bytes per corpus byte through the LDS-DMA path); above, the persistent 256x256 tile on
-    // v_mfma_f32_16x16x32 with the two waves of every SIMD staggered by one k-step
-    if (tile == 0) tile = ps.nq > 128 ? 9 : (ps.nq > 64 ? 46 : 42);
+    // v_mfma_f32_16x16x32 (8; variant 9 staggers the two waves of every SIMD by one k-step: measured equal or 1-2 % slower)
+    if (tile == 0) tile = ps.nq > 128 ? 8 : (ps.nq > 64 ? 46 : 42);
     const bool persistent = tile == 8 || tile == 9;
     const int64_t bn = filter_tile_cols(tile);
 

@@ -63,10 +63,13 @@ class MicroBatcher:
     (a top-k prefix of a top-k' list is the top-k, so results are identical to separate searches).
     """
 
-    def __init__(self, engine, max_wait_s: float = 0.001, max_queries: int = 2048):
+    def __init__(self, engine, max_wait_s: float = 0.001, max_queries: int = 2048, lock: "threading.Lock | None" = None):
         import queue
 
         self.engine = engine
+        # the engine (one index handle, one stream, shared workspace) is not re-entrant: every call into it - the fused
+        # batches here and the subset / serialised searches of `create_app` - runs under ONE lock
+        self.lock = lock or threading.Lock()
         self.max_wait_s = max_wait_s
         self.max_queries = max_queries
         self._q: "queue.Queue" = queue.Queue()
@@ -104,7 +107,8 @@ class MicroBatcher:
                     raise ValueError(f"queries of different dimensions in one batch: {sorted(dims)}")
                 k_max = max(b[1] for b in batch)
                 fused = np.concatenate([np.asarray(b[0], dtype=np.float32) for b in batch], axis=0)
-                scores, indices = self.engine.search(fused, k_max)
+                with self.lock:
+                    scores, indices = self.engine.search(fused, k_max)
                 lo = 0
                 for vec, k, fut in batch:
                     hi = lo + len(vec)
@@ -122,7 +126,7 @@ def create_app(engine, micro_batch_wait_ms: float = 0.0) -> FastAPI:
     `micro_batch_wait_ms > 0`, fused into shared GPU batches by `MicroBatcher`."""
     app = FastAPI()
     lock = threading.Lock()
-    batcher = MicroBatcher(engine, max_wait_s=micro_batch_wait_ms / 1e3) if micro_batch_wait_ms > 0 else None
+    batcher = MicroBatcher(engine, max_wait_s=micro_batch_wait_ms / 1e3, lock=lock) if micro_batch_wait_ms > 0 else None
 
     def _search(query_vec: np.ndarray, top_k: int, subset_ids=None) -> tuple[np.ndarray, np.ndarray]:
         if query_vec.ndim != 2:
@@ -181,8 +185,11 @@ def create_app(engine, micro_batch_wait_ms: float = 0.0) -> FastAPI:
             import io as _io
 
             body = await request.body()
-            query_vec = np.load(_io.BytesIO(body), allow_pickle=False)
-            scores, indices = _search(query_vec, top_k)
+
+            def _decode_and_search():  # off the event loop: other requests are accepted (and fused) meanwhile
+                return _search(np.load(_io.BytesIO(body), allow_pickle=False), top_k)
+
+            scores, indices = await run_in_threadpool(_decode_and_search)
             payload = np.ascontiguousarray(scores).tobytes() + np.ascontiguousarray(indices).tobytes()
             return Response(content=payload, media_type="application/octet-stream",
                             headers={"x-nq": str(scores.shape[0]), "x-k": str(scores.shape[1])})
