@@ -70,3 +70,75 @@ def test_shard_bounds_are_contiguous_and_aligned():
     assert [b[i + 1] - b[i] for i in range(8)] == [1_250_000] * 8
     b = shard_bounds(1001, 4, align=256)
     assert b == sorted(b) and b[-1] == 1001
+
+
+# ---- the multi-GPU server's dispatch (vod_amd.search.group), world_size 2 on gloo ----------------------------------------
+
+
+def _group_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.flat_ip import flat_ip_topk, merge_shard_topk, topk_desc_tiebreak
+        from vod_amd.distributed import ShardedFlatIndex, shard_bounds
+        from vod_amd.search.group import GroupDispatcher
+
+        rng = np.random.default_rng(11)
+        n, d = 3000, 24
+        x = rng.integers(-4, 5, size=(n, d)).astype(np.float32)
+        labels = rng.integers(0, 5, size=n).astype(np.int32)
+        bounds = shard_bounds(n, world, align=256)
+        lo, hi = bounds[rank], bounds[rank + 1]
+
+        def local_search(queries, kk, base, subset=None):
+            q = queries.numpy()
+            if subset is None:
+                s, i = flat_ip_topk(q, x[lo:hi], kk, id_base=base)
+            else:  # the shard's own labels decide eligibility: what the HIP index does with its slice of the row labels
+                full = q.astype(np.float64) @ x[lo:hi].astype(np.float64).T
+                sub = subset.numpy()
+                for r in range(len(q)):
+                    allowed = sub[r][sub[r] >= 0]
+                    if allowed.size:
+                        full[r, ~np.isin(labels[lo:hi], allowed)] = np.nan
+                s, i = topk_desc_tiebreak(full, kk, id_base=base)
+            return torch.from_numpy(s), torch.from_numpy(i)
+
+        def merge(gs, gi):
+            s, i = merge_shard_topk(list(gs.numpy()), list(gi.numpy()), gs.shape[-1])
+            return torch.from_numpy(s), torch.from_numpy(i)
+
+        disp = GroupDispatcher(ShardedFlatIndex(None, lo, local_search=local_search, merge=merge), rank, world, torch.device("cpu"))
+        if rank != 0:
+            served = disp.worker_loop()
+            np.save(os.path.join(out_dir, f"served_{rank}.npy"), np.array([served]))
+            return
+        ok = True
+        for nq, k, with_subset in [(7, 10, False), (1, 3, False), (33, 50, True), (5, 2000, False)]:
+            q = rng.integers(-4, 5, size=(nq, d)).astype(np.float32)
+            sub = None
+            full = q.astype(np.float64) @ x.astype(np.float64).T
+            if with_subset:
+                sub = np.full((nq, 2), -1, dtype=np.int32)
+                sub[::2, 0] = 3
+                sub[1::4] = [1, 4]
+                for r in range(nq):
+                    allowed = sub[r][sub[r] >= 0]
+                    if allowed.size:
+                        full[r, ~np.isin(labels, allowed)] = np.nan
+            s, i = disp.search(q, k, subset=sub)
+            rs, ri = topk_desc_tiebreak(full, k)
+            ok = ok and np.array_equal(i, ri) and np.array_equal(s, rs)
+        disp.stop()
+        np.save(os.path.join(out_dir, "ok_0.npy"), np.array([ok]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_group_dispatcher_two_ranks_gloo(tmp_path):
+    """Rank 0 drives, rank 1 serves: header / queries / subset labels are broadcast, both ranks run the same sharded
+    search, rank 0's merged answers equal the oracle on the whole store, the stop word ends rank 1's loop."""
+    mp.spawn(_group_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert np.load(tmp_path / "ok_0.npy")[0] == 1
+    assert np.load(tmp_path / "served_1.npy")[0] == 4

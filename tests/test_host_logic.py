@@ -454,3 +454,36 @@ def test_samples_to_dict_has_the_collate_field_contract():
                                          log_weights=np.zeros((1, 1)), max_sampling_id=np.zeros(1), lse_pos=np.zeros(1), lse_neg=np.zeros(1), raw_scores={})
     with pytest.raises(ValueError):
         samples_to_dict(ps_nolabel, [[0.0]])
+
+
+def test_factory_port_is_resolved_once_for_all_ranks(tmp_path):
+    """`port < 0` (pick a free port) must yield the SAME port on every rank: rank 0 picks, `broadcast_fn` hands it on
+    (the reference: `_resolve_ports`, src/vod_search/factory.py:380-394); a connect-only rank may not invent its own."""
+    import numpy as np
+
+    from vod_amd import factory
+
+    vecs = np.zeros((4, 8), dtype=np.float32)
+    cfg = factory.HipMipsFactoryConfig(port=-1)
+    sent = {}
+
+    def bcast(p):  # rank 0's side of fabric.broadcast(p, 0)
+        sent["port"] = p
+        return p
+
+    m0 = factory.build_hip_mips_index(vecs, config=cfg, cache_dir=tmp_path, broadcast_fn=bcast)
+    assert m0.port == sent["port"] and m0.port > 0
+    m1 = factory.build_hip_mips_index(vecs, config=cfg, cache_dir=tmp_path, skip_setup=True, broadcast_fn=lambda _p: sent["port"])
+    assert m1.port == m0.port and m1.get_client().port == m0.port
+    with pytest.raises(ValueError, match="resolve the port once"):
+        factory.build_hip_mips_index(vecs, config=cfg, cache_dir=tmp_path, skip_setup=True)
+    assert factory.HipMipsFactoryConfig().port == 6637  # the reference's default (faiss_search/client.py:124)
+
+
+def test_master_command_line_for_a_multi_gpu_group(tmp_path):
+    m = vclient.HipMipsMaster(tmp_path / "v.npy", devices=[0, 1, 2, 3], port=7001, skip_setup=True)
+    cmd = m._make_cmd()
+    assert cmd[cmd.index("--devices") + 1] == "0,1,2,3" and "--device" not in cmd
+    m1 = vclient.HipMipsMaster(tmp_path / "v.npy", device=2, port=7001, skip_setup=True)
+    cmd1 = m1._make_cmd()
+    assert cmd1[cmd1.index("--device") + 1] == "2" and "--devices" not in cmd1

@@ -35,7 +35,7 @@ class ShardedFlatIndex:
         self.group = group
         self.always_exchange = always_exchange  # run the all-gather + merge even with one rank (exercises RCCL on a 1-GPU box)
         self._native_path = local_search is None and merge is None  # HIP search + ONE packed all-gather + HIP merge
-        self._local_search = local_search or (lambda q, k, base: local_index.search(q, k, id_base=base))
+        self._local_search = local_search or (lambda q, k, base, subset=None: local_index.search(q, k, id_base=base, subset=subset))
         if merge is None:
             from vod_amd.index import merge_topk as merge  # HIP k-way merge
         self._merge = merge
@@ -45,8 +45,9 @@ class ShardedFlatIndex:
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
-    def search(self, queries: torch.Tensor, k: int) -> tuple[torch.Tensor, torch.Tensor]:
-        """queries [nq, d], identical on every rank.  Returns (scores f32 [nq, k], global ids i64 [nq, k])."""
+    def search(self, queries: torch.Tensor, k: int, subset: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+        """queries [nq, d] (and `subset` int32 [nq, S] allowed row labels, optional), identical on every rank.
+        Returns (scores f32 [nq, k], global ids i64 [nq, k])."""
         world = self.world
         if self._native_path and (world > 1 or (self.always_exchange and dist.is_initialized())):
             from vod_amd.index import PackedTopk
@@ -56,10 +57,10 @@ class ShardedFlatIndex:
                 self._packed = PackedTopk(nq, k, self.local_index.device)
                 self._gathered = torch.empty((world * self._packed.nbytes,), dtype=torch.uint8, device=self.local_index.device)
             p = self._packed
-            self.local_index.search(queries, k, id_base=self.row_offset, out=(p.scores, p.ids))
+            self.local_index.search(queries, k, id_base=self.row_offset, out=(p.scores, p.ids), subset=subset)
             dist.all_gather_into_tensor(self._gathered, p.buffer, group=self.group)  # 12 * nq * k bytes per rank, one collective
             return p.merge_gathered(self._gathered, world)
-        s, i = self._local_search(queries, k, self.row_offset)
+        s, i = self._local_search(queries, k, self.row_offset) if subset is None else self._local_search(queries, k, self.row_offset, subset)
         if world == 1:
             return s, i
         nq, kk = s.shape

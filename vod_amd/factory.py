@@ -26,12 +26,30 @@ class HipMipsFactoryConfig:
     metric: str = "inner_product"   # src/vod_configs/search.py:130
     dtype: str = "float16"          # HBM storage type (float16 | bfloat16)
     host: str = "http://localhost"
-    port: int = -1                  # < 0: pick a free port
+    port: int = 6637                # the reference's default (faiss_search/client.py:124); < 0 = pick a free one, which only
+                                    # works when ONE process resolves it and tells the others - see `resolve_port`
     logging_level: str = "CRITICAL"
     device: int = 0
+    devices: tuple[int, ...] | None = None  # row-shard the store over these GPUs behind one address
 
     def fingerprint(self) -> dict:
         return {"factory": self.factory, "metric": self.metric, "dtype": self.dtype}
+
+
+def resolve_port(config: HipMipsFactoryConfig, broadcast_fn: None | typ.Callable[[int], int] = None) -> HipMipsFactoryConfig:
+    """Turn `port < 0` into a concrete free port that EVERY rank agrees on.
+
+    The reference does this in `_resolve_ports` (/root/reference/src/vod_search/factory.py:380-394): rank 0 picks a free
+    port and `fabric.broadcast(port, 0)` hands it to the others, before any master is built.  `broadcast_fn(port) -> port`
+    plays the fabric's role (e.g. `lambda p: fabric.broadcast(p, 0)`); without one the port is only valid in this process."""
+    if config.port >= 0:
+        return config
+    from vod_amd.search.socket import find_available_port
+
+    port = find_available_port()
+    if broadcast_fn is not None:
+        port = int(broadcast_fn(port))
+    return dataclasses.replace(config, port=port)
 
 
 def build_hip_mips_index(
@@ -42,11 +60,21 @@ def build_hip_mips_index(
     skip_setup: bool = False,
     barrier_fn: None | typ.Callable[[str], None] = None,
     free_resources: bool = False,
+    serve_on_gpu: bool = True,  # noqa: ARG001 - the reference's keyword (factory.py:139); this engine only exists on the GPU
+    devices: None | typ.Sequence[int] = None,
+    broadcast_fn: None | typ.Callable[[int], int] = None,
 ) -> HipMipsMaster:
     if config is None:
         config = HipMipsFactoryConfig()
     elif isinstance(config, dict):
         config = HipMipsFactoryConfig(**config)
+    if config.port < 0:
+        if skip_setup and broadcast_fn is None:
+            # a rank that only connects cannot invent the port the serving rank picked (round-1 bug: every rank drew its own)
+            raise ValueError("port < 0 with skip_setup=True: resolve the port once (resolve_port / broadcast_fn) and pass it to every rank")
+        config = resolve_port(config, broadcast_fn)
+    if devices is None and config.devices is not None:
+        devices = list(config.devices)
     if config.factory != "Flat" or config.metric != "inner_product":
         raise ValueError("the HIP MIPS engine is an exact inner-product index (factory='Flat', metric='inner_product')")
     from vod_amd.zarr_store import ZarrVectors
@@ -76,4 +104,5 @@ def build_hip_mips_index(
         free_resources=free_resources,
         dtype=config.dtype,
         device=config.device,
+        devices=None if devices is None else list(devices),
     )

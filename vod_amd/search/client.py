@@ -126,6 +126,7 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
     `vectors_path` is a `.npy` file ([N, D] float32 / float16) or a store directory written by
     `vod_amd.store.save_vectors`.  Counterpart of `FaissMaster(index_path, nprobe, logging_level, host, port,
     skip_setup, free_resources, serve_on_gpu)`; `nprobe` is accepted and ignored (the index is exact).
+    `devices=[0, ..., 7]` serves ONE index row-sharded over several GPUs from the same address.
     """
 
     def __init__(  # noqa: PLR0913
@@ -139,6 +140,8 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         free_resources: bool = False,
         dtype: str = "float16",
         device: int = 0,
+        devices: None | list[int] = None,
+        serve_on_gpu: bool = True,  # noqa: ARG002 - accepted for call-site compatibility: this engine only exists on the GPU
     ):
         super().__init__(skip_setup=skip_setup, free_resources=free_resources)
         self.vectors_path = pathlib.Path(vectors_path)
@@ -147,6 +150,10 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         self.port = find_available_port() if port < 0 else port
         self.dtype = dtype
         self.device = device
+        # `devices=[...]`: the store is row-sharded over these GPUs behind the SAME host:port (one worker process per
+        # GPU on an RCCL group; what `FaissMaster(serve_on_gpu=True)` gets from faiss's index_cpu_to_all_gpus,
+        # /root/reference/src/vod_search/faiss_search/client.py:118-137, server.py:51-54)
+        self.devices = None if devices is None else [int(d) for d in devices]
 
     def _make_env(self) -> dict[str, str]:
         env = copy(dict(os.environ))
@@ -162,7 +169,7 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
             "--port", str(self.port),
             "--logging-level", str(self.logging_level),
             "--dtype", self.dtype,
-            "--device", str(self.device),
+            *(["--devices", ",".join(map(str, self.devices))] if self.devices is not None else ["--device", str(self.device)]),
         ]
 
     def get_client(self) -> HipMipsClient:

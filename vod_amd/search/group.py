@@ -1,0 +1,68 @@
+"""One search over N processes, each owning a row shard of the store on its own GPU.
+
+Counterpart of what the reference's server gets from `faiss.index_cpu_to_all_gpus(index, co)` with
+`co.shard = True` (/root/reference/src/vod_search/faiss_search/server.py:51-54, src/vod_configs/search.py:80):
+ONE server address answers for an index sharded over every GPU of the node.  faiss does it with threads inside one
+process (`IndexShards`); here it is one process per GPU on an RCCL group (MI355X-native process model): rank 0
+owns the HTTP endpoint, broadcasts every request (a 6-word header, the queries, optionally the subset labels), all
+ranks run the same `ShardedFlatIndex.search` (local fused top-k -> one packed all-gather -> merge) and rank 0
+answers.  Ranks > 0 sit in `worker_loop()` until rank 0 broadcasts the stop word.
+
+The collective sequence is identical on every rank by construction (header, payload, search); rank 0 must
+serialise its callers (the server's lock does).  `device` is where the broadcast tensors live: the rank's GPU
+under RCCL, the CPU under gloo (tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+OP_STOP, OP_SEARCH = 0, 1
+
+
+class GroupDispatcher:
+    def __init__(self, sharded, rank: int, world: int, device: torch.device, group: dist.ProcessGroup | None = None):
+        self.sharded = sharded  # ShardedFlatIndex-like: .search(queries, k, subset=None) -> (scores, ids), collective
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+
+    # -- rank 0 ------------------------------------------------------------------------------------
+    def search(self, query_vec: np.ndarray, top_k: int, subset: np.ndarray | None = None) -> tuple[np.ndarray, np.ndarray]:
+        assert self.rank == 0, "only rank 0 drives the group"
+        q = torch.from_numpy(np.ascontiguousarray(query_vec, dtype=np.float32)).to(self.device)
+        sub = None
+        if subset is not None:
+            sub = torch.from_numpy(np.ascontiguousarray(subset, dtype=np.int32)).to(self.device)
+        header = torch.tensor([OP_SEARCH, q.shape[0], q.shape[1], int(top_k), 0 if sub is None else sub.shape[1], 0],
+                              dtype=torch.int64, device=self.device)
+        if self.world > 1:
+            dist.broadcast(header, 0, group=self.group)
+            dist.broadcast(q, 0, group=self.group)
+            if sub is not None:
+                dist.broadcast(sub, 0, group=self.group)
+        scores, ids = self.sharded.search(q, int(top_k), subset=sub)
+        return scores.cpu().numpy(), ids.cpu().numpy()
+
+    def stop(self) -> None:
+        if self.rank == 0 and self.world > 1:
+            dist.broadcast(torch.tensor([OP_STOP, 0, 0, 0, 0, 0], dtype=torch.int64, device=self.device), 0, group=self.group)
+
+    # -- ranks > 0 ---------------------------------------------------------------------------------
+    def worker_loop(self) -> int:
+        """Serve requests until rank 0 says stop.  Returns the number of searches served."""
+        assert self.rank != 0
+        served = 0
+        while True:
+            header = torch.zeros(6, dtype=torch.int64, device=self.device)
+            dist.broadcast(header, 0, group=self.group)
+            op, nq, dim, k, n_sub, _ = (int(v) for v in header.cpu())
+            if op == OP_STOP:
+                return served
+            q = torch.empty((nq, dim), dtype=torch.float32, device=self.device)
+            dist.broadcast(q, 0, group=self.group)
+            sub = None
+            if n_sub:
+                sub = torch.empty((nq, n_sub), dtype=torch.int32, device=self.device)
+                dist.broadcast(sub, 0, group=self.group)
+            self.sharded.search(q, k, subset=sub)
+            served += 1

@@ -200,9 +200,12 @@ def create_app(engine, micro_batch_wait_ms: float = 0.0) -> FastAPI:
 
 
 class HipEngine:
-    """The production engine: a `HipFlatIndex` fed from a vector file, searched on the GPU."""
+    """The production engine: a `HipFlatIndex` fed from a vector file, searched on the GPU.
 
-    def __init__(self, vectors_path: str, dtype: str = "float16", device: int = 0, subset_ids_path: str | None = None):
+    `row_range=(lo, hi)`: hold only rows [lo, hi) of the store (one shard of a multi-GPU group); ids stay global."""
+
+    def __init__(self, vectors_path: str, dtype: str = "float16", device: int = 0, subset_ids_path: str | None = None,
+                 row_range: tuple[int, int] | None = None):
         import torch
 
         from vod_amd import store
@@ -211,44 +214,67 @@ class HipEngine:
         self._torch = torch
         vectors = store.open_vectors(vectors_path)
         n, d = vectors.shape
-        self.index = HipFlatIndex(d, max(n, 1), dtype=getattr(torch, dtype), device=device)
+        lo, hi = (0, n) if row_range is None else (int(row_range[0]), int(row_range[1]))
+        self.n_store, self.row_lo, self.row_hi = n, lo, hi
+        self.index = HipFlatIndex(d, max(hi - lo, 1), dtype=getattr(torch, dtype), device=device)
         step = 262144
-        if hasattr(vectors, "iter_row_blocks"):  # zarr store: blocks aligned to its chunk grid, each chunk decoded once
+        if hasattr(vectors, "iter_row_blocks") and row_range is None:  # zarr store: blocks aligned to its chunk grid, each chunk decoded once
             for _lo, rows in vectors.iter_row_blocks(step):
                 self.index.add(rows if rows.dtype != np.float64 else rows.astype(np.float32))
         else:
-            for lo in range(0, n, step):  # H2D in slices; the store converts to fp16/bf16 on the device
-                self.index.add(np.ascontiguousarray(vectors[lo : lo + step]))
+            for b0 in range(lo, hi, step):  # H2D in slices; the store converts to fp16/bf16 on the device
+                rows = np.ascontiguousarray(vectors[b0 : min(hi, b0 + step)])
+                self.index.add(rows if rows.dtype != np.float64 else rows.astype(np.float32))
         self.vocab: dict[str, int] = {}
         if subset_ids_path:  # one subset id (string) per stored row -> int32 labels on the device
             ids = np.load(subset_ids_path, allow_pickle=False)
             if len(ids) != n:
                 raise ValueError(f"{subset_ids_path}: {len(ids)} subset ids for {n} vectors")
-            uniq, codes = np.unique(ids.astype(str), return_inverse=True)
+            uniq, codes = np.unique(ids.astype(str), return_inverse=True)  # the vocabulary is global: same codes on every shard
             self.vocab = {str(u): i for i, u in enumerate(uniq)}
-            self.index.set_row_labels(codes.astype(np.int32))
+            self.index.set_row_labels(codes[lo:hi].astype(np.int32))
 
     @property
     def ntotal(self) -> int:
         return self.index.ntotal
 
+    def encode_subset(self, subset_ids: list[list[str]] | None) -> np.ndarray | None:
+        if subset_ids is None:
+            return None
+        if not self.vocab:
+            raise ValueError("the server was started without --subset-ids-path: cannot filter by subset id")
+        width = max(1, max(len(s) for s in subset_ids))
+        subset = np.full((len(subset_ids), width), -1, dtype=np.int32)
+        for r, names in enumerate(subset_ids):
+            # an unknown subset id matches no row: -2 keeps the query restricted (and empty) instead of unrestricted
+            subset[r, : len(names)] = [self.vocab.get(str(nm), -2) for nm in names]
+        return subset
+
     def search(self, query_vec: np.ndarray, top_k: int, subset_ids: list[list[str]] | None = None) -> tuple[np.ndarray, np.ndarray]:
         if query_vec.shape[1] != self.index.dim:
             raise ValueError(f"query dimension {query_vec.shape[1]} != index dimension {self.index.dim}")
-        subset = None
-        if subset_ids is not None:
-            if not self.vocab:
-                raise ValueError("the server was started without --subset-ids-path: cannot filter by subset id")
-            width = max(1, max(len(s) for s in subset_ids))
-            subset = np.full((len(subset_ids), width), -1, dtype=np.int32)
-            for r, names in enumerate(subset_ids):
-                # an unknown subset id matches no row: -2 keeps the query restricted (and empty) instead of unrestricted
-                subset[r, : len(names)] = [self.vocab.get(str(nm), -2) for nm in names]
-        scores, ids = self.index.search(query_vec, top_k, subset=subset)
+        scores, ids = self.index.search(query_vec, top_k, id_base=self.row_lo, subset=self.encode_subset(subset_ids))
         return scores.cpu().numpy(), ids.cpu().numpy()
 
 
-def parse_args() -> argparse.Namespace:
+class GroupHipEngine:
+    """Rank 0's engine of a multi-GPU group (`--devices`): same `.ntotal` / `.search` as `HipEngine`, but every search is
+    broadcast to the N ranks, each searching its row shard on its own GPU, and merged (vod_amd.search.group)."""
+
+    def __init__(self, local: HipEngine, dispatcher):
+        self.local, self.dispatcher = local, dispatcher
+
+    @property
+    def ntotal(self) -> int:
+        return self.local.n_store
+
+    def search(self, query_vec: np.ndarray, top_k: int, subset_ids: list[list[str]] | None = None) -> tuple[np.ndarray, np.ndarray]:
+        if query_vec.shape[1] != self.local.index.dim:
+            raise ValueError(f"query dimension {query_vec.shape[1]} != index dimension {self.local.index.dim}")
+        return self.dispatcher.search(query_vec, top_k, subset=self.local.encode_subset(subset_ids))
+
+
+def parse_args(argv=None) -> argparse.Namespace:
     p = argparse.ArgumentParser()
     p.add_argument("--vectors-path", type=str, required=True)
     p.add_argument("--host", type=str, default="localhost")
@@ -256,16 +282,106 @@ def parse_args() -> argparse.Namespace:
     p.add_argument("--logging-level", type=str, default="INFO")
     p.add_argument("--dtype", type=str, default="float16", choices=["float16", "bfloat16"])
     p.add_argument("--device", type=int, default=0)
+    p.add_argument("--devices", type=str, default=None,
+                   help="comma-separated GPU ids: the store is row-sharded over them, one worker process per GPU on an RCCL "
+                        "group, rank 0 answers HTTP (the reference's `--serve-on-gpu` = faiss index_cpu_to_all_gpus, server.py:51-54)")
     p.add_argument("--subset-ids-path", type=str, default=None, help=".npy with one subset id (string) per vector")
     p.add_argument("--micro-batch-wait-ms", type=float, default=0.0,
                    help="> 0: fuse requests that arrive within this window into one GPU batch (default: serialise, as the reference)")
-    return p.parse_args()
+    # set by the owner process for its workers
+    p.add_argument("--rank", type=int, default=None, help=argparse.SUPPRESS)
+    p.add_argument("--master-port", type=int, default=0, help=argparse.SUPPRESS)
+    return p.parse_args(argv)
 
 
-def main() -> None:
+def _die_with_parent() -> None:  # child side of Popen: SIGTERM when the owner goes away, however it goes
+    import ctypes
+    import signal
+
+    ctypes.CDLL(None).prctl(1, signal.SIGTERM)  # PR_SET_PDEATHSIG
+
+
+def run_owner(args: argparse.Namespace, argv: list[str]) -> int:
+    """`--devices a,b,...`: start one fresh worker per GPU and wait.  The owner never touches a GPU (it does not import
+    torch), so the workers are ordinary children - nothing that has initialised HIP is forked or replaced."""
+    import os
+    import signal
+    import subprocess
+    import sys
+    import time
+
+    from vod_amd.search.socket import find_available_port
+
+    devices = [int(x) for x in args.devices.split(",") if x.strip() != ""]
+    if not devices:
+        raise SystemExit("--devices needs at least one GPU id")
+    port = find_available_port()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
+    procs = [subprocess.Popen([sys.executable, "-m", "vod_amd.search.server", *argv, "--rank", str(r), "--master-port", str(port)],
+                              env=env, preexec_fn=_die_with_parent) for r in range(len(devices))]
+
+    def _stop(*_):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+
+    signal.signal(signal.SIGTERM, _stop)
+    signal.signal(signal.SIGINT, _stop)
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.1)
+        for p in procs:
+            if p.poll() not in (None, 0) and rc == 0:  # a worker died: the group cannot answer any more
+                rc = p.returncode if p.returncode > 0 else 1
+                _stop()
+    return rc
+
+
+def run_worker(args: argparse.Namespace) -> None:
+    import torch
+    import torch.distributed as dist
     import uvicorn
 
-    args = parse_args()
+    from vod_amd import store
+    from vod_amd.distributed import ShardedFlatIndex, shard_bounds
+    from vod_amd.search.group import GroupDispatcher
+
+    devices = [int(x) for x in args.devices.split(",") if x.strip() != ""]
+    rank, world = args.rank, len(devices)
+    torch.cuda.set_device(devices[rank])
+    dev = torch.device("cuda", devices[rank])
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{args.master_port}", rank=rank, world_size=world, device_id=dev)
+    n = store.open_vectors(args.vectors_path).shape[0]
+    bounds = shard_bounds(n, world, align=256)
+    local = HipEngine(args.vectors_path, dtype=args.dtype, device=devices[rank], subset_ids_path=args.subset_ids_path,
+                      row_range=(bounds[rank], bounds[rank + 1]))
+    sharded = ShardedFlatIndex(local.index, row_offset=bounds[rank], always_exchange=True)
+    dispatcher = GroupDispatcher(sharded, rank, world, dev)
+    dist.barrier()  # every shard is resident before rank 0 starts answering (the master's ping loop waits for that)
+    if rank != 0:
+        dispatcher.worker_loop()
+    else:
+        host = re.sub(r"^(http|https)://", "", args.host)
+        try:
+            uvicorn.run(create_app(GroupHipEngine(local, dispatcher), micro_batch_wait_ms=args.micro_batch_wait_ms), host=host,
+                        port=args.port, workers=1, log_level=args.logging_level.lower())
+        finally:
+            dispatcher.stop()
+    dist.destroy_process_group()
+
+
+def main(argv=None) -> None:
+    import sys
+
+    import uvicorn
+
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.devices is not None and args.rank is None:
+        raise SystemExit(run_owner(args, argv))
+    if args.devices is not None:
+        return run_worker(args)
     engine = HipEngine(args.vectors_path, dtype=args.dtype, device=args.device, subset_ids_path=args.subset_ids_path)
     host = re.sub(r"^(http|https)://", "", args.host)
     uvicorn.run(create_app(engine, micro_batch_wait_ms=args.micro_batch_wait_ms), host=host, port=args.port, workers=1,
