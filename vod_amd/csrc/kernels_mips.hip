@@ -680,7 +680,7 @@ __device__ key_t64 radix_select_kth_lds(const key_t64* keys, int total, int k, i
 // One workgroup per query.  The LDS buffer holds SB keys (SB >= 2*kp, power of two): the running top-k sits in
 // front, candidates are folded in rounds of SB - kp.  Between stages only the k-th best key (the threshold) and the
 // SET of the k best are needed, so intermediate launches use a radix select + compaction (unsorted top-k);
-// the last launch of a search (SELECT_FINAL) sorts and writes the result rows.
+// the last launch of a search (SELECT_FINAL) then sorts those k and writes the result rows.
 // SELECT_THRESHOLD_ONLY (after a GMAX stage): the candidates are group maxima, not rows - only the threshold leaves.
 // The threshold never decreases: a stage whose candidates do not fill the top-k keeps the bound it was given.
 enum : int { SELECT_FINAL = 1, SELECT_THRESHOLD_ONLY = 2 };
@@ -688,9 +688,9 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
                                                           const key_t64* __restrict__ cand,
                                                           unsigned int* __restrict__ cnt, int cap, int dense_n,
                                                           float* __restrict__ thr_s, key_t64* __restrict__ thr_key,
-                                                          unsigned int* __restrict__ overflow, int flags,
+                                                          unsigned int* __restrict__ overflow, unsigned int* __restrict__ ovf_q, int flags,
                                                           int64_t id_base, float* __restrict__ out_scores,
-                                                          int64_t* __restrict__ out_ids) {
+                                                          int64_t* __restrict__ out_ids, const int* __restrict__ q_map) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     key_t64* keys = (key_t64*)smem;
     int* hist = (int*)(keys + sb);  // 264 ints: bins, scratch words, compaction counter at [258] (see radix_select_kth_lds)
@@ -699,8 +699,11 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
     const bool final_sort = (flags & SELECT_FINAL) != 0;
     const bool thr_only = (flags & SELECT_THRESHOLD_ONLY) != 0;
     unsigned n = dense_n >= 0 ? (unsigned)dense_n : cnt[q];
-    if (n > (unsigned)cap) {
-        if (tid == 0) atomicOr(overflow, 1u);
+    if (n > (unsigned)cap) {  // this query lost candidates in this stage: the host recovers it (and only it)
+        if (tid == 0) {
+            atomicOr(overflow, 1u);
+            if (ovf_q) ovf_q[q] = 1u;
+        }
         n = cap;
     }
     for (int i = tid; i < kp; i += 256) keys[i] = thr_only ? 0ull : topk[(size_t)q * kp + i];
@@ -711,22 +714,16 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
         const int take = min((int)n - done, room);
         const int total = kp + take;
         const bool last_round = done + take >= (int)n;
-        if (final_sort && last_round) {
-            int P = 64;
-            while (P < total) P <<= 1;
-            for (int i = kp + tid; i < P; i += 256) keys[i] = (i < total) ? cand[(size_t)q * cap + done + (i - kp)] : 0ull;
-            bitonic_sort_desc_lds(keys, P, tid);
-            kth = keys[k - 1];
-        } else {
+        {
             for (int i = kp + tid; i < total; i += 256) keys[i] = cand[(size_t)q * cap + done + (i - kp)];
             __syncthreads();
             kth = radix_select_kth_lds(keys, total, k, hist, tid);  // total >= kp >= k (zeros pad the running top-k)
             // compaction: the keys >= kth (exactly k of them unless kth == 0) move to the front, zeros behind
-            key_t64 mine[16];  // SB <= 4096 keys / 256 threads
+            key_t64 mine[32];  // SB <= 8192 keys / 256 threads
             int n_mine = 0;
             for (int i = tid; i < total; i += 256) {
                 const key_t64 e = keys[i];
-                if (e >= kth && e != 0ull && n_mine < 16) mine[n_mine++] = e;
+                if (e >= kth && e != 0ull && n_mine < 32) mine[n_mine++] = e;
             }
             if (tid == 0) hist[258] = 0;
             __syncthreads();
@@ -735,19 +732,24 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
             for (int i = tid; i < kp; i += 256) keys[i] = 0ull;
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
+            for (int u = 0; u < 32; ++u)
                 if (u < n_mine) keys[base + u] = mine[u];
             __syncthreads();
         }
         done += take;
     } while (done < (int)n);
+    if (final_sort) {  // the k best are in front, unordered: only they are sorted
+        bitonic_sort_desc_lds(keys, kp, tid);
+        kth = keys[k - 1];
+    }
     if (!thr_only)
         for (int i = tid; i < kp; i += 256) topk[(size_t)q * kp + i] = keys[i];
     if (out_scores != nullptr) {  // last select of a search: the sorted keys leave as (float32 score, int64 id) rows
+        const size_t qo = q_map ? (size_t)q_map[q] : (size_t)q;
         for (int c = tid; c < k; c += 256) {
             const key_t64 key = keys[c];
-            out_scores[(size_t)q * k + c] = key ? unflip_f32((unsigned)(key >> 32)) : -__builtin_inff();
-            out_ids[(size_t)q * k + c] = key ? id_base + (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)) : -1;
+            out_scores[qo * k + c] = key ? unflip_f32((unsigned)(key >> 32)) : -__builtin_inff();
+            out_ids[qo * k + c] = key ? id_base + (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)) : -1;
         }
     }
     if (tid == 0) {
@@ -843,8 +845,9 @@ __global__ void mips_prepare_kernel(const void* __restrict__ q_src, int q_dtype,
                                     uint16_t* __restrict__ q_pad, int store_dtype, int64_t nq_pad, int64_t dim_pad,
                                     key_t64* __restrict__ topk, int64_t n_topk, unsigned int* __restrict__ cnt,
                                     float* __restrict__ thr_s, key_t64* __restrict__ thr_key,
-                                    unsigned int* __restrict__ overflow, int clear_overflow,
-                                    const float* __restrict__ seed_scores, const int64_t* __restrict__ seed_ids, int k) {
+                                    unsigned int* __restrict__ overflow, unsigned int* __restrict__ ovf_q, int clear_overflow,
+                                    const float* __restrict__ seed_scores, const int64_t* __restrict__ seed_ids, int k,
+                                    const int* __restrict__ q_map) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t chunks_per_row = dim_pad / 8;
     if (i < nq_pad * chunks_per_row) {
@@ -856,10 +859,11 @@ __global__ void mips_prepare_kernel(const void* __restrict__ q_src, int q_dtype,
             const int64_t c = c0 + e;
             uint16_t v = 0;
             if (row < nq && c < dim) {
+                const int64_t srow = q_map ? (int64_t)q_map[row] : row;
                 float f;
-                if (q_dtype == 2) f = ((const float*)q_src)[row * dim + c];
-                else if (q_dtype == 0) f = (float)(((const _Float16*)q_src)[row * dim + c]);
-                else f = (float)(((const __bf16*)q_src)[row * dim + c]);
+                if (q_dtype == 2) f = ((const float*)q_src)[srow * dim + c];
+                else if (q_dtype == 0) f = (float)(((const _Float16*)q_src)[srow * dim + c]);
+                else f = (float)(((const __bf16*)q_src)[srow * dim + c]);
                 if (store_dtype == 0) {
                     const _Float16 h = (_Float16)f;
                     v = __builtin_bit_cast(uint16_t, h);
@@ -877,8 +881,10 @@ __global__ void mips_prepare_kernel(const void* __restrict__ q_src, int q_dtype,
         cnt[i] = 0;
         float ts = -__builtin_inff();
         key_t64 tk = 0;
-        if (seed_scores != nullptr && i < nq && seed_ids[i * k + (k - 1)] >= 0) {
-            const float s = seed_scores[i * k + (k - 1)];
+        const int64_t srow = (q_map && i < nq) ? (int64_t)q_map[i] : i;
+        if (ovf_q != nullptr && i < nq) ovf_q[i] = 0u;
+        if (seed_scores != nullptr && i < nq && seed_ids[srow * k + (k - 1)] >= 0) {
+            const float s = seed_scores[srow * k + (k - 1)];
             if (s == s) {
                 ts = s;
                 tk = (key_t64)flip_f32(s) << 32;  // low word 0: every row with this score still passes `key > thr_key`
@@ -892,14 +898,14 @@ __global__ void mips_prepare_kernel(const void* __restrict__ q_src, int q_dtype,
 
 hipError_t launch_search_prepare(const SearchWorkspace& ws, const void* q_src, int q_dtype, int64_t nq, int64_t dim,
                                  int store_dtype, int64_t nq_pad, int64_t dim_pad, bool clear_overflow,
-                                 const float* seed_scores, const int64_t* seed_ids, int k, hipStream_t stream) {
+                                 const float* seed_scores, const int64_t* seed_ids, int k, const int* q_map, hipStream_t stream) {
     const int64_t n_topk = nq_pad * ws.kp;
     const int64_t n = std::max(n_topk, nq_pad * (dim_pad / 8));
     const int threads = 256;
     const unsigned blocks = (unsigned)((n + threads - 1) / threads);
     hipLaunchKernelGGL(mips_prepare_kernel, dim3(blocks), dim3(threads), 0, stream, q_src, q_dtype, nq, dim,
                        (uint16_t*)ws.q_pad, store_dtype, nq_pad, dim_pad, ws.topk, n_topk, ws.cnt, ws.thr_s, ws.thr_key,
-                       ws.overflow, clear_overflow ? 1 : 0, seed_scores, seed_ids, k);
+                       ws.overflow, ws.ovf_q, clear_overflow ? 1 : 0, seed_scores, seed_ids, k, q_map);
     return hipGetLastError();
 }
 
@@ -1012,14 +1018,18 @@ hipError_t launch_filter(int store_dtype, int tile, int mode, const void* store,
 }
 
 hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, int flags, hipStream_t stream,
-                         int64_t id_base, float* out_scores, int64_t* out_ids) {
-    int sb = 2048;  // keys per workgroup buffer: 16 KB -> 8 workgroups per CU
+                         int64_t id_base, float* out_scores, int64_t* out_ids, const int* q_map) {
+    // keys per workgroup buffer: 16 KB -> 8 workgroups per CU; a stage with a KNOWN large candidate count per query (the
+    // bootstrap's group maxima) gets a buffer that takes them in one round
+    int sb = 2048;
     while (sb < 2 * ws.kp) sb <<= 1;
+    while (dense_n > sb - ws.kp && sb < 8192) sb <<= 1;
     const size_t lds = (size_t)sb * sizeof(key_t64) + 264 * sizeof(int);
+    if (hipError_t e = allow_dynamic_lds((const void*)mips_select_kernel, 8192 * (int)sizeof(key_t64) + 264 * (int)sizeof(int)); e != hipSuccess) return e;
     const bool final_sort = (flags & SELECT_FINAL) != 0;
     hipLaunchKernelGGL(mips_select_kernel, dim3((unsigned)nq), dim3(256), lds, stream, ws.topk, (int)ws.kp, k, sb, ws.cand,
-                       ws.cnt, (int)ws.cap, (int)dense_n, ws.thr_s, ws.thr_key, ws.overflow, flags, id_base,
-                       final_sort ? out_scores : nullptr, final_sort ? out_ids : nullptr);
+                       ws.cnt, (int)ws.cap, (int)dense_n, ws.thr_s, ws.thr_key, ws.overflow, ws.ovf_q, flags, id_base,
+                       final_sort ? out_scores : nullptr, final_sort ? out_ids : nullptr, q_map);
     return hipGetLastError();
 }
 

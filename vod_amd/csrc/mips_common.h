@@ -68,10 +68,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 __device__ __forceinline__ bool subset_allows(const FilterExtra& ex, int q, int row) {
     if (ex.row_label == nullptr) return true;
     const int lab = ex.row_label[row];
+    const int qq = ex.q_map ? ex.q_map[q] : q;
     bool any = false, ok = false;
 #pragma unroll 1
     for (int s = 0; s < ex.n_qlab; ++s) {
-        const int ql = ex.q_label[(size_t)q * ex.n_qlab + s];
+        const int ql = ex.q_label[(size_t)qq * ex.n_qlab + s];
         any |= ql != -1;  // -1 = empty slot; any other value (incl. an unknown id mapped to -2) restricts the query
         ok |= ql == lab;
     }

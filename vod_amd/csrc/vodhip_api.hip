@@ -52,11 +52,13 @@ struct PendingSearch {
     int64_t* out_ids = nullptr;
     const int* q_label = nullptr;  // subset labels in force when the search was enqueued
     int n_qlab = 0;
+    const int* q_map = nullptr;    // recovery of a few queries: workspace row -> row of the caller's batch (device)
     int slot = 0;                  // overflow-flag word / completion event of this search
     size_t ev_begin = 0, ev_end = 0;  // profile events of this search in ev_pool
 };
 
 constexpr int MAX_IN_FLIGHT = 4;  // searches that may be enqueued before the oldest is finished
+constexpr int64_t OVF_ROWS = 65536;  // per-query overflow flags are kept for batches up to this many queries
 
 }  // namespace
 
@@ -73,20 +75,22 @@ struct vodhip_index {
     void* stage_dev = nullptr;  // raw-dtype staging for host ingest
     SearchWorkspace ws;
     unsigned int* overflow_host = nullptr;  // pinned, one word per in-flight slot
+    unsigned int* ovf_q = nullptr;          // device [MAX_IN_FLIGHT][OVF_ROWS]: which queries of a slot's search overflowed
+    int* q_map = nullptr;                   // device [MAX_IN_FLIGHT][OVF_ROWS]: the rows a slot's recovery pass re-searches
     hipEvent_t done[MAX_IN_FLIGHT] = {};    // recorded after a search's overflow word is copied back
     std::deque<PendingSearch> inflight;     // oldest first
     int next_slot = 0;
     // tunables
-    int64_t cand_cap = 8192;
+    int64_t cand_cap = 16384;
     int64_t dense_rows = 2048;   // indexes up to this many rows are scored densely in one launch
     int64_t growth_x100 = 0;     // FILTER stage = growth x the rows its threshold was calibrated on; 0 = 8
     int64_t sample_div = 48;     // GMAX bootstrap scores ~ ntotal / sample_div sampled rows
     int64_t force_safe = 0;
     int64_t tile = 0;
-    int64_t small_chunk_tiles = 1024;  // launches with fewer 256x256 tiles than this use the 128x128 kernel
+    int64_t small_chunk_tiles = 256;  // launches with fewer 256x256 tiles than this (less than one per CU) use the 128x128 kernel
     int64_t profile = 0;  // 1: bracket every filter launch with HIP events (bench / roofline accounting)
     // stats
-    int64_t last_overflow = 0, last_chunks = 0, last_safe_reruns = 0;
+    int64_t last_overflow = 0, last_chunks = 0, last_safe_reruns = 0, last_recovered_queries = 0;
     int64_t last_filter_launches = 0, last_filter_ns = 0;
     std::vector<hipEvent_t> ev_pool;  // pairs (start, stop), reused across searches
     size_t ev_used = 0;
@@ -170,7 +174,11 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, bool safe, int 
     // at least 4k groups: the k-th largest of G group maxima is exceeded by a fraction -ln(1 - k/G) / rg of the rows,
     // which is ~ 1.15 k/S at G = 4k and blows up as G approaches k
     const int64_t s_min = round_up(std::max<int64_t>(4 * rg * (int64_t)k, 2048), bm);
-    const int64_t s_max = std::min(rg * cap, n / 2) / bm * bm;
+    int64_t kp = 64;
+    while (kp < k) kp <<= 1;
+    // one candidate slot per group, and the select kernel takes the group maxima in ONE round of its largest buffer
+    const int64_t g_max = std::min<int64_t>(cap, 8192 - kp);
+    const int64_t s_max = std::min(rg * g_max, n / 2) / bm * bm;
     if (s_max < s_min) return make_safe_schedule(n, cap, st);  // too few rows for k group maxima: short, all dense
     const int64_t s = std::min(s_max, std::max(s_min, round_up(n / std::max<int64_t>(ix->sample_div, 2), bm)));
     // S sampled rows at stride (n-1)/(S-1): the last one is row (S-1)*rstride <= n-1, all distinct (S <= n/2)
@@ -215,6 +223,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
     // the subset labels in force when THIS search was enqueued (a recovery pass may run after younger searches changed them)
     ix->ws.extra.row_label = (ix->row_label && ps.q_label) ? ix->row_label : nullptr;
     ix->ws.extra.n_qlab = ps.n_qlab;
+    const bool track_ovf = ps.nq <= OVF_ROWS;  // per-query overflow flags of this search's slot
     const bool subset = ix->ws.extra.row_label != nullptr;
     if (subset && !safe && recovery == 0) {
         // group maxima would include ineligible rows: a subset search runs the exhaustive-free geometric schedule instead
@@ -241,10 +250,15 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
         const int64_t nq_pad = round_up(nq, bn);
         // one launch: queries -> store dtype with zero padded rows / columns, running top-k and counters cleared,
         // thresholds -inf (or seeded from the previous result in a recovery pass), overflow word cleared at the first pass
-        HIP_OK(launch_search_prepare(ws, (const char*)ps.queries + (size_t)qb * ix->dim * q_es, ps.q_dtype, nq, ix->dim,
-                                     ix->dtype, nq_pad, ix->dim_pad, qb == 0, recovery > 0 ? ps.out_scores + qb * k : nullptr,
-                                     recovery > 0 ? ps.out_ids + qb * k : nullptr, k, stream));
-        ix->ws.extra.q_label = ps.q_label ? ps.q_label + (size_t)qb * ps.n_qlab : nullptr;
+        // with a query map (recovery of a few queries) workspace row r is row q_map[qb + r] of the caller's arrays
+        const int* q_map = ps.q_map ? ps.q_map + qb : nullptr;
+        const int64_t row0 = ps.q_map ? 0 : qb;
+        ix->ws.ovf_q = track_ovf ? ix->ovf_q + (size_t)ps.slot * OVF_ROWS + qb : nullptr;
+        HIP_OK(launch_search_prepare(ws, (const char*)ps.queries + (size_t)row0 * ix->dim * q_es, ps.q_dtype, nq, ix->dim,
+                                     ix->dtype, nq_pad, ix->dim_pad, qb == 0, recovery > 0 ? ps.out_scores + row0 * k : nullptr,
+                                     recovery > 0 ? ps.out_ids + row0 * k : nullptr, k, q_map, stream));
+        ix->ws.extra.q_label = ps.q_label ? ps.q_label + (size_t)row0 * ps.n_qlab : nullptr;
+        ix->ws.extra.q_map = q_map;
         for (size_t c = 0; c < stages.size(); ++c) {
             const Stage& sg = stages[c];
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -262,7 +276,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
             int tile_c = tile;
             if (persistent && ix->tile == 0 && sg.kind == ST_FILTER) {  // (nq_pad is a multiple of 256 there, which the 128-wide tile divides)
                 const int64_t tiles256 = ((sg.e - sg.b + 255) / 256) * (nq_pad / 256);
-                if (tiles256 < ix->small_chunk_tiles) tile_c = 1;
+                if (tiles256 < ix->small_chunk_tiles) tile_c = 1;  // fewer than one 256x256 tile per CU
             }
             ix->ws.extra.sample_rstride = (int)sg.rstride;
             ix->ws.extra.sample_groups = (int)sg.n_groups;
@@ -277,7 +291,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
                 dense_n = sg.n_groups;
                 flags |= 2;
             }
-            HIP_OK(launch_select(ws, nq, k, dense_n, flags, stream, ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k));
+            HIP_OK(launch_select(ws, nq, k, dense_n, flags, stream, ps.id_base, ps.out_scores + row0 * k, ps.out_ids + row0 * k, q_map));
         }
         if (stages.empty())  // empty index: nothing was selected, the cleared top-k leaves as pads
             HIP_OK(launch_output(ws, nq, k, ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k, stream));
@@ -321,6 +335,8 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
         return fail("hipMalloc of the %zu-byte vector store failed: %s", bytes, hipGetErrorString(e));
     }
     e = hipMemset(ix->data, 0, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->ovf_q, MAX_IN_FLIGHT * OVF_ROWS * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc((void**)&ix->q_map, MAX_IN_FLIGHT * OVF_ROWS * sizeof(int));
     if (e == hipSuccess) e = hipHostMalloc((void**)&ix->overflow_host, MAX_IN_FLIGHT * sizeof(unsigned int), hipHostMallocDefault);
     for (int i = 0; i < MAX_IN_FLIGHT && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ix->done[i], hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -344,6 +360,8 @@ int vodhip_index_destroy(vodhip_index_t* ix) {
     (void)hipFree(ix->data);
     (void)hipFree(ix->stage_dev);
     (void)hipFree(ix->row_label);
+    (void)hipFree(ix->ovf_q);
+    (void)hipFree(ix->q_map);
     (void)hipHostFree(ix->overflow_host);
     delete ix;
     return 0;
@@ -494,18 +512,36 @@ int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
     ix->inflight.pop_front();
     ix->last_overflow = 0;
     ix->last_safe_reruns = 0;
+    ix->last_recovered_queries = 0;
     if (ps.nq > 0) {
         HIP_OK(hipEventSynchronize(ix->done[ps.slot]));  // this search only: younger ones keep the device busy
         // A candidate list overflowed: the result is valid (real rows, real scores) but may miss hits.  Recovery
         // passes re-scan the store against thresholds seeded from that result - its k-th score is a lower bound of the
         // true k-th best, so few rows survive - in 1, 2, 4, ... FILTER stages, and in the exhaustive schedule (dense
         // chunks of <= cap rows, cannot overflow) once the stages are that short.
+        PendingSearch rs = ps;  // what the recovery passes search: the whole batch, or only the queries that overflowed
         for (int pass = 1; ix->overflow_host[ps.slot]; ++pass) {
             if (pass > 40) return fail("internal error: the exhaustive schedule overflowed");
             ix->last_overflow = 1;
             ix->last_safe_reruns = pass;
+            if (pass == 1 && ps.nq <= OVF_ROWS) {
+                // the select kernels flagged the queries whose lists overflowed: usually a few (their neighbours are
+                // clustered in the store): only they are searched again, as a small batch on the small-batch kernels
+                std::vector<unsigned int> flags((size_t)ps.nq);
+                HIP_OK(hipMemcpy(flags.data(), ix->ovf_q + (size_t)ps.slot * OVF_ROWS, (size_t)ps.nq * sizeof(unsigned int), hipMemcpyDeviceToHost));
+                std::vector<int> rows;
+                for (int64_t q = 0; q < ps.nq; ++q)
+                    if (flags[(size_t)q]) rows.push_back((int)q);
+                ix->last_recovered_queries = rows.empty() ? ps.nq : (int64_t)rows.size();
+                if (!rows.empty() && (int64_t)rows.size() < ps.nq) {
+                    int* dmap = ix->q_map + (size_t)ps.slot * OVF_ROWS;
+                    HIP_OK(hipMemcpy(dmap, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+                    rs.q_map = dmap;
+                    rs.nq = (int64_t)rows.size();
+                }
+            }
             const size_t ev_keep = ix->ev_used;
-            if (enqueue_search(ix, ps, false, pass, stream)) return -1;
+            if (enqueue_search(ix, rs, false, pass, stream)) return -1;
             ix->ev_used = ev_keep;  // recovery passes are not part of the launch accounting
             HIP_OK(hipStreamSynchronize(stream));
         }
@@ -529,7 +565,7 @@ int vodhip_index_search(vodhip_index_t* ix, const void* queries, int q_dtype, in
 int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
     if (!ix || !key) return fail("NULL argument");
     if (!strcmp(key, "cand_cap")) {
-        if (value < ROW_ALIGN || value > (1 << 15)) return fail("cand_cap must be in [256, 32768]");
+        if (value < ROW_ALIGN || value > (1 << 16)) return fail("cand_cap must be in [256, 65536]");
         ix->cand_cap = value;
     } else if (!strcmp(key, "dense_rows")) {
         if (value < ROW_ALIGN) return fail("dense_rows must be >= 256");
@@ -563,6 +599,8 @@ int vodhip_index_get_stat(const vodhip_index_t* ix, const char* key, int64_t* ou
         *out = ix->last_chunks;
     else if (!strcmp(key, "last_safe_reruns"))
         *out = ix->last_safe_reruns;
+    else if (!strcmp(key, "last_recovered_queries"))
+        *out = ix->last_recovered_queries;
     else if (!strcmp(key, "last_filter_launches"))
         *out = ix->last_filter_launches;
     else if (!strcmp(key, "last_filter_ns"))

@@ -18,6 +18,7 @@ struct FilterExtra {
     int n_qlab = 0;
     int sample_rstride = 0;           // GMAX launches: store rows between consecutive sampled rows (>= 1)
     int sample_groups = 0;            // GMAX launches: number of lane groups of the sample (= candidate slots per query)
+    const int* q_map = nullptr;       // recovery of a few queries: workspace row -> row of the caller's batch (q_label is indexed by the latter)
 };
 
 struct SearchWorkspace {
@@ -28,6 +29,7 @@ struct SearchWorkspace {
     float* thr_s = nullptr;          // [nq_pad] score of the current k-th best (-inf until k hits exist)
     key_t64* thr_key = nullptr;      // [nq_pad] key of the current k-th best (0 until k hits exist)
     unsigned int* overflow = nullptr;  // [1] set when a candidate buffer overflowed
+    unsigned int* ovf_q = nullptr;     // [nq] per query: its candidate list overflowed in some stage (set by the select kernel), or NULL
     int64_t nq_cap = 0;
     int64_t cap = 0;
     int64_t kp = 0;
@@ -41,16 +43,18 @@ struct SearchWorkspace {
 hipError_t launch_convert_rows(const void* src, int src_dtype, int64_t n_rows, int64_t dim, void* dst, int dst_dtype,
                                int64_t dst_stride, hipStream_t stream);
 // seed_scores / seed_ids ([nq, k] device, or NULL): a previous valid-but-incomplete result whose k-th score seeds the thresholds
+// q_map ([nq] device, or NULL): workspace row r is row q_map[r] of q_src / of the seed arrays
 hipError_t launch_search_prepare(const SearchWorkspace& ws, const void* q_src, int q_dtype, int64_t nq, int64_t dim,
                                  int store_dtype, int64_t nq_pad, int64_t dim_pad, bool clear_overflow,
-                                 const float* seed_scores, const int64_t* seed_ids, int k, hipStream_t stream);
+                                 const float* seed_scores, const int64_t* seed_ids, int k, const int* q_map, hipStream_t stream);
 hipError_t launch_filter(int store_dtype, int tile, int mode, const void* store, const void* q_pad, int64_t dim_pad,
                          int64_t row_begin, int64_t row_end, int64_t n_sample_tiles, int64_t nq, int64_t nq_pad,
                          const SearchWorkspace& ws, hipStream_t stream);
 // flags: 1 = final (sort; the top-k also leaves as float32 scores / int64 ids (+ id_base) in out_scores / out_ids [nq, k]),
 //        2 = threshold only (the candidates are GMAX group maxima: nothing enters the running top-k)
+//        q_map: result row r is written to row q_map[r] of out_scores / out_ids
 hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, int flags, hipStream_t stream,
-                         int64_t id_base = 0, float* out_scores = nullptr, int64_t* out_ids = nullptr);
+                         int64_t id_base = 0, float* out_scores = nullptr, int64_t* out_ids = nullptr, const int* q_map = nullptr);
 hipError_t launch_output(const SearchWorkspace& ws, int64_t nq, int k, int64_t id_base, float* out_scores,
                          int64_t* out_ids, hipStream_t stream);
 hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int64_t stride_s, int64_t stride_i, int n_shards,
