@@ -498,6 +498,38 @@ def test_clustered_row_order_needs_no_recovery(nq, k):
         assert ix.get_stat("last_overflow") == 0 and ix.get_stat("last_safe_reruns") == 0
 
 
+def test_only_the_overflowing_queries_are_searched_again():
+    """A few queries whose neighbours form one huge block overflow their candidate lists; the recovery pass re-searches
+    THEM (as a small batch, results written back through the query map), not the whole batch."""
+    rng = np.random.default_rng(17)
+    n, d, nq, k = 120_000, 64, 300, 50
+    x = rng.integers(-2, 3, size=(n, d)).astype(np.float16)
+    x[70_000:100_000, :8] = 8            # 30k near-identical rows: every one beats the background for the queries below
+    x[70_000:100_000, 8] = (np.arange(30_000) % 7).astype(np.float16)
+    q = rng.integers(-2, 3, size=(nq, d)).astype(np.float16)
+    hot = [3, 77, 150, 299]
+    q[hot, :8] = 8
+    q[hot, 8] = 1
+    with _index(x, cand_cap=4096) as ix:
+        _assert_exact(ix, q, x, k)
+        assert ix.get_stat("last_overflow") == 1
+        assert ix.get_stat("last_recovered_queries") == len(hot)
+    sub = np.full((nq, 1), -1, dtype=np.int32)  # the same through the subset path: labels follow the query map
+    sub[hot] = 1
+    labels = (np.arange(n) % 2).astype(np.int32)
+    from oracle.flat_ip import topk_desc_tiebreak
+
+    with _index(x, cand_cap=4096) as ix:
+        ix.set_row_labels(labels)
+        s, i = ix.search(torch.from_numpy(q).cuda(), k, subset=sub)
+    full = q.astype(np.float64) @ x.astype(np.float64).T
+    for r in hot:
+        full[r, labels != 1] = np.nan
+    rs, ri = topk_desc_tiebreak(full, k)
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(s.cpu().numpy(), rs)
+
+
 def test_stale_rows_beyond_ntotal_do_not_leak_into_the_bootstrap():
     """reset() keeps the old bytes in the store: the sampled rows of the bootstrap must all lie below ntotal."""
     big = np.full((50000, 64), 8, dtype=np.float16)

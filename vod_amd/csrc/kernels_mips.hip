@@ -713,7 +713,6 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
     do {
         const int take = min((int)n - done, room);
         const int total = kp + take;
-        const bool last_round = done + take >= (int)n;
         {
             for (int i = kp + tid; i < total; i += 256) keys[i] = cand[(size_t)q * cap + done + (i - kp)];
             __syncthreads();
