@@ -17,7 +17,7 @@ The reference functions exercised (paths relative to /root/reference/src):
   shard        vod_search/sharded_search.py:65-106,176-203
   stack        vod_types/retrieval.py:259-287
   io           vod_search/io.py:17-32
-  gradients    vod_models/vod_gradients/retrieval.py:30-243
+  gradients    vod_models/vod_gradients/retrieval.py:30-243 (incl. the auxiliary losses :94-150)
 """
 from __future__ import annotations
 
@@ -359,6 +359,57 @@ def gen_gradients() -> None:
     run("retrieval_grad_inbatch", 16, 96, 128, False, 0.1, False, 15)
 
 
+def gen_gradients_aux() -> None:
+    """The auxiliary losses of RetrievalGradients (retrieval.py:94-150), one fixture per term and one with all three."""
+    import torch
+
+    grad = M["gradients"]
+    RealmBatch = M["batch"].RealmBatch
+
+    def run(name, cfg, nq, nd, h, three_d, pad_frac, nopos_row, seed):
+        fn = grad.RetrievalGradients(**cfg)
+        g = torch.Generator().manual_seed(seed)
+        q = (0.3 * torch.randn(nq, h, generator=g, dtype=torch.float32)).requires_grad_(True)
+        s = torch.randn(*((nq, nd, h) if three_d else (nd, h)), generator=g, dtype=torch.float32, requires_grad=True)
+        score = torch.randn(nq, nd, generator=g)
+        pad = torch.rand(nq, nd, generator=g) < pad_frac
+        pad[:, 0] = False
+        score = score.masked_fill(pad, -float("inf"))
+        rel = (torch.rand(nq, nd, generator=g) < 0.25).long()
+        rel[:, 0] = 1
+        if nopos_row:
+            rel[1, :] = 0
+        sparse = (-2.0 + torch.randn(nq, nd, generator=g)).masked_fill(torch.rand(nq, nd, generator=g) < 0.2, float("nan"))
+        dense = torch.randn(nq, nd, generator=g).masked_fill(torch.rand(nq, nd, generator=g) < 0.2, float("nan"))
+        dummy = torch.zeros(1, dtype=torch.long)
+        batch = RealmBatch(
+            query__input_ids=dummy, query__attention_mask=dummy, query__id="", query__subset_ids=[], query__section_ids=[],
+            section__input_ids=dummy, section__attention_mask=dummy, section__id="",
+            section__relevance=rel, section__idx=torch.zeros(nq, nd, dtype=torch.long), section__score=score,
+            section__sparse=sparse, section__dense=dense, section__log_weight=torch.zeros(nq, nd),
+            section__lse_pos=torch.zeros(nq), section__lse_neg=torch.zeros(nq),
+        )
+        out = fn(batch=batch, query_encoding=q, section_encoding=s)
+        dq, ds = torch.autograd.grad(out.loss, [q, s])
+        diag = {k: v.detach().numpy() for k, v in out.diagnostics.items()}
+        _save(
+            name, {"three_d": three_d, "seed": seed, "config": cfg, "diagnostic_keys": list(out.diagnostics)},
+            q=q.detach().numpy(), s=s.detach().numpy(), score=score.numpy(), relevance=rel.numpy(),
+            sparse=sparse.numpy(), dense=dense.numpy(),
+            loss=out.loss.detach().numpy(), retriever_scores=out.retriever_scores.detach().numpy(),
+            dq=dq.numpy(), ds=ds.numpy(), **{f"diag_{k}": v for k, v in diag.items()},
+        )
+
+    run("retrieval_aux_guidance_sparse", {"guidance": "sparse", "guidance_weight": 0.5}, 5, 12, 32, False, 0.2, False, 31)
+    run("retrieval_aux_guidance_zero", {"guidance": "zero", "guidance_weight": 0.25}, 4, 9, 16, True, 0.3, False, 32)
+    run("retrieval_aux_self_supervision", {"self_supervision_weight": 0.7}, 6, 10, 24, False, 0.2, False, 33)
+    run("retrieval_aux_score_decay", {"score_decay": 0.01}, 5, 11, 16, True, 0.3, False, 34)
+    run("retrieval_aux_all", {"guidance": "sparse", "guidance_weight": 0.3, "self_supervision_weight": 0.4, "score_decay": 0.02},
+        16, 96, 64, False, 0.15, False, 35)
+    run("retrieval_aux_all_nopos", {"guidance": "zero", "guidance_weight": 0.3, "self_supervision_weight": 0.4, "score_decay": 0.02},
+        5, 12, 32, False, 0.2, True, 36)
+
+
 def gen_flat_ip() -> None:
     """Build-owned (NOT from the reference: faiss is absent) exact fixtures: small-integer fp16 vectors."""
     sys.path.insert(0, str(HERE.parent.parent))
@@ -374,12 +425,18 @@ def gen_flat_ip() -> None:
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["gradients_aux"]:  # add the round-2 fixtures without touching the others
+        manifest.update(json.loads((HERE / "manifest.json").read_text()))
+        gen_gradients_aux()
+        (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True))
+        raise SystemExit(0)
     gen_merge()
     gen_normalize()
     gen_gather()
     gen_sampling()
     gen_search_plumbing()
     gen_gradients()
+    gen_gradients_aux()
     gen_flat_ip()
     (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True))
     total = sum(p.stat().st_size for p in HERE.glob("*.npz"))

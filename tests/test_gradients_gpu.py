@@ -92,8 +92,68 @@ def test_half_precision_encodings(dtype):
     assert dq.dtype == dtype and ds.dtype == dtype
 
 
-def test_auxiliary_losses_are_rejected():
+AUX_NAMES = ["retrieval_aux_guidance_sparse", "retrieval_aux_guidance_zero", "retrieval_aux_self_supervision",
+             "retrieval_aux_score_decay", "retrieval_aux_all", "retrieval_aux_all_nopos"]
+
+
+@pytest.mark.parametrize("name", AUX_NAMES)
+def test_auxiliary_losses_match_reference_golden(name):
+    """The reference's guidance / self-supervision / score-decay terms (retrieval.py:94-150) as extra terms of the fused
+    row kernel: loss, every diagnostic (same keys, same order) and both gradients vs reference-generated vectors."""
+    import json
+
     from vod_amd.gradients import RetrievalGradients
 
-    with pytest.raises(NotImplementedError):
-        RetrievalGradients(guidance_weight=0.1)
+    g = np.load(GOLDEN / f"{name}.npz")
+    params = json.loads((GOLDEN / "manifest.json").read_text())[name]["params"]
+    qt = torch.tensor(g["q"], device="cuda", requires_grad=True)
+    st = torch.tensor(g["s"], device="cuda", requires_grad=True)
+    batch = {k: torch.tensor(g[v], device="cuda") for k, v in
+             [("section__score", "score"), ("section__relevance", "relevance"), ("section__sparse", "sparse"), ("section__dense", "dense")]}
+    out = RetrievalGradients(**params["config"])(batch=batch, query_encoding=qt, section_encoding=st)
+    out.loss.backward()
+    np.testing.assert_allclose(out.loss.item(), g["loss"], **TOL)
+    assert list(out.diagnostics) == params["diagnostic_keys"]
+    for key in params["diagnostic_keys"]:
+        np.testing.assert_allclose(out.diagnostics[key].item(), g[f"diag_{key}"], **TOL)
+    np.testing.assert_allclose(qt.grad.cpu().numpy(), g["dq"], **TOL)
+    np.testing.assert_allclose(st.grad.cpu().numpy(), g["ds"], **TOL)
+
+
+@pytest.mark.parametrize("three_d", [False, True])
+def test_auxiliary_losses_match_fp64_oracle_at_c5_shape(three_d):
+    from oracle.gradients import retrieval_gradients
+    from vod_amd.gradients import RetrievalGradients
+
+    rng = np.random.default_rng(9)
+    B, D, H = (64, 32, 768) if three_d else (64, 2048, 256)
+    q = (rng.normal(size=(B, H)) / np.sqrt(H)).astype(np.float32)
+    s = rng.normal(size=(B, D, H) if three_d else (D, H)).astype(np.float32)
+    score = rng.normal(size=(B, D)).astype(np.float32)
+    score[rng.uniform(size=(B, D)) < 0.1] = -np.inf
+    score[:, 0] = 0.5
+    rel = (rng.uniform(size=(B, D)) < 0.05).astype(np.int64)
+    rel[:, 0] = 1
+    sparse = (rng.gamma(2.0, 4.0, size=(B, D)) - 12).astype(np.float32)
+    sparse[rng.uniform(size=(B, D)) < 0.3] = np.nan
+    cfg = dict(guidance="sparse", guidance_weight=0.2, self_supervision_weight=0.3, score_decay=0.01)
+    ref = retrieval_gradients(q, s, score, rel, sparse, None, **cfg)
+    qt = torch.tensor(q, device="cuda", requires_grad=True)
+    st = torch.tensor(s, device="cuda", requires_grad=True)
+    batch = {"section__score": torch.tensor(score, device="cuda"), "section__relevance": torch.tensor(rel, device="cuda"),
+             "section__sparse": torch.tensor(sparse, device="cuda"), "section__dense": None}
+    out = RetrievalGradients(**cfg)(batch=batch, query_encoding=qt, section_encoding=st)
+    out.loss.backward()
+    np.testing.assert_allclose(out.loss.item(), ref["loss"], **TOL)
+    for key in ("sparse_guidance", "self_supervision", "score_decay", "kl_score", "kl_sparse"):
+        np.testing.assert_allclose(out.diagnostics[key].item(), ref[key], **TOL)
+    assert "kl_dense" not in out.diagnostics
+    np.testing.assert_allclose(qt.grad.cpu().numpy(), ref["dq"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(st.grad.cpu().numpy(), ref["ds"], rtol=2e-4, atol=2e-5)
+
+
+def test_invalid_guidance_type_is_rejected():
+    from vod_amd.gradients import RetrievalGradients
+
+    with pytest.raises(ValueError, match="guidance"):
+        RetrievalGradients(guidance="dense", guidance_weight=0.1)

@@ -504,12 +504,11 @@ def test_only_the_overflowing_queries_are_searched_again():
     rng = np.random.default_rng(17)
     n, d, nq, k = 120_000, 64, 300, 50
     x = rng.integers(-2, 3, size=(n, d)).astype(np.float16)
-    x[70_000:100_000, :8] = 8            # 30k near-identical rows: every one beats the background for the queries below
-    x[70_000:100_000, 8] = (np.arange(30_000) % 7).astype(np.float16)
+    x[70_000:100_000] = x[70_000]        # 30k IDENTICAL rows (duplicated sections): for the queries below every one of
+    x[70_000:100_000, :8] = 8            # them ties at the top score, so no threshold can keep them out of the lists
     q = rng.integers(-2, 3, size=(nq, d)).astype(np.float16)
     hot = [3, 77, 150, 299]
-    q[hot, :8] = 8
-    q[hot, 8] = 1
+    q[hot] = x[70_000]
     with _index(x, cand_cap=4096) as ix:
         _assert_exact(ix, q, x, k)
         assert ix.get_stat("last_overflow") == 1

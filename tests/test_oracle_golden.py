@@ -126,6 +126,24 @@ def test_gradients_match_reference(name):
         np.testing.assert_allclose(out[k], g[k], **tol)
 
 
+AUX_NAMES = ["retrieval_aux_guidance_sparse", "retrieval_aux_guidance_zero", "retrieval_aux_self_supervision",
+             "retrieval_aux_score_decay", "retrieval_aux_all", "retrieval_aux_all_nopos"]
+
+
+@pytest.mark.parametrize("name", AUX_NAMES)
+def test_auxiliary_losses_match_reference(name):
+    """RetrievalGradients._auxiliary_losses (retrieval.py:94-150): guidance (huber), self-supervision, score decay."""
+    g = _load(name)
+    cfg = MANIFEST[name]["params"]["config"]
+    out = ograd.retrieval_gradients(g["q"], g["s"], g["score"], g["relevance"], g["sparse"], g["dense"], **cfg)
+    tol = dict(rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out["loss"], g["loss"], **tol)  # NaN == NaN: a row without positives poisons the loss
+    np.testing.assert_allclose(out["dq"], g["dq"], **tol)
+    np.testing.assert_allclose(out["ds"], g["ds"], **tol)
+    for key in MANIFEST[name]["params"]["diagnostic_keys"]:
+        np.testing.assert_allclose(out[key], g[f"diag_{key}"], **tol)
+
+
 @pytest.mark.parametrize("name", ["flat_ip_exact_small", "flat_ip_exact_768"])
 def test_flat_ip_fixture_selfconsistent(name):
     """Build-owned fixture (faiss parity unpinned): blocked fp64 top-k == full-matrix lexsort, ties -> smaller id."""

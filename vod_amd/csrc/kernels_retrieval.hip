@@ -17,7 +17,8 @@
 namespace vodhip {
 
 constexpr int RT_THREADS = 256;
-constexpr int WS_STRIDE = 8;  // floats of workspace per row: loss, has_pos, kl_score, kl_sparse, kl_dense
+constexpr int WS_STRIDE = 8;       // floats of workspace per row: loss, has_pos, kl_score, kl_sparse, kl_dense
+constexpr int WS_STRIDE_AUX = 16;  // ... + huber sum, huber count, cross entropy, row counted, score^2 sum, finite count
 
 template <int DT>
 __device__ __forceinline__ float ld_enc(const void* p, int64_t i) {
@@ -90,7 +91,7 @@ template <int DT, bool S3D, bool PRE = false>
 __global__ __launch_bounds__(RT_THREADS) void retrieval_forward_kernel(
     const void* __restrict__ q, const void* __restrict__ s, int D, int H, const float* __restrict__ score,
     const int64_t* __restrict__ relevance, const float* __restrict__ sparse, const float* __restrict__ dense,
-    float* __restrict__ retriever_scores, float* __restrict__ d_scores, float* __restrict__ workspace) {
+    float* __restrict__ retriever_scores, float* __restrict__ d_scores, float* __restrict__ workspace, RetrievalAux aux) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qrow = (float*)smem;   // [H]
     float* S = qrow + H;          // [D] scores -> log-probs
@@ -173,6 +174,90 @@ __global__ __launch_bounds__(RT_THREADS) void retrieval_forward_kernel(
         d_scores[b * D + d] = g;
     }
 
+    // 4b. auxiliary losses (retrieval.py:94-150), all functions of the row of scores / log-probs that is in LDS now.
+    //     Each writes its row partials and its UNNORMALISED gradient w.r.t. the scores; the finalize kernel divides by
+    //     the batch-wide counts and adds the weighted terms to the loss and to d_scores.
+    const int ws_stride = aux.enabled ? WS_STRIDE_AUX : WS_STRIDE;
+    if (aux.enabled) {
+        const int64_t n_el = (int64_t)gridDim.x * D;
+        float* w = workspace + b * ws_stride;
+        // guidance: huber(logp - ref) over entries finite in both, ref = sparse scores | zeros (:116-126,180-183)
+        if (aux.w_guidance > 0.f) {
+            float hs = 0.f, hc = 0.f, gh = 0.f;
+            for (int d = tid; d < D; d += RT_THREADS) {
+                const float lp = S[d];
+                const float ref = aux.guidance_type == 1 ? sparse[b * D + d] : 0.f;
+                if (finite_f(lp) && finite_f(ref)) {
+                    const float x = lp - ref, ax = fabsf(x);
+                    hs += ax < 1.f ? 0.5f * x * x : ax - 0.5f;
+                    hc += 1.f;
+                    gh += fminf(1.f, fmaxf(-1.f, x));
+                }
+            }
+            hs = block_sum(hs, red);
+            hc = block_sum(hc, red);
+            gh = block_sum(gh, red);
+            for (int d = tid; d < D; d += RT_THREADS) {  // log-softmax backward: g - p * sum(g)
+                const float lp = S[d];
+                const float ref = aux.guidance_type == 1 ? sparse[b * D + d] : 0.f;
+                const float g = (finite_f(lp) && finite_f(ref)) ? fminf(1.f, fmaxf(-1.f, lp - ref)) : 0.f;
+                const float p = finite_f(lp) ? expf(lp) : 0.f;
+                aux.grad[b * D + d] = g - p * gh;
+            }
+            if (tid == 0) { w[8] = hs; w[9] = hc; }
+        }
+        // self-supervision: cross entropy of the positives' log-probs against their own arg-max (:129-140)
+        if (aux.w_self > 0.f) {
+            float lm = -__builtin_inff();
+            for (int d = tid; d < D; d += RT_THREADS) {
+                const float sc = score_row[d];
+                const bool pos = !(__builtin_isinf(sc) && sc < 0) && relevance[b * D + d] > 0;
+                if (pos) lm = fmaxf(lm, S[d]);
+            }
+            lm = block_max(lm, red);
+            float first = -1e30f, se2 = 0.f, n_p = 0.f;
+            for (int d = tid; d < D; d += RT_THREADS) {
+                const float sc = score_row[d];
+                const bool pos = !(__builtin_isinf(sc) && sc < 0) && relevance[b * D + d] > 0;
+                if (pos) {
+                    n_p += 1.f;
+                    se2 += expf(S[d] - lm);
+                    if (S[d] == lm) first = fmaxf(first, -(float)d);  // first arg-max = smallest index
+                }
+            }
+            first = block_max(first, red);
+            se2 = block_sum(se2, red);
+            n_p = block_sum(n_p, red);
+            const int idx = (int)(-first);
+            const bool in_r = npos > 0.f;  // `n_positives > 0` AFTER the fallback (:57,138): a row without positives stays in
+            const float ce = n_p > 0.f ? logf(se2) : __builtin_nanf("");
+            for (int d = tid; d < D; d += RT_THREADS) {
+                const float sc = score_row[d];
+                const bool pos = !(__builtin_isinf(sc) && sc < 0) && relevance[b * D + d] > 0;
+                float g = 0.f;
+                // (a row without positives makes the LOSS NaN - log-softmax of an all -inf row - but sends no gradient:
+                //  `torch.where(targets > 0, logp, -inf)` selects none of its log-probs)
+                if (in_r && n_p > 0.f && pos) g = expf(S[d] - lm) / se2 - (d == idx ? 1.f : 0.f);
+                aux.grad[n_el + b * D + d] = g;  // sums to zero over the row: the log-softmax backward leaves it unchanged
+            }
+            if (tid == 0) { w[10] = in_r ? ce : 0.f; w[11] = in_r ? 1.f : 0.f; }
+        }
+        // score decay: mean of the squared finite scores (:143-145)
+        if (aux.w_decay > 0.f) {
+            float ss = 0.f, sn = 0.f;
+            for (int d = tid; d < D; d += RT_THREADS) {
+                const float v = retriever_scores[b * D + d];
+                const bool fin = finite_f(v);
+                ss += fin ? v * v : 0.f;
+                sn += fin ? 1.f : 0.f;
+                aux.grad[2 * n_el + b * D + d] = fin ? 2.f * v : 0.f;
+            }
+            ss = block_sum(ss, red);
+            sn = block_sum(sn, red);
+            if (tid == 0) { w[12] = ss; w[13] = sn; }
+        }
+    }
+
     // 5. KL diagnostics against the sampling distributions (retrieval.py:79-86,225-243)
     //    p side: log-softmax of the finite model log-probs
     float pm = -__builtin_inff();
@@ -194,7 +279,7 @@ __global__ __launch_bounds__(RT_THREADS) void retrieval_forward_kernel(
     const float kl1 = sparse ? row_kld(sparse + b * D, S, D, red) : __builtin_nanf("");
     const float kl2 = dense ? row_kld(dense + b * D, S, D, red) : __builtin_nanf("");
     if (tid == 0) {
-        float* w = workspace + b * WS_STRIDE;
+        float* w = workspace + b * ws_stride;
         w[0] = has_pos ? row_loss : 0.f;
         w[1] = has_pos ? 1.f : 0.f;
         w[2] = kl0;
@@ -205,17 +290,25 @@ __global__ __launch_bounds__(RT_THREADS) void retrieval_forward_kernel(
 
 __global__ __launch_bounds__(RT_THREADS) void retrieval_finalize_kernel(const float* __restrict__ workspace, int B,
                                                                         int64_t n_elems, float* __restrict__ d_scores,
-                                                                        float* __restrict__ loss, float* __restrict__ kl) {
+                                                                        float* __restrict__ loss, float* __restrict__ kl,
+                                                                        RetrievalAux aux) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
+    const int stride = aux.enabled ? WS_STRIDE_AUX : WS_STRIDE;
     float l = 0.f, n = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
+    float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // huber sum / count, cross-entropy sum / rows, score^2 sum / count
     for (int b = tid; b < B; b += RT_THREADS) {
-        const float* w = workspace + (int64_t)b * WS_STRIDE;
+        const float* w = workspace + (int64_t)b * stride;
         l += w[0];
         n += w[1];
         k0 += w[2];
         k1 += w[3];
         k2 += w[4];
+        if (aux.enabled) {
+            if (aux.w_guidance > 0.f) { a[0] += w[8]; a[1] += w[9]; }
+            if (aux.w_self > 0.f) { a[2] += w[10]; a[3] += w[11]; }
+            if (aux.w_decay > 0.f) { a[4] += w[12]; a[5] += w[13]; }
+        }
     }
     l = block_sum(l, red);
     n = block_sum(n, red);
@@ -223,14 +316,37 @@ __global__ __launch_bounds__(RT_THREADS) void retrieval_finalize_kernel(const fl
     k1 = block_sum(k1, red);
     k2 = block_sum(k2, red);
     const float inv = n > 0.f ? 1.f / n : __builtin_nanf("");
+    float c_g = 0.f, c_s = 0.f, c_d = 0.f;  // weight / count of each auxiliary mean
+    float total = n > 0.f ? l / n : __builtin_nanf("");  // retrieval.py:171-176
+    if (aux.enabled) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a[i] = block_sum(a[i], red);
+        const float nan = __builtin_nanf("");
+        const float lg = a[1] > 0.f ? a[0] / a[1] : nan, ls = a[3] > 0.f ? a[2] / a[3] : nan, ld = a[5] > 0.f ? a[4] / a[5] : nan;
+        if (aux.w_guidance > 0.f) { total += aux.w_guidance * lg; c_g = a[1] > 0.f ? aux.w_guidance / a[1] : nan; }
+        if (aux.w_self > 0.f) { total += aux.w_self * ls; c_s = a[3] > 0.f ? aux.w_self / a[3] : nan; }
+        if (aux.w_decay > 0.f) { total += aux.w_decay * ld; c_d = a[5] > 0.f ? aux.w_decay / a[5] : nan; }
+        if (blockIdx.x == 0 && tid == 0) {
+            aux.out[0] = aux.w_guidance > 0.f ? lg : nan;
+            aux.out[1] = aux.w_self > 0.f ? ls : nan;
+            aux.out[2] = aux.w_decay > 0.f ? ld : nan;
+        }
+    }
     if (blockIdx.x == 0 && tid == 0) {
-        loss[0] = n > 0.f ? l / n : __builtin_nanf("");  // retrieval.py:171-176
+        loss[0] = total;
         kl[0] = k0 / B;
         kl[1] = k1 / B;
         kl[2] = k2 / B;
     }
-    for (int64_t i = (int64_t)blockIdx.x * RT_THREADS + tid; i < n_elems; i += (int64_t)gridDim.x * RT_THREADS)
-        d_scores[i] *= inv;
+    for (int64_t i = (int64_t)blockIdx.x * RT_THREADS + tid; i < n_elems; i += (int64_t)gridDim.x * RT_THREADS) {
+        float g = d_scores[i] * inv;
+        if (aux.enabled) {
+            if (aux.w_guidance > 0.f) g += c_g * aux.grad[i];
+            if (aux.w_self > 0.f) g += c_s * aux.grad[n_elems + i];
+            if (aux.w_decay > 0.f) g += c_d * aux.grad[2 * n_elems + i];
+        }
+        d_scores[i] = g;
+    }
 }
 
 // dq[b,h] = go * sum_d dS[b,d] * s[(b,)d,h]
@@ -369,7 +485,7 @@ static hipError_t launch_small_gemm(int dta, int dtb, const void* A, int64_t sa_
 hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype, int sections_3d, int64_t B, int64_t D,
                                     int64_t H, const float* score, const int64_t* relevance, const float* sparse,
                                     const float* dense, float* retriever_scores, float* d_scores, float* loss, float* kl,
-                                    float* workspace, hipStream_t stream) {
+                                    float* workspace, const RetrievalAux& aux, hipStream_t stream) {
     const size_t lds = (size_t)(H + D + 4) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (!sections_3d) {
@@ -383,7 +499,7 @@ hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype,
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);           \
         if (e != hipSuccess) return e;                                                                                \
         hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(RT_THREADS), lds, stream, q, s, (int)D, (int)H, score,       \
-                           relevance, sparse, dense, retriever_scores, d_scores, workspace);                          \
+                           relevance, sparse, dense, retriever_scores, d_scores, workspace, aux);                     \
     }
         VOD_FWDP(0) VOD_FWDP(1) VOD_FWDP(2)
 #undef VOD_FWDP
@@ -392,7 +508,7 @@ hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype,
         const int64_t n_el = B * D;
         const unsigned blk = (unsigned)std::min<int64_t>(1024, (n_el + RT_THREADS - 1) / RT_THREADS);
         hipLaunchKernelGGL(retrieval_finalize_kernel, dim3(blk), dim3(RT_THREADS), 0, stream, workspace, (int)B, n_el, d_scores,
-                           loss, kl);
+                           loss, kl, aux);
         return hipGetLastError();
     }
 #define VOD_FWD(DT, S3)                                                                                              \
@@ -401,7 +517,7 @@ hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype,
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         if (e != hipSuccess) return e;                                                                               \
         hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(RT_THREADS), lds, stream, q, s, (int)D, (int)H, score,      \
-                           relevance, sparse, dense, retriever_scores, d_scores, workspace);                         \
+                           relevance, sparse, dense, retriever_scores, d_scores, workspace, aux);                    \
     }
     VOD_FWD(0, false) VOD_FWD(0, true) VOD_FWD(1, false) VOD_FWD(1, true) VOD_FWD(2, false) VOD_FWD(2, true)
 #undef VOD_FWD
@@ -410,7 +526,7 @@ hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype,
     const int64_t n_elems = B * D;
     const unsigned blocks = (unsigned)std::min<int64_t>(1024, (n_elems + RT_THREADS - 1) / RT_THREADS);
     hipLaunchKernelGGL(retrieval_finalize_kernel, dim3(blocks), dim3(RT_THREADS), 0, stream, workspace, (int)B, n_elems,
-                       d_scores, loss, kl);
+                       d_scores, loss, kl, aux);
     return hipGetLastError();
 }
 

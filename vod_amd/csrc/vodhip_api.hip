@@ -683,7 +683,35 @@ int vodhip_retrieval_forward(const void* q, const void* s, int enc_dtype, int se
     if (D > 16384) return fail("D=%lld exceeds 16384 sections per row", (long long)D);
     if (enc_dtype < 0 || enc_dtype > 2) return fail("invalid enc_dtype");
     HIP_OK(launch_retrieval_forward(q, s, enc_dtype, sections_3d, B, D, H, score, relevance, sparse, dense,
-                                    retriever_scores, d_scores, loss, kl, workspace, (hipStream_t)stream));
+                                    retriever_scores, d_scores, loss, kl, workspace, RetrievalAux(), (hipStream_t)stream));
+    return 0;
+}
+
+int vodhip_retrieval_forward_aux(const void* q, const void* s, int enc_dtype, int sections_3d, int64_t B, int64_t D, int64_t H,
+                                 const float* score, const int64_t* relevance, const float* sparse, const float* dense,
+                                 int guidance_type, float guidance_weight, float self_supervision_weight, float score_decay,
+                                 float* retriever_scores, float* d_scores, float* loss, float* kl, float* aux_losses,
+                                 float* aux_grad, float* workspace, void* stream) {
+    if (!q || !s || !score || !relevance || !retriever_scores || !d_scores || !loss || !kl || !workspace || !aux_losses)
+        return fail("NULL argument");
+    if (B <= 0 || D <= 0 || H <= 0) return fail("invalid sizes");
+    if (D > 16384) return fail("D=%lld exceeds 16384 sections per row", (long long)D);
+    if (enc_dtype < 0 || enc_dtype > 2) return fail("invalid enc_dtype");
+    if (guidance_type != 0 && guidance_type != 1) return fail("guidance_type must be 0 (zero) or 1 (sparse)");
+    if (guidance_weight < 0 || self_supervision_weight < 0 || score_decay < 0) return fail("negative auxiliary weight");
+    const bool any = guidance_weight > 0 || self_supervision_weight > 0 || score_decay > 0;
+    if (any && !aux_grad) return fail("aux_grad (3*B*D floats) is required when an auxiliary weight is > 0");
+    if (guidance_weight > 0 && guidance_type == 1 && !sparse) return fail("guidance='sparse' needs the sparse scores");
+    RetrievalAux aux;
+    aux.enabled = 1;
+    aux.guidance_type = guidance_type;
+    aux.w_guidance = guidance_weight;
+    aux.w_self = self_supervision_weight;
+    aux.w_decay = score_decay;
+    aux.grad = aux_grad;
+    aux.out = aux_losses;
+    HIP_OK(launch_retrieval_forward(q, s, enc_dtype, sections_3d, B, D, H, score, relevance, sparse, dense,
+                                    retriever_scores, d_scores, loss, kl, workspace, aux, (hipStream_t)stream));
     return 0;
 }
 

@@ -84,10 +84,18 @@ struct HybridArgs {
 hipError_t launch_merge_hybrid(const HybridArgs& a, hipStream_t stream);
 
 // ---- launchers (kernels_retrieval.hip) --------------------------------------------------------
+// auxiliary losses of the retrieval objective (passed by value; `enabled` = 0 leaves the plain loss and an 8-float row stride)
+struct RetrievalAux {
+    int enabled = 0;
+    int guidance_type = 0;   // 0 = "zero", 1 = "sparse"
+    float w_guidance = 0.f, w_self = 0.f, w_decay = 0.f;
+    float* grad = nullptr;   // [3][B*D] scratch: unnormalised gradients of the three terms w.r.t. the scores
+    float* out = nullptr;    // [3] loss values: guidance, self-supervision, score decay (NaN where the weight is 0)
+};
 hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype, int sections_3d, int64_t B, int64_t D,
                                     int64_t H, const float* score, const int64_t* relevance, const float* sparse,
                                     const float* dense, float* retriever_scores, float* d_scores, float* loss,
-                                    float* kl, float* workspace, hipStream_t stream);
+                                    float* kl, float* workspace, const RetrievalAux& aux, hipStream_t stream);
 hipError_t launch_retrieval_backward(const void* q, const void* s, int enc_dtype, int sections_3d, int64_t B, int64_t D,
                                      int64_t H, const float* d_scores, const float* grad_out, float* dq, float* ds,
                                      hipStream_t stream);

@@ -5,9 +5,9 @@ constructor, same keyword-only call `(batch, query_encoding, section_encoding)`,
 `retriever_scores`, `diagnostics` with kl_score / kl_sparse / kl_dense).  The ~15 torch kernels of the
 reference's forward (einsum, masked_fill, log_softmax, targets, loss, three KLs) and the autograd backward
 become one fused forward launch (+ finalize) and two backward launches, wrapped in a
-`torch.autograd.Function` so `loss.backward()` keeps working.  Auxiliary losses (guidance,
-self-supervision, score decay; all weight 0 in the shipped config) are not implemented: a non-zero weight
-raises.
+`torch.autograd.Function` so `loss.backward()` keeps working.  The auxiliary losses (guidance,
+self-supervision, score decay: retrieval.py:94-150; all weight 0 in the shipped config) are extra terms of the same
+row kernel: values in `diagnostics`, gradients folded into the same dLoss/dScores.
 """
 from __future__ import annotations
 
@@ -30,7 +30,7 @@ class RealmOutput:
 
 class _RetrievalLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, s, score, relevance, sparse, dense):  # noqa: ANN001
+    def forward(ctx, q, s, score, relevance, sparse, dense, aux_cfg=(0, 0.0, 0.0, 0.0)):  # noqa: ANN001
         lib = _native.load_library()
         if not q.is_cuda:
             raise _native.NativeLibraryError("RetrievalGradients needs device tensors (there is no CPU path)")
@@ -53,24 +53,29 @@ class _RetrievalLoss(torch.autograd.Function):
         d_scores = torch.empty((B, D), dtype=torch.float32, device=dev)
         loss = torch.empty((1,), dtype=torch.float32, device=dev)
         kl = torch.empty((3,), dtype=torch.float32, device=dev)
-        work = torch.empty((8 * B,), dtype=torch.float32, device=dev)
+        g_type, w_g, w_ss, w_sd = aux_cfg
+        any_aux = w_g > 0 or w_ss > 0 or w_sd > 0
+        work = torch.empty((16 * B,), dtype=torch.float32, device=dev)
+        aux = torch.full((3,), float("nan"), dtype=torch.float32, device=dev)
+        aux_grad = torch.empty((3, B, D), dtype=torch.float32, device=dev) if any_aux else None
         with torch.cuda.device(dev):
             _native.check(
-                lib.vodhip_retrieval_forward(
+                lib.vodhip_retrieval_forward_aux(
                     qc.data_ptr(), sc.data_ptr(), _native.torch_dtype_code(enc), int(three_d), B, D, H,
                     score_c.data_ptr(), rel_c.data_ptr(),
                     None if sparse_c is None else sparse_c.data_ptr(), None if dense_c is None else dense_c.data_ptr(),
-                    scores.data_ptr(), d_scores.data_ptr(), loss.data_ptr(), kl.data_ptr(), work.data_ptr(),
-                    _native.current_stream_ptr(dev),
+                    int(g_type), float(w_g), float(w_ss), float(w_sd),
+                    scores.data_ptr(), d_scores.data_ptr(), loss.data_ptr(), kl.data_ptr(), aux.data_ptr(),
+                    None if aux_grad is None else aux_grad.data_ptr(), work.data_ptr(), _native.current_stream_ptr(dev),
                 )
             )
         ctx.save_for_backward(qc, sc, d_scores)
         ctx.meta = (enc, three_d, B, D, H, q.dtype, s.dtype)
-        ctx.mark_non_differentiable(scores, kl)
-        return loss.reshape(()), scores, kl
+        ctx.mark_non_differentiable(scores, kl, aux)
+        return loss.reshape(()), scores, kl, aux
 
     @staticmethod
-    def backward(ctx, g_loss, _g_scores, _g_kl):  # noqa: ANN001
+    def backward(ctx, g_loss, _g_scores, _g_kl, _g_aux):  # noqa: ANN001
         lib = _native.load_library()
         qc, sc, d_scores = ctx.saved_tensors
         enc, three_d, B, D, H, q_dt, s_dt = ctx.meta
@@ -85,7 +90,7 @@ class _RetrievalLoss(torch.autograd.Function):
                     d_scores.data_ptr(), go.data_ptr(), dq.data_ptr(), ds.data_ptr(), _native.current_stream_ptr(dev),
                 )
             )
-        return dq.to(q_dt), ds.to(s_dt), None, None, None, None
+        return dq.to(q_dt), ds.to(s_dt), None, None, None, None, None
 
 
 class RetrievalGradients:
@@ -93,8 +98,8 @@ class RetrievalGradients:
 
     def __init__(self, guidance: str = "zero", guidance_weight: float = 0.0, self_supervision_weight: float = 0.0,
                  score_decay: float = 0.0):
-        if guidance_weight > 0 or self_supervision_weight > 0 or score_decay > 0:
-            raise NotImplementedError("auxiliary losses (guidance / self-supervision / score decay) are outside the fused path")
+        if guidance not in ("zero", "sparse"):
+            raise ValueError(f"guidance must be 'zero' or 'sparse', got {guidance!r}")  # the reference's GuidanceType (:11)
         self.guidance = guidance
         self.guidance_weight = guidance_weight
         self.self_supervision_weight = self_supervision_weight
@@ -103,11 +108,19 @@ class RetrievalGradients:
     def __call__(self, *, batch: typ.Any, query_encoding: torch.Tensor, section_encoding: torch.Tensor,
                  lm_logits: None | torch.Tensor = None) -> RealmOutput:  # noqa: ARG002
         get = (lambda k: batch.get(k)) if isinstance(batch, dict) else (lambda k: getattr(batch, k, None))
-        loss, scores, kl = _RetrievalLoss.apply(
+        loss, scores, kl, aux = _RetrievalLoss.apply(
             query_encoding, section_encoding, get("section__score"), get("section__relevance"),
             get("section__sparse"), get("section__dense"),
+            (1 if self.guidance == "sparse" else 0, float(self.guidance_weight), float(self.self_supervision_weight), float(self.score_decay)),
         )
-        diagnostics = {"kl_score": kl[0]}
+        diagnostics = {}
+        if self.guidance_weight > 0:  # insertion order and keys of the reference's `_auxiliary_losses` (:104-118)
+            diagnostics[f"{self.guidance}_guidance"] = aux[0]
+        if self.self_supervision_weight > 0:
+            diagnostics["self_supervision"] = aux[1]
+        if self.score_decay > 0:
+            diagnostics["score_decay"] = aux[2]
+        diagnostics["kl_score"] = kl[0]
         if get("section__sparse") is not None:
             diagnostics["kl_sparse"] = kl[1]
         if get("section__dense") is not None:
