@@ -302,7 +302,17 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
     // FILTER: tile xt = rows [row_begin + xt*256, +256).  GMAX: tile xt = the 8 lane groups xt*8 .. xt*8+7 of a stratified
     // row sample (see the a_src set-up; every sampled row lies below ntotal by construction of the schedule).
     const size_t tile_rows_stride = MODE == MODE_GMAX ? (size_t)8 * (size_t)ex.sample_rstride : (size_t)BM;
-    const size_t tile_step_bytes = (size_t)xt_step * tile_rows_stride * dim_pad * 2;
+    size_t tile_step_bytes = (size_t)xt_step * tile_rows_stride * dim_pad * 2;
+#ifdef VODHIP_ABLATION  // timing-only knobs of diagnostic builds (`make ABLATION=1`, "kflags" parameter); results are wrong with bit 0 / 3
+    const bool abl_l2hot = (ex.flags & 1) != 0;      // every workgroup re-reads the same 16 corpus tiles: no HBM first touch
+    const bool abl_dma_early = (ex.flags & 2) != 0;  // all LDS-DMA of the next slice right after the barrier
+    const bool abl_prio = (ex.flags & 4) != 0;       // static s_setprio 1 for waves 4..7
+    const bool abl_nosurv = (ex.flags & 8) != 0;     // thresholds +inf: epilogue floor
+    if (abl_l2hot) tile_step_bytes = 0;
+    if (abl_prio && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+#else
+    constexpr bool abl_l2hot = false, abl_dma_early = false, abl_nosurv = false;
+#endif
 
     const int st_row = lane >> 3, st_slot = lane & 7;
     const char* a_src[NA];
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
 #pragma unroll
     for (int t = 0; t < NA; ++t) {
         const int r = (wave * NA + t) * RPI + st_row;
-        size_t grow = (size_t)row_begin + (size_t)xt0 * BM + r;
+        size_t grow = (size_t)row_begin + (size_t)(abl_l2hot ? (xt0 & 15) : xt0) * BM + r;
         if constexpr (MODE == MODE_GMAX) {
             // tile row r = wm'*128 + i*16 + 4*fq' + rr is member (i, rr) of lane group (wm', fq'): sample index =
             // member * n_groups + group id, i.e. every group holds ONE row of each of 32 strata of the store
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
 #pragma unroll
     for (int j = 0; j < NB16; ++j) {
         const int q = q0 + wn * TN + j * 16 + fr;
-        thr[j] = (MODE == MODE_FILTER && q < nq) ? thr_s[q] : __builtin_inff();
+        thr[j] = (MODE == MODE_FILTER && q < nq && !abl_nosurv) ? thr_s[q] : __builtin_inff();
     }
 #pragma unroll
     for (int j = 0; j < NB16; ++j) asm volatile("" : "+v"(thr[j]));
@@ -503,15 +513,16 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
         int kbyte;
         next_fetch(it, t, pre, kbyte);
         const int nslot = (g + 1) & 1;
+        if (abl_dma_early && pre) stage_part(nslot, kbyte, 0, 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             Frags f;
             read_b(base, ks, f);
             read_a(base, ks, f, 0, 4);
-            if (pre) stage_part(nslot, kbyte, 2 * ks, 4);
+            if (pre && !abl_dma_early) stage_part(nslot, kbyte, 2 * ks, 4);
             read_a(base, ks, f, 4, 8);
             mma(f, 0, 4, FIRST && ks == 0);
-            if (pre) stage_part(nslot, kbyte, 2 * ks + 1, 4);
+            if (pre && !abl_dma_early) stage_part(nslot, kbyte, 2 * ks + 1, 4);
             mma(f, 4, 8, FIRST && ks == 0);
         }
         ++g;

@@ -87,6 +87,7 @@ struct vodhip_index {
     int64_t sample_div = 48;     // GMAX bootstrap scores ~ ntotal / sample_div sampled rows
     int64_t force_safe = 0;
     int64_t tile = 0;
+    int64_t kflags = 0;
     int64_t small_chunk_tiles = 256;  // launches with fewer 256x256 tiles than this (less than one per CU) use the 128x128 kernel
     int64_t profile = 0;  // 1: bracket every filter launch with HIP events (bench / roofline accounting)
     // stats
@@ -219,7 +220,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
 
     const int q_es = elem_size(ps.q_dtype);
     if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
-    ix->ws.extra.flags = 0;
+    ix->ws.extra.flags = (int)ix->kflags;  // timing knobs of diagnostic builds (ignored by production kernels)
     // the subset labels in force when THIS search was enqueued (a recovery pass may run after younger searches changed them)
     ix->ws.extra.row_label = (ix->row_label && ps.q_label) ? ix->row_label : nullptr;
     ix->ws.extra.n_qlab = ps.n_qlab;
@@ -576,6 +577,8 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
         ix->force_safe = value;
     } else if (!strcmp(key, "small_chunk_tiles")) {
         ix->small_chunk_tiles = value;
+    } else if (!strcmp(key, "kflags")) {
+        ix->kflags = value;
     } else if (!strcmp(key, "sample_div")) {
         if (value < 2) return fail("sample_div must be >= 2");
         ix->sample_div = value;
