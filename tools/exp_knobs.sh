@@ -10,9 +10,8 @@ for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']; print('ms/step %.4f  filter_ms %.4f  qps %.0f' % (d['ms_per_step'], r['kernel_ms_per_step'], d['value']))
 " >> $out; }
-for rep in 1 2; do
-for f in 0 1 2 4 8 9 6 3; do run --param kflags=$f; done
-done
-for f in 0 1 2 8 9; do run --nq 256 --param kflags=$f; done
-for f in 0 2 4 6; do run --tile 9 --param kflags=$f; done
+for f in 8 72 8 72 0 64; do run --param kflags=$f; done
+for f in 8 72 8 72 24 88; do run --nq 256 --param kflags=$f; done
+for f in 8 72; do run --nq 512 --param kflags=$f; done
+
 cat $out

@@ -308,10 +308,13 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
     const bool abl_dma_early = (ex.flags & 2) != 0;  // all LDS-DMA of the next slice right after the barrier
     const bool abl_prio = (ex.flags & 4) != 0;       // static s_setprio 1 for waves 4..7
     const bool abl_nosurv = (ex.flags & 8) != 0;     // thresholds +inf: epilogue floor
+    const bool abl_corpus_nt = (ex.flags & 16) != 0;   // corpus LDS-DMA with the nt cache policy
+    const bool abl_corpus_sc0 = (ex.flags & 32) != 0;  // corpus LDS-DMA with sc0
+    const bool abl_blocked = (ex.flags & 64) != 0;     // corpus read AS IF stored [tile][k-slice][256 rows][128 B]: one tile = 384 contiguous KB (timing only)
     if (abl_l2hot) tile_step_bytes = 0;
     if (abl_prio && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
 #else
-    constexpr bool abl_l2hot = false, abl_dma_early = false, abl_nosurv = false;
+    constexpr bool abl_l2hot = false, abl_dma_early = false, abl_nosurv = false, abl_blocked = false;
 #endif
 
     const int st_row = lane >> 3, st_slot = lane & 7;
@@ -329,6 +332,8 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
             grow = ((size_t)idx * (size_t)ex.sample_groups + (size_t)xt0 * 8 + grp_in_tile) * (size_t)ex.sample_rstride;
         }
         a_src[t] = (const char*)X + (grow * dim_pad + (st_slot ^ ((r >> 1) & 7)) * 8) * 2;
+        if (abl_blocked)
+            a_src[t] = (const char*)X + ((size_t)row_begin + (size_t)xt0 * BM) * dim_pad * 2 + (size_t)r * ROW_BYTES + (st_slot ^ ((r >> 1) & 7)) * 16;
     }
 #pragma unroll
     for (int t = 0; t < NBI; ++t) {
@@ -341,10 +346,16 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
 #pragma unroll
         for (int u = 0; u < G; ++u) {
             if ((u * nparts) / G != part) continue;
-            if (u < NA)
-                glds16(a_src[u] + kbyte, sa + (wave * NA + u) * RPI * ROW_BYTES);
-            else
+            if (u < NA) {
+                const int kb = abl_blocked ? kbyte * BM : kbyte;
+#ifdef VODHIP_ABLATION
+                if (abl_corpus_nt) { glds16_aux<2>(a_src[u] + kb, sa + (wave * NA + u) * RPI * ROW_BYTES); continue; }
+                if (abl_corpus_sc0) { glds16_aux<1>(a_src[u] + kb, sa + (wave * NA + u) * RPI * ROW_BYTES); continue; }
+#endif
+                glds16(a_src[u] + kb, sa + (wave * NA + u) * RPI * ROW_BYTES);
+            } else {
                 glds16(b_src[u - NA] + kbyte, sb + (wave * NBI + (u - NA)) * RPI * ROW_BYTES);
+            }
         }
     };
 

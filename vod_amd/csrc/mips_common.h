@@ -48,6 +48,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const VOD_AS1 void*)gsrc, (VOD_AS3 void*)lds_dst, 16, 0, 0);
 }
 
+// the same with a cache-policy immediate (diagnostic builds): 1 = sc0, 2 = nt (MI355X_MICROARCH "nt-weights")
+template <int AUX>
+__device__ __forceinline__ void glds16_aux(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const VOD_AS1 void*)gsrc, (VOD_AS3 void*)lds_dst, 16, 0, AUX);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     // counted wait: all but the N youngest vector-memory operations of this wave are complete
