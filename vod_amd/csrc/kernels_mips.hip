@@ -267,10 +267,11 @@ void mips_filter_kernel(
 // tile's first interval, beside the partner's MFMAs.  Results are bit-identical (same products, same summation order).
 //
 // Survivors go to a per-wave list in LDS (positions from a ballot prefix: no atomic, no workgroup barrier) that the wave
-// itself flushes to the global candidate lists (exact-key test, subset test, one global atomic per record) when it holds
-// WSTG_FLUSH records and at kernel end; a record that does not fit is emitted directly.
-constexpr int WSTG_CAP = 128;   // records per wave list
-constexpr int WSTG_FLUSH = 48;  // flush when at least this many are pending (checked once per tile)
+// itself flushes to the global candidate lists (exact-key test, subset test, one global atomic per record; all records of a
+// flush share the two memory round trips) when it holds WSTG_FLUSH records and at kernel end; a record that does not fit
+// is emitted directly.
+constexpr int WSTG_CAP = 256;    // records per wave list (8 lists x 3 KB next to the two 64 KB operand slots)
+constexpr int WSTG_FLUSH = 176;  // flush when at least this many are pending (checked once per tile)
 constexpr int WSTG_BYTES = 8 * WSTG_CAP * 12;
 template <int DT, int MODE, bool SUBSET, bool STAGGER>
 __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
@@ -381,9 +382,39 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
     key_t64* const wl_key = (key_t64*)(smem + NSTAGE * STAGE_BYTES) + wave * WSTG_CAP;
     int* const wl_q = (int*)(smem + NSTAGE * STAGE_BYTES + NWAVES * WSTG_CAP * 8) + wave * WSTG_CAP;
     int wl_n = 0;  // wave-uniform
+    // A flush costs the wave (and, at the next barrier, its workgroup) two dependent global round trips - the exact-key
+    // test against thr_key, then the returning atomic that reserves the slot - whatever the number of records, so all
+    // (up to 4 per lane) go through each phase together and the list is sized to make flushes rare.
     auto wl_flush = [&]() {
         const int n = wl_n < WSTG_CAP ? wl_n : WSTG_CAP;
-        for (int e = lane; e < n; e += 64) emit_candidate<SUBSET>(wl_key[e], wl_q[e], thr_key, cand, cnt, cap, overflow, ex);
+        constexpr int PER_LANE = WSTG_CAP / 64;
+        key_t64 fk[PER_LANE];
+        int fq_[PER_LANE];
+        bool ok[PER_LANE];
+        unsigned slot[PER_LANE];
+#pragma unroll
+        for (int u = 0; u < PER_LANE; ++u) {
+            const int e = lane + 64 * u;
+            ok[u] = e < n;
+            fk[u] = ok[u] ? wl_key[e] : 0ull;
+            fq_[u] = ok[u] ? wl_q[e] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < PER_LANE; ++u) {
+            ok[u] = ok[u] && fk[u] > thr_key[fq_[u]];
+            if constexpr (SUBSET) ok[u] = ok[u] && subset_allows(ex, fq_[u], (int)(0xFFFFFFFFu - (unsigned)fk[u]));
+        }
+#pragma unroll
+        for (int u = 0; u < PER_LANE; ++u) slot[u] = ok[u] ? atomicAdd(&cnt[fq_[u]], 1u) : 0u;
+#pragma unroll
+        for (int u = 0; u < PER_LANE; ++u) {
+            if (ok[u]) {
+                if (slot[u] < (unsigned)cap)
+                    cand[(size_t)fq_[u] * cap + slot[u]] = fk[u];
+                else
+                    atomicOr(overflow, 1u);
+            }
+        }
         wl_n = 0;
     };
     // every lane with `p` appends (key, q): list position = wl_n + rank of the lane among the appending lanes
