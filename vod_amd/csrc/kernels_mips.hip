@@ -405,7 +405,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
             if constexpr (SUBSET) ok[u] = ok[u] && subset_allows(ex, fq_[u], (int)(0xFFFFFFFFu - (unsigned)fk[u]));
         }
 #pragma unroll
-        for (int u = 0; u < PER_LANE; ++u) slot[u] = ok[u] ? atomicAdd(&cnt[fq_[u]], 1u) : 0u;
+        for (int u = 0; u < PER_LANE; ++u) slot[u] = ok[u] ? atomicAdd(&cnt[(size_t)fq_[u] * CNT_STRIDE], 1u) : 0u;
 #pragma unroll
         for (int u = 0; u < PER_LANE; ++u) {
             if (ok[u]) {
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
     const int tid = threadIdx.x;
     const bool final_sort = (flags & SELECT_FINAL) != 0;
     const bool thr_only = (flags & SELECT_THRESHOLD_ONLY) != 0;
-    unsigned n = dense_n >= 0 ? (unsigned)dense_n : cnt[q];
+    unsigned n = dense_n >= 0 ? (unsigned)dense_n : cnt[(size_t)q * CNT_STRIDE];
     if (n > (unsigned)cap) {  // this query lost candidates in this stage: the host recovers it (and only it)
         if (tid == 0) {
             atomicOr(overflow, 1u);
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
             thr_key[q] = kth;
             thr_s[q] = unflip_f32((unsigned)(kth >> 32));
         }
-        cnt[q] = 0;
+        cnt[(size_t)q * CNT_STRIDE] = 0;
     }
 }
 
@@ -930,7 +930,7 @@ __global__ void mips_prepare_kernel(const void* __restrict__ q_src, int q_dtype,
     }
     if (i < n_topk) topk[i] = 0;
     if (i < nq_pad) {
-        cnt[i] = 0;
+        cnt[i * CNT_STRIDE] = 0;
         float ts = -__builtin_inff();
         key_t64 tk = 0;
         const int64_t srow = (q_map && i < nq) ? (int64_t)q_map[i] : i;

@@ -93,7 +93,7 @@ __device__ __forceinline__ void emit_candidate(key_t64 key, int q, const key_t64
     bool ok = key > thr_key[q];
     if constexpr (SUBSET) ok = ok && subset_allows(ex, q, (int)(0xFFFFFFFFu - (unsigned)key));
     if (ok) {
-        const unsigned slot = atomicAdd(&cnt[q], 1u);
+        const unsigned slot = atomicAdd(&cnt[(size_t)q * CNT_STRIDE], 1u);
         if (slot < (unsigned)cap)
             cand[(size_t)q * cap + slot] = key;
         else
@@ -131,7 +131,7 @@ __device__ __forceinline__ void append_survivors(float thr, int q, int row_end, 
         }
     }
     if (mask == 0) return;
-    unsigned slot = atomicAdd(&cnt[q], (unsigned)__builtin_popcount(mask));
+    unsigned slot = atomicAdd(&cnt[(size_t)q * CNT_STRIDE], (unsigned)__builtin_popcount(mask));
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         if (mask & (1u << i)) {

@@ -122,7 +122,7 @@ int ensure_workspace(vodhip_index* ix, int64_t nq_pad, int64_t cap, int64_t kp) 
     HIP_OK(hipMalloc((void**)&w.q_pad, (size_t)nq_cap * ix->dim_pad * 2));
     HIP_OK(hipMalloc((void**)&w.topk, (size_t)nq_cap * kp * sizeof(key_t64)));
     HIP_OK(hipMalloc((void**)&w.cand, (size_t)nq_cap * cap * sizeof(key_t64)));
-    HIP_OK(hipMalloc((void**)&w.cnt, (size_t)nq_cap * sizeof(unsigned int)));
+    HIP_OK(hipMalloc((void**)&w.cnt, (size_t)nq_cap * CNT_STRIDE * sizeof(unsigned int)));
     HIP_OK(hipMalloc((void**)&w.thr_s, (size_t)nq_cap * sizeof(float)));
     HIP_OK(hipMalloc((void**)&w.thr_key, (size_t)nq_cap * sizeof(key_t64)));
     HIP_OK(hipMalloc((void**)&w.overflow, sizeof(unsigned int)));
