@@ -157,7 +157,7 @@ void make_safe_schedule(int64_t n, int64_t cap, std::vector<Stage>& st) {
 
 // `recovery` > 0: pass number after a candidate-list overflow - no bootstrap (the thresholds are seeded from the previous
 // result), 2^(recovery-1) equal FILTER stages, and the exhaustive schedule once a stage would be <= cap rows.
-void make_schedule(const vodhip_index* ix, int k, int gmax_tile, bool safe, int recovery, std::vector<Stage>& st) {
+void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad, bool safe, int recovery, std::vector<Stage>& st) {
     st.clear();
     const int64_t n = ix->ntotal, cap = ix->cand_cap;
     if (n <= 0) return;
@@ -181,7 +181,17 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, bool safe, int 
     const int64_t g_max = std::min<int64_t>(cap, 8192 - kp);
     const int64_t s_max = std::min(rg * g_max, n / 2) / bm * bm;
     if (s_max < s_min) return make_safe_schedule(n, cap, st);  // too few rows for k group maxima: short, all dense
-    const int64_t s = std::min(s_max, std::max(s_min, round_up(n / std::max<int64_t>(ix->sample_div, 2), bm)));
+    int64_t s = std::min(s_max, std::max(s_min, round_up(n / std::max<int64_t>(ix->sample_div, 2), bm)));
+    if (gmax_tile == 8 || gmax_tile == 9) {
+        // the persistent kernel runs one workgroup per CU: a bootstrap of r.x "rounds" of tiles costs as much as r+1 full ones.
+        // Whole rounds only: down when that keeps >= 4k groups (a cheaper bootstrap), up otherwise (a tighter bound for free)
+        int dev = 0, n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        const int64_t per_round = std::max<int64_t>(1, n_cu / std::max<int64_t>(1, nq_pad / 256)) * bm;  // sampled rows per round
+        const int64_t down = s / per_round * per_round, up = round_up(s, per_round);
+        if (down >= s_min) s = down;
+        else if (up <= s_max) s = up;
+    }
     // S sampled rows at stride (n-1)/(S-1): the last one is row (S-1)*rstride <= n-1, all distinct (S <= n/2)
     st.push_back({ST_GMAX, 0, 0, s / bm, (n - 1) / (s - 1), s / rg});
     const double growth = std::min(256.0, std::max(1.25, ix->growth_x100 > 0 ? ix->growth_x100 / 100.0 : 8.0));
@@ -215,7 +225,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
     const int64_t bn = filter_tile_cols(tile);
 
     std::vector<Stage> stages;
-    make_schedule(ix, k, tile, safe, recovery, stages);
+    make_schedule(ix, k, tile, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), bn), safe, recovery, stages);
     ix->last_chunks = (int64_t)stages.size();
 
     const int q_es = elem_size(ps.q_dtype);
