@@ -305,13 +305,13 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
     const size_t tile_rows_stride = MODE == MODE_GMAX ? (size_t)8 * (size_t)ex.sample_rstride : (size_t)BM;
     size_t tile_step_bytes = (size_t)xt_step * tile_rows_stride * dim_pad * 2;
 #ifdef VODHIP_ABLATION  // timing-only knobs of diagnostic builds (`make ABLATION=1`, "kflags" parameter); results are wrong with bit 0 / 3
-    const bool abl_l2hot = (ex.flags & 1) != 0;      // every workgroup re-reads the same 16 corpus tiles: no HBM first touch
-    const bool abl_dma_early = (ex.flags & 2) != 0;  // all LDS-DMA of the next slice right after the barrier
-    const bool abl_prio = (ex.flags & 4) != 0;       // static s_setprio 1 for waves 4..7
-    const bool abl_nosurv = (ex.flags & 8) != 0;     // thresholds +inf: epilogue floor
-    const bool abl_corpus_nt = (ex.flags & 16) != 0;   // corpus LDS-DMA with the nt cache policy
-    const bool abl_corpus_sc0 = (ex.flags & 32) != 0;  // corpus LDS-DMA with sc0
-    const bool abl_blocked = (ex.flags & 64) != 0;     // corpus read AS IF stored [tile][k-slice][256 rows][128 B]: one tile = 384 contiguous KB (timing only)
+    const bool abl_l2hot = (ex.flags & (1 << 8)) != 0;      // every workgroup re-reads the same 16 corpus tiles: no HBM first touch
+    const bool abl_dma_early = (ex.flags & (2 << 8)) != 0;  // all LDS-DMA of the next slice right after the barrier
+    const bool abl_prio = (ex.flags & (4 << 8)) != 0;       // static s_setprio 1 for waves 4..7
+    const bool abl_nosurv = (ex.flags & (8 << 8)) != 0;     // thresholds +inf: epilogue floor
+    const bool abl_corpus_nt = (ex.flags & (16 << 8)) != 0;   // corpus LDS-DMA with the nt cache policy
+    const bool abl_corpus_sc0 = (ex.flags & (32 << 8)) != 0;  // corpus LDS-DMA with sc0
+    const bool abl_blocked = (ex.flags & (64 << 8)) != 0;     // corpus read AS IF stored [tile][k-slice][256 rows][128 B]: one tile = 384 contiguous KB (timing only)
     if (abl_l2hot) tile_step_bytes = 0;
     if (abl_prio && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
 #else
@@ -341,6 +341,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
         const int r = (wave * NBI + t) * RPI + st_row;
         b_src[t] = (const char*)Q + ((size_t)(q0 + r) * dim_pad + (st_slot ^ ((r >> 1) & 7)) * 8) * 2;
     }
+    const bool corpus_nt = (ex.flags & FILTER_FLAG_CORPUS_NT) != 0;  // single q-tile: corpus lines are read once (nt cache policy)
     auto stage_part = [&](int slot, int kbyte, int part, int nparts) {
         char* sa = smem + slot * STAGE_BYTES;
         char* sb = sa + A_BYTES;
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
             if ((u * nparts) / G != part) continue;
             if (u < NA) {
                 const int kb = abl_blocked ? kbyte * BM : kbyte;
+                if (corpus_nt) { glds16_aux<2>(a_src[u] + kb, sa + (wave * NA + u) * RPI * ROW_BYTES); continue; }
 #ifdef VODHIP_ABLATION
                 if (abl_corpus_nt) { glds16_aux<2>(a_src[u] + kb, sa + (wave * NA + u) * RPI * ROW_BYTES); continue; }
                 if (abl_corpus_sc0) { glds16_aux<1>(a_src[u] + kb, sa + (wave * NA + u) * RPI * ROW_BYTES); continue; }

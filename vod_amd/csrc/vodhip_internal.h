@@ -16,9 +16,11 @@ typedef unsigned long long key_t64;
 // nq = 256 ran 143 us with survivors, 74 us without).
 constexpr int CNT_STRIDE = 32;  // in unsigned ints
 
+enum : int { FILTER_FLAG_CORPUS_NT = 1 };  // FilterExtra::flags bit 0; bits 8.. = timing knobs of diagnostic builds
+
 // Extra, optional inputs of the filter kernels (passed by value).
 struct FilterExtra {
-    int flags = 0;                    // bit 0: rotated K order per q-tile workgroup (experiment knob)
+    int flags = 0;                    // FILTER_FLAG_* | (diagnostic knobs << 8)
     const int* row_label = nullptr;   // [ntotal] subset label of every stored row, or NULL (no subset filtering)
     const int* q_label = nullptr;     // [nq, n_qlab] allowed labels per query (-1 = empty slot; all -1 = unrestricted)
     int n_qlab = 0;
