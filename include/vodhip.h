@@ -77,8 +77,9 @@ int vodhip_index_get_rows(const vodhip_index_t* index, int64_t row_begin, int64_
  * the reference's `indices += offset` at src/vod_search/sharded_search.py:103,155 -- pads stay -1).
  * out_scores / out_ids are DEVICE pointers [nq, k].  1 <= k <= VODHIP_MAX_K.
  *
- * vodhip_index_search        enqueue + wait + exactness check (re-runs in the exhaustive-safe
- *                            schedule if a candidate buffer overflowed); results are final on return.
+ * vodhip_index_search        enqueue + wait + exactness check (if a query's candidate list overflowed, that query is
+ *                            searched again with thresholds seeded from its incomplete result; the exhaustive
+ *                            schedule is the last resort); results are final on return.
  * vodhip_index_search_async  enqueue only.  Must be followed by vodhip_index_search_finish on the
  *                            same index before the outputs are trusted.  Up to 4 searches may be in flight
  *                            (same stream; they share the workspace in stream order); finish completes the
@@ -104,8 +105,16 @@ int vodhip_index_search_finish(vodhip_index_t* index, void* stream);
 int vodhip_index_set_row_labels(vodhip_index_t* index, const int32_t* labels, int64_t n_rows, int location, void* stream);
 int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels_dev, int n_per_query);
 
-/* Tunables / introspection (tests and bench).  key: "cand_cap", "dense_rows", "growth", "force_safe",
- * "tile" (0 = auto, 1 = 128x128, 2 = 256x256); stats: "last_overflow", "last_chunks", "last_safe_reruns". */
+/* Tunables / introspection (tests and bench).
+ * params: "cand_cap" (candidate slots per query and stage, default 16384), "dense_rows" (indexes up to this many rows are
+ *   scored densely, default 2048), "sample_div" (the threshold bootstrap scores ~ntotal / sample_div sampled rows, default 96),
+ *   "growth" (x100: a filter stage covers growth x the rows its threshold was calibrated on, default 800),
+ *   "force_safe" (1 = exhaustive schedule: dense chunks of <= cand_cap rows), "tile" (0 = auto; 1 = 128x128, 42 / 46 = small-batch
+ *   rings, 8 / 9 = persistent 256x256 without / with the wave stagger), "small_chunk_tiles", "profile" (1 = HIP events around
+ *   every filter launch), "kflags" (timing knobs of diagnostic builds).
+ * stats (of the search completed by the last vodhip_index_search_finish): "last_overflow" (a candidate list overflowed),
+ *   "last_safe_reruns" (recovery passes run), "last_recovered_queries" (queries the first recovery pass re-searched),
+ *   "last_chunks" (stages), "last_filter_launches", "last_filter_ns" (with "profile"). */
 int vodhip_index_set_param(vodhip_index_t* index, const char* key, int64_t value);
 int vodhip_index_get_stat(const vodhip_index_t* index, const char* key, int64_t* out);
 
