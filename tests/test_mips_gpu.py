@@ -498,16 +498,18 @@ def test_clustered_row_order_needs_no_recovery(nq, k):
         assert ix.get_stat("last_overflow") == 0 and ix.get_stat("last_safe_reruns") == 0
 
 
-def test_only_the_overflowing_queries_are_searched_again():
+@pytest.mark.parametrize("nq", [300, 2300])
+def test_only_the_overflowing_queries_are_searched_again(nq):
     """A few queries whose neighbours form one huge block overflow their candidate lists; the recovery pass re-searches
-    THEM (as a small batch, results written back through the query map), not the whole batch."""
+    THEM (as a small batch, results written back through the query map), not the whole batch.  nq = 2300: two workspace
+    passes, flagged queries in both."""
     rng = np.random.default_rng(17)
-    n, d, nq, k = 120_000, 64, 300, 50
+    n, d, k = 120_000, 64, 50
     x = rng.integers(-2, 3, size=(n, d)).astype(np.float16)
     x[70_000:100_000] = x[70_000]        # 30k IDENTICAL rows (duplicated sections): for the queries below every one of
     x[70_000:100_000, :8] = 8            # them ties at the top score, so no threshold can keep them out of the lists
     q = rng.integers(-2, 3, size=(nq, d)).astype(np.float16)
-    hot = [3, 77, 150, 299]
+    hot = [3, 77, 150, nq - 1]
     q[hot] = x[70_000]
     with _index(x, cand_cap=4096) as ix:
         _assert_exact(ix, q, x, k)
