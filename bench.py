@@ -310,7 +310,7 @@ def main() -> None:
         tfile = ROOT / "profiles" / "hbm_traffic.json"
         if tfile.exists():  # HBM bytes per step from this round's rocprofv3 --pmc passes of the same command (tools/pmc.sh)
             try:
-                ent = json.loads(tfile.read_text()).get(f"{n_total}x{d}x{nq}@{world}")
+                ent = json.loads(tfile.read_text()).get(f"{n_total}x{d}x{nq}@{world}" + ("" if args.data == "iid" else "/clustered"))
                 if isinstance(ent, dict):
                     traffic, traffic_src = ent.get("bytes"), ent.get("source")
                 else:
