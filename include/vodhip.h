@@ -116,6 +116,12 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
  *   "last_safe_reruns" (recovery passes run), "last_recovered_queries" (queries the first recovery pass re-searched),
  *   "last_chunks" (stages), "last_filter_launches", "last_filter_ns" (with "profile"). */
 int vodhip_index_set_param(vodhip_index_t* index, const char* key, int64_t value);
+/* Host-side planning only (no device is touched): the stage list a search of `nq` queries for the top `k` of `ntotal` rows
+ * would run, with the given tunables (<= 0 = library default; tile 0 = auto; recovery_pass 0 = the normal schedule).
+ * out: int64 [max_stages][6] = {kind (0 FILTER, 1 DENSE, 2 GMAX bootstrap), row_begin, row_end, sampled tiles, sample row
+ * stride, sample groups}.  Returns the number of stages, or -1. */
+int vodhip_debug_schedule(int64_t ntotal, int k, int64_t nq, int64_t cand_cap, int64_t dense_rows, int64_t sample_div,
+                          int64_t growth_x100, int tile, int recovery_pass, int64_t* out, int max_stages);
 int vodhip_index_get_stat(const vodhip_index_t* index, const char* key, int64_t* out);
 
 /* ---------------------------------------------------------------------------------------------

@@ -1,0 +1,151 @@
+"""Host-side planning of a search (`vodhip_debug_schedule`: no device is touched), checked on CPU.
+
+Invariants of the stage list, over seeded random (ntotal, k, nq, cand_cap) and the BASELINE shapes:
+  * the FILTER / DENSE stages tile [0, ntotal) exactly once, in order; a DENSE stage never exceeds cand_cap rows;
+  * a GMAX bootstrap samples S = tiles * BM rows, all below ntotal, all distinct, in >= 2k (4k when cand_cap allows) and
+    <= cand_cap groups, and the
+    sample is STRATIFIED: the rows one lane reports the maximum of (one candidate slot) are one row of every 1/32 (1/16) of
+    the store - the tile-row -> (slot, member) map below mirrors the address set-up of kernels_mips.hip;
+  * a FILTER stage never covers more rows than keep the candidate lists below capacity for ANY row order;
+  * recovery passes 1, 2, 3, ... use 1, 2, 4, ... FILTER stages and end in dense chunks.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+from hypothesis import given, settings
+from hypothesis import strategies as st
+
+FILTER, DENSE, GMAX = 0, 1, 2
+
+
+def _schedule(n, k, nq, cap=0, dense=0, sdiv=0, growth=0, tile=0, recovery=0):
+    from vod_amd import _native
+
+    lib = _native.load_library()
+    out = (ctypes.c_int64 * (4096 * 6))()
+    r = lib.vodhip_debug_schedule(n, k, nq, cap, dense, sdiv, growth, tile, recovery, out, 4096)
+    assert r >= 0, _native.last_error() if hasattr(_native, "last_error") else r
+    return np.array(out[: r * 6], dtype=np.int64).reshape(r, 6)
+
+
+def _tile_geometry(nq, tile=0):
+    """(BM rows per tile, rows per lane group, TM rows per wave tile, MI 32-row blocks per wave tile) of the GMAX kernel."""
+    if tile == 0:
+        tile = 8 if nq > 128 else (46 if nq > 64 else 42)
+    if tile in (8, 9):
+        return 256, 32, None, None
+    if tile == 1:
+        return 128, 16, 64, 2
+    return 256, 16, 64, 2  # 42: 4 x 1 waves, 46: 4 x 2 waves -> 64-row wave tiles either way
+
+
+def _sampled_rows_by_slot(stage, nq, tile=0):
+    """slot -> sorted store rows, by the same tile-row decomposition the kernels use to build their LDS-DMA addresses."""
+    bm, rg, tm, mi = _tile_geometry(nq, tile)
+    n_tiles, rstride, n_groups = int(stage[3]), int(stage[4]), int(stage[5])
+    r = np.arange(bm)
+    if tm is None:  # persistent 16x16x32 layout: tile row = wm*128 + i*16 + 4*fq + rr
+        grp = (r >> 7) * 4 + ((r >> 2) & 3)
+        member = ((r >> 4) & 7) * 4 + (r & 3)
+    else:           # 32x32x16 layout: tile row = wm*TM + i*32 + 8*(rr>>2) + 4*fh + (rr&3)
+        bb = r & 31
+        grp = ((r // tm) * mi + (r % tm) // 32) * 2 + ((bb >> 2) & 1)
+        member = (bb >> 3) * 4 + (bb & 3)
+    per_tile = bm // rg
+    slots = {}
+    for xt in range(n_tiles):
+        slot = xt * per_tile + grp
+        rows = (member * n_groups + slot) * rstride
+        for s_, row in zip(slot, rows):
+            slots.setdefault(int(s_), []).append(int(row))
+    return {s_: sorted(v) for s_, v in slots.items()}, rg
+
+
+def _check(n, k, nq, cap=16384, tile=0, **kw):
+    st_ = _schedule(n, k, nq, cap=cap, tile=tile, **kw)
+    if n == 0:
+        assert len(st_) == 0
+        return st_
+    scans = st_[st_[:, 0] != GMAX]
+    assert scans[0, 1] == 0 and scans[-1, 2] == n
+    assert np.all(scans[1:, 1] == scans[:-1, 2]) and np.all(scans[:, 2] > scans[:, 1])
+    assert np.all((scans[scans[:, 0] == DENSE][:, 2] - scans[scans[:, 0] == DENSE][:, 1]) <= cap)
+    boots = st_[st_[:, 0] == GMAX]
+    assert len(boots) <= 1
+    if not len(boots) and len(scans) > 1 and scans[1, 0] == FILTER:  # geometric fallback: dense head, growing filter stages
+        assert scans[0, 0] == DENSE and np.all(scans[1:, 0] == FILTER)
+    if len(boots):
+        assert st_[0, 0] == GMAX and np.all(scans[:, 0] == FILTER)
+        b = boots[0]
+        bm, rg, _, _ = _tile_geometry(nq, tile)
+        s_rows = int(b[3]) * bm
+        kp = 64
+        while kp < k:
+            kp *= 2
+        assert b[5] * rg == s_rows and 2 * k <= b[5] <= min(cap, 8192 - kp)
+        if min(cap, 8192 - kp) >= 4 * k + 256 // rg and n // 2 >= 4 * k * rg + 256:
+            assert b[5] >= 4 * k
+        assert b[4] >= 2 and (s_rows - 1) * b[4] <= n - 1 and s_rows <= n // 2
+        rows_safe = max(256, int(cap * s_rows / (1.6 * k)) // 256 * 256)
+        assert np.all(scans[:, 2] - scans[:, 1] <= rows_safe)
+    return st_
+
+
+@pytest.mark.parametrize("n,k,nq", [(10_000_000, 100, 1024), (1_250_000, 100, 1024), (1_000_000, 100, 256), (40_000_000, 200, 512),
+                                    (100_000, 10, 32), (20_000, 10, 32), (4200, 5, 130), (2049, 100, 130), (2048, 100, 130), (1, 1, 1), (0, 5, 3)])
+def test_baseline_shapes(n, k, nq):
+    st_ = _check(n, k, nq)
+    if n >= 100_000:
+        assert st_[0, 0] == GMAX and 3 <= len(st_) <= 7  # bootstrap + 2..6 filter stages (round 1: 6 launches, 4 of them tiny)
+
+
+@settings(max_examples=300, deadline=None)
+@given(n=st.integers(1, 50_000_000), k=st.sampled_from([1, 3, 10, 64, 100, 128, 200, 500, 2048]),
+       nq=st.sampled_from([1, 32, 64, 65, 128, 129, 256, 257, 1024, 2048, 5000]), cap=st.sampled_from([256, 512, 4096, 16384, 65536]),
+       tile=st.sampled_from([0, 1, 8, 9, 42, 46]))
+def test_schedule_invariants(n, k, nq, cap, tile):
+    if cap < 4 * k:
+        return  # cand_cap below k is refused by the search itself; below 4k the (valid) schedule can run to thousands of stages
+    _check(n, k, nq, cap=cap, tile=tile)
+
+
+@pytest.mark.parametrize("n,k,nq,tile", [(10_000_000, 100, 1024, 0), (1_250_000, 100, 1024, 9), (300_000, 50, 100, 0), (300_000, 50, 40, 0),
+                                         (60_000, 40, 300, 0), (50_000, 10, 200, 1)])
+def test_bootstrap_sample_is_stratified_distinct_and_in_range(n, k, nq, tile):
+    st_ = _schedule(n, k, nq, tile=tile)
+    assert st_[0, 0] == GMAX
+    slots, rg = _sampled_rows_by_slot(st_[0], nq, tile)
+    n_groups, rstride = int(st_[0, 5]), int(st_[0, 4])
+    assert sorted(slots) == list(range(n_groups))            # every candidate slot is written by exactly one lane group
+    all_rows = np.concatenate([np.array(v) for v in slots.values()])
+    assert len(all_rows) == n_groups * rg == len(np.unique(all_rows)) and all_rows.max() < n and all_rows.min() >= 0
+    stratum = n_groups * rstride                               # store rows per stratum
+    for s_, rows in slots.items():
+        assert len(rows) == rg
+        assert [r // stratum for r in rows] == list(range(rg))  # one row of every stratum: tight for sorted / clustered stores too
+    assert (n - 1) - all_rows.max() < n_groups * rg  # integer stride: fewer than S rows at the end of the store are beyond the sample
+
+
+def test_recovery_passes_halve_the_stages_and_end_dense():
+    n, k, nq, cap = 1_000_000, 100, 300, 4096
+    prev = 0
+    for p in range(1, 12):
+        st_ = _check(n, k, nq, cap=cap, recovery=p)
+        assert not np.any(st_[:, 0] == GMAX)  # thresholds are seeded from the previous result
+        if np.all(st_[:, 0] == DENSE):
+            assert np.all(st_[:, 2] - st_[:, 1] <= cap)
+            break
+        assert len(st_) == 2 ** (p - 1) and len(st_) >= prev
+        prev = len(st_)
+    else:
+        pytest.fail("recovery never reached the exhaustive schedule")
+
+
+def test_large_k_uses_the_bootstrap_with_bounded_stages_not_hundreds_of_dense_chunks():
+    """k = 2048 leaves room for 3k (< 4k) groups in the select buffer: the bootstrap still runs, with stages short enough for
+    the candidate lists (the alternative is ntotal / cand_cap = 610 dense launches at 10 M rows)."""
+    st_ = _check(10_000_000, 2048, 256)
+    assert st_[0, 0] == GMAX and st_[0, 5] >= 2 * 2048 and len(st_) < 40
+    tiny_cap = _check(1_048_577, 100, 1, cap=256)  # cap too small for any bootstrap: dense head + geometric stages
+    assert tiny_cap[0, 0] == DENSE and np.all(tiny_cap[1:, 0] == FILTER) and len(tiny_cap) < 40

@@ -155,6 +155,20 @@ void make_safe_schedule(int64_t n, int64_t cap, std::vector<Stage>& st) {
     for (int64_t b = 0; b < n; b += step) st.push_back({ST_DENSE, b, std::min(n, b + step), 0, 0, 0});
 }
 
+// dense head of <= cap rows, then FILTER stages that grow by 1 + cap / 4k (each emits ~ (growth - 1) k survivors per query for
+// exchangeable row order): the schedule for searches that cannot use the bootstrap (subset filters; k too large for cap)
+void make_geometric_schedule(int64_t n, int k, int64_t cap, std::vector<Stage>& st) {
+    int64_t b = std::min(n, std::max<int64_t>(ROW_ALIGN, std::min<int64_t>(cap, 2048) / ROW_ALIGN * ROW_ALIGN));
+    if (b < k && b < n) return make_safe_schedule(n, cap, st);
+    st.push_back({ST_DENSE, 0, b, 0, 0, 0});
+    const double growth = std::min(8.0, std::max(1.25, 1.0 + (double)cap / (4.0 * k)));
+    while (b < n) {
+        const int64_t e = std::min(n, round_up(std::max((int64_t)((double)b * growth), b + ROW_ALIGN), ROW_ALIGN));
+        st.push_back({ST_FILTER, b, e, 0, 0, 0});
+        b = e;
+    }
+}
+
 // `recovery` > 0: pass number after a candidate-list overflow - no bootstrap (the thresholds are seeded from the previous
 // result), 2^(recovery-1) equal FILTER stages, and the exhaustive schedule once a stage would be <= cap rows.
 void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad, bool safe, int recovery, std::vector<Stage>& st) {
@@ -172,15 +186,19 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad,
         return;
     }
     const int64_t bm = filter_tile_rows(gmax_tile), rg = filter_group_rows(gmax_tile);
-    // at least 4k groups: the k-th largest of G group maxima is exceeded by a fraction -ln(1 - k/G) / rg of the rows,
-    // which is ~ 1.15 k/S at G = 4k and blows up as G approaches k
-    const int64_t s_min = round_up(std::max<int64_t>(4 * rg * (int64_t)k, 2048), bm);
+    // 4k groups wanted, 2k needed: the k-th largest of G group maxima is exceeded by a fraction -ln(1 - k/G) / rg of the rows,
+    // ~1.15 k/S at G = 4k, 1.39 k/S at G = 2k (the stage-size bound below allows 1.6 k/S), and it blows up as G approaches k
     int64_t kp = 64;
     while (kp < k) kp <<= 1;
     // one candidate slot per group, and the select kernel takes the group maxima in ONE round of its largest buffer
     const int64_t g_max = std::min<int64_t>(cap, 8192 - kp);
     const int64_t s_max = std::min(rg * g_max, n / 2) / bm * bm;
-    if (s_max < s_min) return make_safe_schedule(n, cap, st);  // too few rows for k group maxima: short, all dense
+    const int64_t s_need = round_up(std::max<int64_t>(2 * rg * (int64_t)k, 2048), bm);
+    if (s_max < s_need) {  // no usable bootstrap (few rows, or k too large for cap): all dense when that is a few launches
+        if (n <= 64 * cap) return make_safe_schedule(n, cap, st);
+        return make_geometric_schedule(n, k, cap, st);
+    }
+    const int64_t s_min = std::min(s_max, round_up(std::max<int64_t>(4 * rg * (int64_t)k, 2048), bm));
     int64_t s = std::min(s_max, std::max(s_min, round_up(n / std::max<int64_t>(ix->sample_div, 2), bm)));
     if (gmax_tile == 8 || gmax_tile == 9) {
         // the persistent kernel runs one workgroup per CU: a bootstrap of r.x "rounds" of tiles costs as much as r+1 full ones.
@@ -243,19 +261,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
         // group maxima would include ineligible rows: a subset search runs the exhaustive-free geometric schedule instead
         // (dense head of <= cap rows, then FILTER stages growing by `growth`)
         stages.clear();
-        const int64_t n = ix->ntotal;
-        int64_t b = std::min(n, std::max<int64_t>(ROW_ALIGN, std::min<int64_t>(cap, 2048) / ROW_ALIGN * ROW_ALIGN));
-        if (b >= k || b == n) {
-            stages.push_back({ST_DENSE, 0, b, 0, 0, 0});
-            const double growth = std::min(8.0, std::max(1.25, 1.0 + (double)cap / (4.0 * k)));
-            while (b < n) {
-                int64_t e = std::min(n, round_up(std::max((int64_t)((double)b * growth), b + ROW_ALIGN), ROW_ALIGN));
-                stages.push_back({ST_FILTER, b, e, 0, 0, 0});
-                b = e;
-            }
-        } else {
-            make_safe_schedule(n, cap, stages);
-        }
+        make_geometric_schedule(ix->ntotal, k, cap, stages);
         ix->last_chunks = (int64_t)stages.size();
     }
     const SearchWorkspace& ws = ix->ws;
@@ -574,6 +580,31 @@ int vodhip_index_search(vodhip_index_t* ix, const void* queries, int q_dtype, in
                         float* out_scores, int64_t* out_ids, void* stream) {
     if (vodhip_index_search_async(ix, queries, q_dtype, nq, k, id_base, out_scores, out_ids, stream)) return -1;
     return vodhip_index_search_finish(ix, stream);
+}
+
+int vodhip_debug_schedule(int64_t ntotal, int k, int64_t nq, int64_t cand_cap, int64_t dense_rows, int64_t sample_div,
+                          int64_t growth_x100, int tile, int recovery_pass, int64_t* out, int max_stages) {
+    if (!out || max_stages < 1 || k < 1 || nq < 1 || ntotal < 0) return fail("invalid arguments");
+    vodhip_index tmp;  // host-side planning only: no device call uses it
+    tmp.ntotal = ntotal;
+    if (cand_cap > 0) tmp.cand_cap = cand_cap;
+    if (dense_rows > 0) tmp.dense_rows = round_up(dense_rows, ROW_ALIGN);
+    if (sample_div > 0) tmp.sample_div = sample_div;
+    tmp.growth_x100 = growth_x100;
+    if (tile == 0) tile = nq > 128 ? 8 : (nq > 64 ? 46 : 42);
+    std::vector<Stage> st;
+    make_schedule(&tmp, k, tile, round_up(std::min(MAX_NQ_PER_PASS, nq), filter_tile_cols(tile)), false, recovery_pass, st);
+    if ((int)st.size() > max_stages) return fail("%d stages do not fit max_stages=%d", (int)st.size(), max_stages);
+    for (size_t i = 0; i < st.size(); ++i) {
+        int64_t* o = out + i * 6;
+        o[0] = st[i].kind;
+        o[1] = st[i].b;
+        o[2] = st[i].e;
+        o[3] = st[i].n_tiles;
+        o[4] = st[i].rstride;
+        o[5] = st[i].n_groups;
+    }
+    return (int)st.size();
 }
 
 int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
