@@ -73,8 +73,8 @@ def _check(n, k, nq, cap=16384, tile=0, **kw):
     assert np.all((scans[scans[:, 0] == DENSE][:, 2] - scans[scans[:, 0] == DENSE][:, 1]) <= cap)
     boots = st_[st_[:, 0] == GMAX]
     assert len(boots) <= 1
-    if not len(boots) and len(scans) > 1 and scans[1, 0] == FILTER:  # geometric fallback: dense head, growing filter stages
-        assert scans[0, 0] == DENSE and np.all(scans[1:, 0] == FILTER)
+    if not len(boots) and scans[0, 0] == DENSE and len(scans) > 1 and scans[1, 0] == FILTER:
+        assert np.all(scans[1:, 0] == FILTER)  # geometric fallback: dense head, then growing filter stages
     if len(boots):
         assert st_[0, 0] == GMAX and np.all(scans[:, 0] == FILTER)
         b = boots[0]
