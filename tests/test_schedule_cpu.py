@@ -147,5 +147,5 @@ def test_large_k_uses_the_bootstrap_with_bounded_stages_not_hundreds_of_dense_ch
     the candidate lists (the alternative is ntotal / cand_cap = 610 dense launches at 10 M rows)."""
     st_ = _check(10_000_000, 2048, 256)
     assert st_[0, 0] == GMAX and st_[0, 5] >= 2 * 2048 and len(st_) < 40
-    tiny_cap = _check(1_048_577, 100, 1, cap=256)  # cap too small for any bootstrap: dense head + geometric stages
+    tiny_cap = _check(1_048_577, 200, 1, cap=256)  # cap too small for 2k groups: dense head + geometric stages
     assert tiny_cap[0, 0] == DENSE and np.all(tiny_cap[1:, 0] == FILTER) and len(tiny_cap) < 40
