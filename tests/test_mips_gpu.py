@@ -100,8 +100,9 @@ def test_empty_index_and_empty_query():
         assert s.shape == (0, 4) and i.shape == (0, 4)
 
 
-@pytest.mark.parametrize("n,nq", [(9000, 5), (40000, 300), (40000, 130)])
+@pytest.mark.parametrize("n,nq", [(9000, 5), (40000, 300), (40000, 130), (300_000, 130), (300_000, 20)])
 def test_k_max_and_large_k(n, nq):
+    """k = 2048 / 1000: few rows -> dense chunks; 300 k rows -> a bootstrap with 2k..4k groups and short stages."""
     q, x = _int_data(5, n, 64, nq)
     with _index(x) as ix:
         _assert_exact(ix, q, x, 2048)
