@@ -308,6 +308,35 @@ def test_merge_topk_handles_pads_and_ties():
     np.testing.assert_array_equal(ms.cpu().numpy(), rs)
 
 
+@pytest.mark.parametrize("n_sh,nq,k,k_out", [(8, 1024, 100, 100), (8, 40, 200, 200), (3, 17, 100, 30), (2, 5, 7, 64), (1, 9, 100, 100), (8, 6, 1000, 1000)])
+@pytest.mark.parametrize("ordered", [True, False])
+def test_merge_topk_ranked_path_and_unsorted_fallback(n_sh, nq, k, k_out, ordered):
+    """Sorted shard lists (what the search writes) take the rank-by-binary-search path; lists in any other order must fall
+    back to the sorting network and give the same answer.  Duplicated (score, id) pairs across shards, pads, k_out != k."""
+    from oracle.flat_ip import merge_shard_topk
+    from vod_amd.index import merge_topk
+
+    rng = np.random.default_rng(n_sh * 1000 + k)
+    s = rng.integers(-4, 5, size=(n_sh, nq, k)).astype(np.float32)
+    ids = np.stack([rng.permutation(50_000)[: nq * k].reshape(nq, k) + 100_000 * sh for sh in range(n_sh)]).astype(np.int64)
+    if n_sh > 1:  # the same (score, id) pair reported by two shards (overlapping shards): both copies rank, in shard order
+        ids[1, :, 0] = ids[0, :, 0]
+        s[1, :, 0] = s[0, :, 0]
+    for sh in range(n_sh):
+        for r in range(nq):
+            if rng.uniform() < 0.3:
+                cut = rng.integers(0, k + 1)
+                s[sh, r, cut:] = -np.inf
+                ids[sh, r, cut:] = -1
+            valid = ids[sh, r] >= 0
+            o = np.lexsort((ids[sh, r], -s[sh, r], ~valid)) if ordered else rng.permutation(k)
+            s[sh, r], ids[sh, r] = s[sh, r][o], ids[sh, r][o]
+    ms, mi = merge_topk(torch.from_numpy(s).cuda(), torch.from_numpy(ids).cuda(), k_out=k_out)
+    rs, ri = merge_shard_topk(list(s), list(ids), k_out)
+    np.testing.assert_array_equal(mi.cpu().numpy(), ri)
+    np.testing.assert_array_equal(ms.cpu().numpy(), rs)
+
+
 def test_packed_record_merge_matches_plain_merge():
     """The one-all-gather exchange format: [scores | ids] records laid end to end, merged in place."""
     from vod_amd.index import PackedTopk, merge_topk

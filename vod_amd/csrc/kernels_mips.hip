@@ -1110,6 +1110,11 @@ __device__ __forceinline__ bool pair_before(float sa, int64_t ia, float sb, int6
     return ia < ib;
 }
 
+// Fast path: every shard's list arrives sorted best-first with its pads at the tail (what the search writes), so the merged
+// position of an entry is its position in its own list plus, for every other list, the number of entries that come before it
+// (a binary search: the order is total - equal (score, id) pairs are ordered by shard).  No sorting network, no barrier but the
+// one behind the load: 8 x 100 entries merge in a few microseconds instead of the 55-stage bitonic sort of 1024 pairs (51 us).
+// The kernel verifies the precondition while loading and falls back to the bitonic sort for lists that are not sorted.
 __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict__ scores, const int64_t* __restrict__ ids,
                                                          int64_t stride_s, int64_t stride_i, int n_shards, int64_t nq, int k, int k_out,
                                                          float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
@@ -1135,6 +1140,50 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
         }
         ssc[i] = s;
         sid[i] = id;
+    }
+    __syncthreads();
+    // precondition check: within a shard, no entry may come strictly before its predecessor (pads sink to the tail)
+    int unsorted = 0, n_valid = 0;
+    for (int i = tid; i < total; i += 256) {
+        n_valid += sid[i] >= 0;
+        if (i % k + 1 < k) unsorted |= pair_before(ssc[i + 1], sid[i + 1], ssc[i], sid[i]) ? 1 : 0;
+    }
+    unsorted = __syncthreads_or(unsorted);
+    if (!unsorted) {
+        __shared__ int s_valid[4];
+        for (int o = 32; o > 0; o >>= 1) n_valid += __shfl_xor(n_valid, o);
+        if ((tid & 63) == 0) s_valid[tid >> 6] = n_valid;
+        __syncthreads();
+        n_valid = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
+        for (int i = tid; i < total; i += 256) {
+            const int64_t id = sid[i];
+            if (id < 0) continue;
+            const float sc = ssc[i];
+            const int sh = i / k;
+            int rank = i % k;
+            for (int t = 0; t < n_shards && rank < k_out; ++t) {
+                if (t == sh) continue;
+                // entries of list t that come before this one: first position lo where list_t[lo] does NOT come before it
+                int lo = 0, hi = k;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const float ms = ssc[t * k + mid];
+                    const int64_t mi = sid[t * k + mid];
+                    const bool before = pair_before(ms, mi, sc, id) || (mi == id && ms == sc && t < sh);
+                    if (before) lo = mid + 1; else hi = mid;
+                }
+                rank += lo;
+            }
+            if (rank < k_out) {
+                out_scores[q * k_out + rank] = sc;
+                out_ids[q * k_out + rank] = id;
+            }
+        }
+        for (int r = n_valid + tid; r < k_out; r += 256) {  // fewer valid entries than k_out: pads
+            out_scores[q * k_out + r] = -__builtin_inff();
+            out_ids[q * k_out + r] = -1;
+        }
+        return;
     }
     for (int size = 2; size <= P; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
