@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
     }
     unsorted = __syncthreads_or(unsorted);
     if (!unsorted) {
-        __shared__ int s_valid[4];
+        int* s_valid = (int*)(smem + (size_t)P * 12);  // 4 ints behind the entries (all LDS in the one dynamic array)
         for (int o = 32; o > 0; o >>= 1) n_valid += __shfl_xor(n_valid, o);
         if ((tid & 63) == 0) s_valid[tid >> 6] = n_valid;
         __syncthreads();
@@ -1222,7 +1222,7 @@ hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int64_t st
     const int total = n_shards * k;
     size_t P = 64;
     while ((int)P < total) P <<= 1;
-    const size_t lds = P * 12;
+    const size_t lds = P * 12 + 16;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (hipError_t e = allow_dynamic_lds((const void*)merge_topk_kernel, 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(256), lds, stream, scores, ids, stride_s, stride_i, n_shards, nq, k, k_out,
