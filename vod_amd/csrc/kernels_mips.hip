@@ -1148,7 +1148,12 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
         n_valid += sid[i] >= 0;
         if (i % k + 1 < k) unsorted |= pair_before(ssc[i + 1], sid[i + 1], ssc[i], sid[i]) ? 1 : 0;
     }
-    unsorted = __syncthreads_or(unsorted);
+    int* s_flag = (int*)(smem + (size_t)P * 12 + 16);  // (HIP's __syncthreads_or brings a static LDS object of its own)
+    if (tid == 0) *s_flag = 0;
+    __syncthreads();
+    if (unsorted) *s_flag = 1;
+    __syncthreads();
+    unsorted = *s_flag;
     if (!unsorted) {
         int* s_valid = (int*)(smem + (size_t)P * 12);  // 4 ints behind the entries (all LDS in the one dynamic array)
         for (int o = 32; o > 0; o >>= 1) n_valid += __shfl_xor(n_valid, o);
@@ -1222,7 +1227,7 @@ hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int64_t st
     const int total = n_shards * k;
     size_t P = 64;
     while ((int)P < total) P <<= 1;
-    const size_t lds = P * 12 + 16;
+    const size_t lds = P * 12 + 32;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (hipError_t e = allow_dynamic_lds((const void*)merge_topk_kernel, 160 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(256), lds, stream, scores, ids, stride_s, stride_i, n_shards, nq, k, k_out,
