@@ -318,7 +318,7 @@ def test_merge_topk_ranked_path_and_unsorted_fallback(n_sh, nq, k, k_out, ordere
 
     rng = np.random.default_rng(n_sh * 1000 + k)
     s = rng.integers(-4, 5, size=(n_sh, nq, k)).astype(np.float32)
-    ids = np.stack([rng.permutation(50_000)[: nq * k].reshape(nq, k) + 100_000 * sh for sh in range(n_sh)]).astype(np.int64)
+    ids = np.stack([rng.permutation(max(50_000, nq * k))[: nq * k].reshape(nq, k) + 1_000_000 * sh for sh in range(n_sh)]).astype(np.int64)
     if n_sh > 1:  # the same (score, id) pair reported by two shards (overlapping shards): both copies rank, in shard order
         ids[1, :, 0] = ids[0, :, 0]
         s[1, :, 0] = s[0, :, 0]

@@ -21,4 +21,14 @@ for n_shards, nq, k in [(1, 1024, 100), (2, 1024, 100), (4, 1024, 100), (8, 1024
         merge_topk(s, i)
     e1.record()
     torch.cuda.synchronize()
-    print(f"n_shards {n_shards} nq {nq} k {k}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us per merge (incl. output allocation)")
+    t_sorted = e0.elapsed_time(e1) / 50 * 1e3
+    su = s[:, :, torch.randperm(k, device=dev)]  # lists in arbitrary order: the sorting-network fallback
+    iu = i[:, :, torch.randperm(k, device=dev)]
+    merge_topk(su, iu)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50):
+        merge_topk(su, iu)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"n_shards {n_shards} nq {nq} k {k}: sorted lists {t_sorted:.1f} us, unsorted lists {e0.elapsed_time(e1) / 50 * 1e3:.1f} us per merge (incl. output allocation)")
