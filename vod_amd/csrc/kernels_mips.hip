@@ -1160,24 +1160,42 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
         if ((tid & 63) == 0) s_valid[tid >> 6] = n_valid;
         __syncthreads();
         n_valid = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
+        int n_steps = 1;  // binary-search steps that always suffice: 2^n_steps > k
+        while ((1 << n_steps) <= k) ++n_steps;
         for (int i = tid; i < total; i += 256) {
             const int64_t id = sid[i];
             if (id < 0) continue;
             const float sc = ssc[i];
             const int sh = i / k;
             int rank = i % k;
-            for (int t = 0; t < n_shards && rank < k_out; ++t) {
-                if (t == sh) continue;
-                // entries of list t that come before this one: first position lo where list_t[lo] does NOT come before it
-                int lo = 0, hi = k;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    const float ms = ssc[t * k + mid];
-                    const int64_t mi = sid[t * k + mid];
-                    const bool before = pair_before(ms, mi, sc, id) || (mi == id && ms == sc && t < sh);
-                    if (before) lo = mid + 1; else hi = mid;
+            // 8 lists at a time, their binary searches in lockstep: one step = 8 independent LDS reads in flight (a chain of
+            // 7 lists x 7 dependent reads per entry made this path no faster than the sorting network)
+            for (int t0 = 0; t0 < n_shards && rank < k_out; t0 += 8) {
+                int lo[8], hi[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    lo[u] = 0;
+                    hi[u] = (t0 + u < n_shards && t0 + u != sh) ? k : 0;
                 }
-                rank += lo;
+                for (int step = 0; step < n_steps; ++step) {
+                    float ms[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) ms[u] = lo[u] < hi[u] ? ssc[(t0 + u) * k + ((lo[u] + hi[u]) >> 1)] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (lo[u] < hi[u]) {
+                            const int mid = (lo[u] + hi[u]) >> 1;
+                            bool before = ms[u] > sc;
+                            if (ms[u] == sc) {  // equal scores: smaller id first, pads last, equal pairs in shard order
+                                const int64_t mi = sid[(t0 + u) * k + mid];
+                                before = mi >= 0 && (mi < id || (mi == id && t0 + u < sh));
+                            }
+                            if (before) lo[u] = mid + 1; else hi[u] = mid;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rank += lo[u];
             }
             if (rank < k_out) {
                 out_scores[q * k_out + rank] = sc;
