@@ -1113,7 +1113,8 @@ __device__ __forceinline__ bool pair_before(float sa, int64_t ia, float sb, int6
 // Fast path: every shard's list arrives sorted best-first with its pads at the tail (what the search writes), so the merged
 // position of an entry is its position in its own list plus, for every other list, the number of entries that come before it
 // (a binary search: the order is total - equal (score, id) pairs are ordered by shard).  No sorting network, no barrier but the
-// one behind the load: 8 x 100 entries merge in a few microseconds instead of the 55-stage bitonic sort of 1024 pairs (51 us).
+// ones behind the load.  Measured per launch at nq = 1024, k = 100 (kernel trace, tools/bench_merge.py): 2 shards 7 us (sorting
+// network 14), 4 shards 20 (26), 8 shards 38-50 either way - there the launch is bound by per-workgroup latency outside the merge.
 // The kernel verifies the precondition while loading and falls back to the bitonic sort for lists that are not sorted.
 __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict__ scores, const int64_t* __restrict__ ids,
                                                          int64_t stride_s, int64_t stride_i, int n_shards, int64_t nq, int k, int k_out,
