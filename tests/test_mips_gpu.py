@@ -308,7 +308,8 @@ def test_merge_topk_handles_pads_and_ties():
     np.testing.assert_array_equal(ms.cpu().numpy(), rs)
 
 
-@pytest.mark.parametrize("n_sh,nq,k,k_out", [(8, 1024, 100, 100), (8, 40, 200, 200), (3, 17, 100, 30), (2, 5, 7, 64), (1, 9, 100, 100), (8, 6, 1000, 1000)])
+@pytest.mark.parametrize("n_sh,nq,k,k_out", [(8, 1024, 100, 100), (8, 40, 200, 200), (3, 17, 100, 30), (2, 5, 7, 64), (1, 9, 100, 100), (8, 6, 1000, 1000),
+                                             (5, 3, 1638, 2000), (4, 3, 2048, 2048), (7, 11, 33, 33)])
 @pytest.mark.parametrize("ordered", [True, False])
 def test_merge_topk_ranked_path_and_unsorted_fallback(n_sh, nq, k, k_out, ordered):
     """Sorted shard lists (what the search writes) take the rank-by-binary-search path; lists in any other order must fall

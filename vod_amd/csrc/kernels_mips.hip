@@ -23,6 +23,7 @@
 #include "mips_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -1110,30 +1111,44 @@ __device__ __forceinline__ bool pair_before(float sa, int64_t ia, float sb, int6
     return ia < ib;
 }
 
-// Fast path: every shard's list arrives sorted best-first with its pads at the tail (what the search writes), so the merged
-// position of an entry is its position in its own list plus, for every other list, the number of entries that come before it
-// (a binary search: the order is total - equal (score, id) pairs are ordered by shard).  No sorting network, no barrier but the
-// ones behind the load.  Measured per launch at nq = 1024, k = 100 (kernel trace, tools/bench_merge.py): 2 shards 7 us (sorting
-// network 14), 4 shards 20 (26), 8 shards 38-50 either way - there the launch is bound by per-workgroup latency outside the merge.
-// The kernel verifies the precondition while loading and falls back to the bitonic sort for lists that are not sorted.
+// Every shard's list arrives sorted best-first with its pads at the tail (what the search writes), so the merge is a tree of
+// pairwise TOP-L merges instead of a sort: list A against the mirrored list B through one half-cleaner stage leaves the L best of
+// both in A as a bitonic sequence, log2(L) more compare-exchange stages sort it; log2(n_shards) levels.  8 x 100 entries: 24
+// stages on shrinking data against the 55 full-width stages of a bitonic sort of 1024 pairs.  Lists are padded to L = pow2 >=
+// max(k, min(k_out, n_shards * k)) entries, shards to a power of two.  The kernel verifies the precondition while loading and
+// sorts everything (same network, all stages) when a list is not sorted.
+__device__ __forceinline__ void merge_ce(float* ssc, int64_t* sid, int a, int b) {  // best of (a, b) to a
+    const float sa = ssc[a], sb = ssc[b];
+    const int64_t ia = sid[a], ib = sid[b];
+    if (pair_before(sb, ib, sa, ia)) {
+        ssc[a] = sb;
+        ssc[b] = sa;
+        sid[a] = ib;
+        sid[b] = ia;
+    }
+}
+
 __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict__ scores, const int64_t* __restrict__ ids,
                                                          int64_t stride_s, int64_t stride_i, int n_shards, int64_t nq, int k, int k_out,
-                                                         float* __restrict__ out_scores, int64_t* __restrict__ out_ids) {
+                                                         int L, int S2, int flat, float* __restrict__ out_scores,
+                                                         int64_t* __restrict__ out_ids) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int total = n_shards * k;
-    int P = 64;
-    while (P < total) P <<= 1;
+    // entries in LDS: list t at [t * L, t * L + L); `flat` (padded lists would not fit): one list of all n_shards * k entries
+    const int P = S2 * L;
     int64_t* sid = (int64_t*)smem;
     float* ssc = (float*)(smem + (size_t)P * 8);
+    int* s_flag = (int*)(smem + (size_t)P * 12);  // all LDS in the one dynamic array
     const int64_t q = blockIdx.x;
     const int tid = threadIdx.x;
+    const int lmask = L - 1, lshift = 31 - __builtin_clz(L);
+    if (tid == 0) *s_flag = 0;
     for (int i = tid; i < P; i += 256) {
+        const int t = flat ? i / k : i >> lshift, c = flat ? i % k : i & lmask;
         float s = -__builtin_inff();
         int64_t id = -1;
-        if (i < total) {
-            const int sh = i / k, c = i % k;
-            s = scores[(int64_t)sh * stride_s + q * k + c];
-            id = ids[(int64_t)sh * stride_i + q * k + c];
+        if (t < n_shards && c < k) {
+            s = scores[(int64_t)t * stride_s + q * k + c];
+            id = ids[(int64_t)t * stride_i + q * k + c];
             if (id < 0 || s != s) {
                 id = -1;
                 s = -__builtin_inff();
@@ -1143,86 +1158,38 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
         sid[i] = id;
     }
     __syncthreads();
-    // precondition check: within a shard, no entry may come strictly before its predecessor (pads sink to the tail)
-    int unsorted = 0, n_valid = 0;
-    for (int i = tid; i < total; i += 256) {
-        n_valid += sid[i] >= 0;
-        if (i % k + 1 < k) unsorted |= pair_before(ssc[i + 1], sid[i + 1], ssc[i], sid[i]) ? 1 : 0;
-    }
-    int* s_flag = (int*)(smem + (size_t)P * 12 + 16);  // (HIP's __syncthreads_or brings a static LDS object of its own)
-    if (tid == 0) *s_flag = 0;
-    __syncthreads();
+    // precondition check: within a list, no entry may come strictly before its predecessor (pads sink to the tail)
+    int unsorted = 0;
+    for (int i = tid; i < P; i += 256)
+        if ((i & lmask) + 1 < L) unsorted |= pair_before(ssc[i + 1], sid[i + 1], ssc[i], sid[i]) ? 1 : 0;
     if (unsorted) *s_flag = 1;
     __syncthreads();
-    unsorted = *s_flag;
-    if (!unsorted) {
-        int* s_valid = (int*)(smem + (size_t)P * 12);  // 4 ints behind the entries (all LDS in the one dynamic array)
-        for (int o = 32; o > 0; o >>= 1) n_valid += __shfl_xor(n_valid, o);
-        if ((tid & 63) == 0) s_valid[tid >> 6] = n_valid;
-        __syncthreads();
-        n_valid = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
-        int n_steps = 1;  // binary-search steps that always suffice: 2^n_steps > k
-        while ((1 << n_steps) <= k) ++n_steps;
-        for (int i = tid; i < total; i += 256) {
-            const int64_t id = sid[i];
-            if (id < 0) continue;
-            const float sc = ssc[i];
-            const int sh = i / k;
-            int rank = i % k;
-            // 8 lists at a time, their binary searches in lockstep: one step = 8 independent LDS reads in flight (a chain of
-            // 7 lists x 7 dependent reads per entry made this path no faster than the sorting network)
-            for (int t0 = 0; t0 < n_shards && rank < k_out; t0 += 8) {
-                int lo[8], hi[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    lo[u] = 0;
-                    hi[u] = (t0 + u < n_shards && t0 + u != sh) ? k : 0;
+    if (*s_flag) {
+        // general case: bitonic sort of all P entries, best first
+        for (int size = 2; size <= P; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                __syncthreads();
+                for (int t = tid; t < (P >> 1); t += 256) {
+                    const int pos = 2 * t - (t & (stride - 1));
+                    if ((pos & size) == 0) merge_ce(ssc, sid, pos, pos + stride); else merge_ce(ssc, sid, pos + stride, pos);
                 }
-                for (int step = 0; step < n_steps; ++step) {
-                    float ms[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) ms[u] = lo[u] < hi[u] ? ssc[(t0 + u) * k + ((lo[u] + hi[u]) >> 1)] : 0.f;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        if (lo[u] < hi[u]) {
-                            const int mid = (lo[u] + hi[u]) >> 1;
-                            bool before = ms[u] > sc;
-                            if (ms[u] == sc) {  // equal scores: smaller id first, pads last, equal pairs in shard order
-                                const int64_t mi = sid[(t0 + u) * k + mid];
-                                before = mi >= 0 && (mi < id || (mi == id && t0 + u < sh));
-                            }
-                            if (before) lo[u] = mid + 1; else hi[u] = mid;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) rank += lo[u];
-            }
-            if (rank < k_out) {
-                out_scores[q * k_out + rank] = sc;
-                out_ids[q * k_out + rank] = id;
             }
         }
-        for (int r = n_valid + tid; r < k_out; r += 256) {  // fewer valid entries than k_out: pads
-            out_scores[q * k_out + r] = -__builtin_inff();
-            out_ids[q * k_out + r] = -1;
-        }
-        return;
-    }
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+    } else {
+        for (int w = 1; w < S2; w <<= 1) {  // level: lists j and j + w (j a multiple of 2w) -> the L best of both, sorted, in list j
+            const int n_pairs = S2 / (2 * w);
             __syncthreads();
-            for (int t = tid; t < (P >> 1); t += 256) {
-                const int pos = 2 * t - (t & (stride - 1));
-                const float sa = ssc[pos], sb = ssc[pos + stride];
-                const int64_t ia = sid[pos], ib = sid[pos + stride];
-                const bool fwd = (pos & size) == 0;  // this run must end up best-first
-                const bool swap = fwd ? pair_before(sb, ib, sa, ia) : pair_before(sa, ia, sb, ib);
-                if (swap) {
-                    ssc[pos] = sb;
-                    ssc[pos + stride] = sa;
-                    sid[pos] = ib;
-                    sid[pos + stride] = ia;
+            for (int e = tid; e < n_pairs * L; e += 256) {  // half-cleaner against the mirrored partner
+                const int pr = e >> lshift, c = e & lmask;
+                const int a = (pr * 2 * w) * L + c, b = (pr * 2 * w + w) * L + (L - 1 - c);
+                merge_ce(ssc, sid, a, b);
+            }
+            for (int stride = L >> 1; stride > 0; stride >>= 1) {  // list j is bitonic now: sort it
+                __syncthreads();
+                for (int e = tid; e < n_pairs * (L >> 1); e += 256) {
+                    const int pr = e >> (lshift - 1), c = e & ((L >> 1) - 1);
+                    const int pos = (pr * 2 * w) * L + 2 * c - (c & (stride - 1));
+                    merge_ce(ssc, sid, pos, pos + stride);
                 }
             }
         }
@@ -1231,7 +1198,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
     for (int i = tid; i < k_out; i += 256) {
         float s = -__builtin_inff();
         int64_t id = -1;
-        if (i < P) {
+        if (i < ((*s_flag) ? P : L)) {
             s = ssc[i];
             id = sid[i];
         }
@@ -1244,13 +1211,21 @@ hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int64_t st
                              int64_t nq, int k, int k_out, float* out_scores, int64_t* out_ids, hipStream_t stream) {
     if (nq == 0) return hipSuccess;
     const int total = n_shards * k;
-    size_t P = 64;
-    while ((int)P < total) P <<= 1;
-    const size_t lds = P * 12 + 32;
+    int L = 1, S2 = 1;
+    while (L < std::max(k, std::min(k_out, total))) L <<= 1;
+    while (S2 < n_shards) S2 <<= 1;
+    int flat = 0;
+    if ((size_t)S2 * L * 12 > 128 * 1024) {  // padded lists too large (odd shard counts with k in the thousands): sort everything
+        flat = 1;
+        S2 = 1;
+        L = 1;
+        while (L < total) L <<= 1;
+    }
+    const size_t lds = (size_t)S2 * L * 12 + 16;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (hipError_t e = allow_dynamic_lds((const void*)merge_topk_kernel, 160 * 1024); e != hipSuccess) return e;
-    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(256), lds, stream, scores, ids, stride_s, stride_i, n_shards, nq, k, k_out,
-                       out_scores, out_ids);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(256), lds, stream, scores, ids, stride_s, stride_i, n_shards, nq, k,
+                       k_out, L, S2, flat, out_scores, out_ids);
     return hipGetLastError();
 }
 
