@@ -1114,7 +1114,9 @@ __device__ __forceinline__ bool pair_before(float sa, int64_t ia, float sb, int6
 // Every shard's list arrives sorted best-first with its pads at the tail (what the search writes), so the merge is a tree of
 // pairwise TOP-L merges instead of a sort: list A against the mirrored list B through one half-cleaner stage leaves the L best of
 // both in A as a bitonic sequence, log2(L) more compare-exchange stages sort it; log2(n_shards) levels.  8 x 100 entries: 24
-// stages on shrinking data against the 55 full-width stages of a bitonic sort of 1024 pairs.  Lists are padded to L = pow2 >=
+// stages on shrinking data against the 55 full-width stages of a bitonic sort of 1024 pairs - 14 us per launch at nq = 1024
+// (the host-side floor of tools/bench_merge.py) against 55 us; 8 x 200 at nq = 512: 18 against 81.  (A rank-by-binary-search
+// variant was no faster than the full sort at 8 shards: ~40 k search steps of ~20 instructions per query.)  Lists are padded to L = pow2 >=
 // max(k, min(k_out, n_shards * k)) entries, shards to a power of two.  The kernel verifies the precondition while loading and
 // sorts everything (same network, all stages) when a list is not sorted.
 __device__ __forceinline__ void merge_ce(float* ssc, int64_t* sid, int a, int b) {  // best of (a, b) to a
