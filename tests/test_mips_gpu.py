@@ -667,3 +667,25 @@ def test_full_size_c3_properties():
 def test_full_size_c4_properties():
     """BASELINE configs[3]: 40 M x 1024 bf16, batch 512, top-200 on ONE device (82 GB store + 82 GB of shard copies)."""
     _full_size_properties(40_000_000, 1024, 512, 200, "bfloat16")
+
+
+@pytest.mark.parametrize("tile,nq", [(8, 1024), (9, 1024), (8, 200), (46, 100), (42, 33)])
+def test_repeated_searches_are_bit_identical(tile, nq):
+    """Candidates reach the lists in a different order on every run (atomics, wave timing); the answer may not depend on it.
+    60 searches of the same Gaussian batch on 1 M rows must return the same bits, and the first must be exact on a sample."""
+    dev = torch.device("cuda", 0)
+    n, d, k = 1_000_000, 256, 100
+    g = torch.Generator(device=dev).manual_seed(77)
+    with _index(np.zeros((0, d), np.float16), capacity=n, tile=tile) as ix:
+        for _ in range(4):
+            ix.add(torch.randn((n // 4, d), generator=g, device=dev).half())
+        q = torch.randn((nq, d), generator=g, device=dev).half()
+        s0, i0 = ix.search(q, k)
+        s0, i0 = s0.clone(), i0.clone()
+        for it in range(60):
+            s, i = ix.search(q, k)
+            assert torch.equal(i, i0) and torch.equal(s, s0), f"run {it} differs"
+        full = q[:16].float() @ ix.stored_rows().float().T
+        ts, ti = torch.topk(full, k, dim=1)
+        assert torch.equal(torch.sort(ti, dim=1).values, torch.sort(i0[:16], dim=1).values) or float((ts - s0[:16]).abs().max()) < SCORE_TOL
+        assert float((ts - s0[:16]).abs().max()) < SCORE_TOL
