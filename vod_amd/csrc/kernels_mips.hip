@@ -97,7 +97,7 @@ void mips_filter_kernel(
             const int bb = r & 31;
             const int grp_in_tile = ((r / TM) * MI + (r % TM) / 32) * 2 + ((bb >> 2) & 1);
             const int idx = (bb >> 3) * 4 + (bb & 3);
-            grow = ((size_t)idx * (size_t)ex.sample_groups + (size_t)xt * (BM / 16) + grp_in_tile) * (size_t)ex.sample_rstride;
+            grow = ((size_t)idx * (size_t)ex.sample_groups + (size_t)xt * (BM / 16) + grp_in_tile) * (size_t)ex.sample_rstride + (size_t)ex.sample_offset;
         }
         a_src[t] = (const char*)X + (grow * dim_pad + c * 8) * 2;
     }
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
             // member * n_groups + group id, i.e. every group holds ONE row of each of 32 strata of the store
             const int grp_in_tile = (r >> 7) * 4 + ((r >> 2) & 3);
             const int idx = ((r >> 4) & 7) * 4 + (r & 3);
-            grow = ((size_t)idx * (size_t)ex.sample_groups + (size_t)xt0 * 8 + grp_in_tile) * (size_t)ex.sample_rstride;
+            grow = ((size_t)idx * (size_t)ex.sample_groups + (size_t)xt0 * 8 + grp_in_tile) * (size_t)ex.sample_rstride + (size_t)ex.sample_offset;
         }
         a_src[t] = (const char*)X + (grow * dim_pad + (st_slot ^ ((r >> 1) & 7)) * 8) * 2;
         if (abl_blocked)

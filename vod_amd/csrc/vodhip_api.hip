@@ -299,6 +299,9 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
                 if (tiles256 < ix->small_chunk_tiles) tile_c = 1;  // fewer than one 256x256 tile per CU
             }
             ix->ws.extra.sample_rstride = (int)sg.rstride;
+            // S sampled rows at offset + i * rstride, i < S: the (ntotal - 1) % rstride-ish rows the integer stride leaves out
+            // are split between the head and the tail of the store
+            ix->ws.extra.sample_offset = sg.kind == ST_GMAX ? (int)(((ix->ntotal - 1) - (sg.n_tiles * filter_tile_rows(tile_c) - 1) * sg.rstride) / 2) : 0;
             ix->ws.extra.sample_groups = (int)sg.n_groups;
             const bool last = c + 1 == stages.size();
             HIP_OK(launch_filter(ix->dtype, tile_c, sg.kind, ix->data, ws.q_pad, ix->dim_pad, sg.b, sg.e, sg.n_tiles, nq, nq_pad,

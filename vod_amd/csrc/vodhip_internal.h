@@ -25,6 +25,7 @@ struct FilterExtra {
     const int* q_label = nullptr;     // [nq, n_qlab] allowed labels per query (-1 = empty slot; all -1 = unrestricted)
     int n_qlab = 0;
     int sample_rstride = 0;           // GMAX launches: store rows between consecutive sampled rows (>= 1)
+    int sample_offset = 0;            // GMAX launches: first sampled row (centres the sample: the unsampled rows split between head and tail)
     int sample_groups = 0;            // GMAX launches: number of lane groups of the sample (= candidate slots per query)
     const int* q_map = nullptr;       // recovery of a few queries: workspace row -> row of the caller's batch (q_label is indexed by the latter)
 };
