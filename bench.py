@@ -60,6 +60,31 @@ def parse_args() -> argparse.Namespace:
     return p.parse_args()
 
 
+def _free_rendezvous_port(socket) -> int:
+    """A free port BELOW the kernel's ephemeral range: ranks 1..N-1 retry the rendezvous while rank 0 is still importing
+    torch, and a client retrying a not-yet-listening localhost port inside that range can be given the port itself as
+    its source (TCP self-connect), after which rank 0's listen fails with EADDRINUSE."""
+    import random
+
+    try:
+        with open("/proc/sys/net/ipv4/ip_local_port_range") as f:
+            lo = int(f.read().split()[0])
+    except (OSError, ValueError):
+        lo = 32768
+    rng = random.SystemRandom()
+    for _ in range(64):
+        port = rng.randrange(20000, max(20001, min(lo, 32768)))
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh children (one per GPU) and wait for them.
 
@@ -68,9 +93,7 @@ def launch_ranks(n: int) -> int:
     import socket
     import subprocess
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = _free_rendezvous_port(socket)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),

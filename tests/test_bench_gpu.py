@@ -76,3 +76,55 @@ print("sharded exchange ok")
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "sharded exchange ok" in out.stdout
+
+
+def test_sharded_index_two_ranks_on_one_gpu(tmp_path):
+    """world_size 2 on real kernels: two processes share the box's GPU, each holds one row shard in its own HIP context and
+    runs `ShardedFlatIndex`'s native path (fused HIP search with the shard's id offset -> ONE packed all-gather -> HIP
+    merge).  RCCL refuses two ranks on one device, so the group is gloo and the exchange is staged through the host
+    (`ShardedFlatIndex._all_gather`); everything else is the multi-GPU code.  Both ranks must hold the oracle's answer
+    for the WHOLE store, ties across the shard boundary included (integer-valued rows)."""
+    script = tmp_path / "two_ranks.py"
+    script.write_text(f"""
+import os
+import sys
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, {str(ROOT)!r})
+from oracle.flat_ip import flat_ip_topk
+from vod_amd.distributed import ShardedFlatIndex, shard_bounds
+from vod_amd.index import HipFlatIndex
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+rng = np.random.default_rng(3)
+n, d, nq = 90001, 160, 260
+x = rng.integers(-5, 6, size=(n, d)).astype(np.float16)
+q = rng.integers(-5, 6, size=(nq, d)).astype(np.float16)
+bounds = shard_bounds(n, world, align=256)
+lo, hi = bounds[rank], bounds[rank + 1]
+ix = HipFlatIndex(d, hi - lo)
+ix.add(x[lo:hi])
+sh = ShardedFlatIndex(ix, row_offset=lo)
+tq = torch.from_numpy(q).cuda()
+for k in (100, 7, 300):
+    s, i = sh.search(tq, k)
+    rs, ri = flat_ip_topk(q.astype(np.float32), x.astype(np.float32), k)
+    assert np.array_equal(i.cpu().numpy(), ri), (rank, k)
+    assert np.array_equal(s.cpu().numpy(), rs), (rank, k)
+    assert (ri >= hi if rank == 0 else ri < lo).any(), "the answer must draw on the OTHER rank's shard"
+dist.barrier()
+dist.destroy_process_group()
+print(f"rank {{rank}} ok", flush=True)
+""")
+    port = "29547"
+    procs = [subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(r), WORLD_SIZE="2"))
+             for r in range(2)]
+    for r, p in enumerate(procs):
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        assert f"rank {r} ok" in out

@@ -41,6 +41,17 @@ class ShardedFlatIndex:
         self._merge = merge
         self._packed = None
 
+    def _all_gather(self, dst: torch.Tensor, src: torch.Tensor) -> None:
+        """ONE all-gather of the packed result.  RCCL moves device buffers directly; a gloo group (the server's
+        `--group-backend gloo`: ranks that share a GPU, hosts without RCCL) has no device all-gather, so the 1.2 MB are
+        staged through the host - same collective sequence, same merge."""
+        if src.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = torch.empty(dst.shape, dtype=dst.dtype)
+            dist.all_gather_into_tensor(host, src.cpu(), group=self.group)
+            dst.copy_(host)
+        else:
+            dist.all_gather_into_tensor(dst, src, group=self.group)
+
     @property
     def world(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
@@ -58,7 +69,7 @@ class ShardedFlatIndex:
                 self._gathered = torch.empty((world * self._packed.nbytes,), dtype=torch.uint8, device=self.local_index.device)
             p = self._packed
             self.local_index.search(queries, k, id_base=self.row_offset, out=(p.scores, p.ids), subset=subset)
-            dist.all_gather_into_tensor(self._gathered, p.buffer, group=self.group)  # 12 * nq * k bytes per rank, one collective
+            self._all_gather(self._gathered, p.buffer)  # 12 * nq * k bytes per rank, one collective
             return p.merge_gathered(self._gathered, world)
         s, i = self._local_search(queries, k, self.row_offset) if subset is None else self._local_search(queries, k, self.row_offset, subset)
         if world == 1:

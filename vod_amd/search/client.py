@@ -142,6 +142,7 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         device: int = 0,
         devices: None | list[int] = None,
         serve_on_gpu: bool = True,  # noqa: ARG002 - accepted for call-site compatibility: this engine only exists on the GPU
+        group_backend: str = "nccl",  # with `devices`: "nccl" (RCCL, one GPU per worker) or "gloo" (host-staged; workers may share a GPU)
     ):
         super().__init__(skip_setup=skip_setup, free_resources=free_resources)
         self.vectors_path = pathlib.Path(vectors_path)
@@ -154,6 +155,7 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         # GPU on an RCCL group; what `FaissMaster(serve_on_gpu=True)` gets from faiss's index_cpu_to_all_gpus,
         # /root/reference/src/vod_search/faiss_search/client.py:118-137, server.py:51-54)
         self.devices = None if devices is None else [int(d) for d in devices]
+        self.group_backend = group_backend
 
     def _make_env(self) -> dict[str, str]:
         env = copy(dict(os.environ))
@@ -169,7 +171,8 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
             "--port", str(self.port),
             "--logging-level", str(self.logging_level),
             "--dtype", self.dtype,
-            *(["--devices", ",".join(map(str, self.devices))] if self.devices is not None else ["--device", str(self.device)]),
+            *(["--devices", ",".join(map(str, self.devices)), "--group-backend", self.group_backend]
+              if self.devices is not None else ["--device", str(self.device)]),
         ]
 
     def get_client(self) -> HipMipsClient:

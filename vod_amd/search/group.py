@@ -10,7 +10,7 @@ answers.  Ranks > 0 sit in `worker_loop()` until rank 0 broadcasts the stop word
 
 The collective sequence is identical on every rank by construction (header, payload, search); rank 0 must
 serialise its callers (the server's lock does).  `device` is where the broadcast tensors live: the rank's GPU
-under RCCL, the CPU under gloo (tests).
+under RCCL, the CPU under gloo (tests, `--group-backend gloo`); `search_device` is where the shard lives.
 """
 from __future__ import annotations
 
@@ -22,9 +22,12 @@ OP_STOP, OP_SEARCH = 0, 1
 
 
 class GroupDispatcher:
-    def __init__(self, sharded, rank: int, world: int, device: torch.device, group: dist.ProcessGroup | None = None):
+    def __init__(self, sharded, rank: int, world: int, device: torch.device, group: dist.ProcessGroup | None = None,
+                 search_device: torch.device | None = None):
         self.sharded = sharded  # ShardedFlatIndex-like: .search(queries, k, subset=None) -> (scores, ids), collective
         self.rank, self.world, self.device, self.group = rank, world, device, group
+        # where the shard lives when that is not where the broadcast tensors live (gloo group in front of GPU shards)
+        self.search_device = device if search_device is None else search_device
 
     # -- rank 0 ------------------------------------------------------------------------------------
     def search(self, query_vec: np.ndarray, top_k: int, subset: np.ndarray | None = None) -> tuple[np.ndarray, np.ndarray]:
@@ -40,8 +43,14 @@ class GroupDispatcher:
             dist.broadcast(q, 0, group=self.group)
             if sub is not None:
                 dist.broadcast(sub, 0, group=self.group)
-        scores, ids = self.sharded.search(q, int(top_k), subset=sub)
+        scores, ids = self._local(q, int(top_k), sub)
         return scores.cpu().numpy(), ids.cpu().numpy()
+
+    def _local(self, q: torch.Tensor, k: int, sub: torch.Tensor | None) -> tuple[torch.Tensor, torch.Tensor]:
+        if self.search_device != self.device:
+            q = q.to(self.search_device)
+            sub = None if sub is None else sub.to(self.search_device)
+        return self.sharded.search(q, k, subset=sub)
 
     def stop(self) -> None:
         if self.rank == 0 and self.world > 1:
@@ -64,5 +73,5 @@ class GroupDispatcher:
             if n_sub:
                 sub = torch.empty((nq, n_sub), dtype=torch.int32, device=self.device)
                 dist.broadcast(sub, 0, group=self.group)
-            self.sharded.search(q, k, subset=sub)
+            self._local(q, k, sub)
             served += 1

@@ -289,6 +289,9 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument("--micro-batch-wait-ms", type=float, default=0.0,
                    help="> 0: fuse requests that arrive within this window into one GPU batch (default: serialise, as the reference)")
     # set by the owner process for its workers
+    p.add_argument("--group-backend", type=str, default="nccl", choices=["nccl", "gloo"],
+                   help="with --devices: the workers' process group.  nccl = RCCL over xGMI (one GPU per worker); gloo = requests "
+                        "and the per-shard top-k travel through host memory, so several workers may share a GPU (bring-up, tests)")
     p.add_argument("--rank", type=int, default=None, help=argparse.SUPPRESS)
     p.add_argument("--master-port", type=int, default=0, help=argparse.SUPPRESS)
     return p.parse_args(argv)
@@ -351,13 +354,16 @@ def run_worker(args: argparse.Namespace) -> None:
     rank, world = args.rank, len(devices)
     torch.cuda.set_device(devices[rank])
     dev = torch.device("cuda", devices[rank])
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{args.master_port}", rank=rank, world_size=world, device_id=dev)
+    if args.group_backend == "nccl":
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{args.master_port}", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{args.master_port}", rank=rank, world_size=world)
     n = store.open_vectors(args.vectors_path).shape[0]
     bounds = shard_bounds(n, world, align=256)
     local = HipEngine(args.vectors_path, dtype=args.dtype, device=devices[rank], subset_ids_path=args.subset_ids_path,
                       row_range=(bounds[rank], bounds[rank + 1]))
     sharded = ShardedFlatIndex(local.index, row_offset=bounds[rank], always_exchange=True)
-    dispatcher = GroupDispatcher(sharded, rank, world, dev)
+    dispatcher = GroupDispatcher(sharded, rank, world, dev if args.group_backend == "nccl" else torch.device("cpu"), search_device=dev)
     dist.barrier()  # every shard is resident before rank 0 starts answering (the master's ping loop waits for that)
     if rank != 0:
         dispatcher.worker_loop()
