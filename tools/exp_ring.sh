@@ -1,0 +1,21 @@
+#!/bin/bash
+# Ring kernel (tiles 10 / 11) vs the two-slot persistent kernel (tile 8): bench lines on one box.  PARITY=1 runs the parity tests first.
+out=gpurun_out/exp_ring.txt; mkdir -p gpurun_out; : > $out
+if [ -n "$PARITY" ]; then timeout 900 python -m pytest tests/test_mips_gpu.py -x -q -m gpu -k "not full_size" 2>&1 | tail -5 >> $out; fi
+run() { echo "== $*" >> $out; timeout 600 python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | python3 -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); r=d['roofline']; v=d.get('verify') or {}
+        print('ms/step %.4f  filter_ms %.4f  launches %.1f  qps %.0f  frac %.3f recovery %s recall %s' % (d['ms_per_step'], r['kernel_ms_per_step'], r['launches_per_step'], d['value'], r['frac'], d['config'].get('recovery_passes'), v.get('recall_at_k_vs_torch_fp32')))
+" >> $out; }
+TILES=${TILES:-"8 10 11"}
+for t in $TILES $TILES; do
+run --param tile=$t
+done
+for t in $TILES; do
+run --param tile=$t --rows 1250000
+run --param tile=$t --rows 1000000 --nq 256
+run --param tile=$t --nq 256
+done
+cat $out

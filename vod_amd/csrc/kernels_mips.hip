@@ -966,10 +966,9 @@ hipError_t launch_search_prepare(const SearchWorkspace& ws, const void* q_src, i
 
 int filter_tile_rows(int tile) { return tile == 1 ? 128 : 256; }
 int filter_tile_cols(int tile) { return tile == 42 ? 64 : (tile == 46 || tile == 1) ? 128 : 256; }
-int filter_group_rows(int tile) { return (tile == 8 || tile == 9) ? 32 : 16; }  // rows per GMAX group
+int filter_group_rows(int tile) { return filter_tile_is_persistent(tile) ? 32 : 16; }  // rows per GMAX group (tiles 10 / 11 bootstrap on tile 8's kernel)
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel): it is a driver call on the launch path
-static hipError_t allow_dynamic_lds(const void* kernel, int bytes) {
+hipError_t allow_dynamic_lds(const void* kernel, int bytes) {
     static std::mutex mu;
     static std::map<std::pair<int, const void*>, int> granted;
     int dev = 0;
@@ -1065,7 +1064,14 @@ hipError_t launch_filter(int store_dtype, int tile, int mode, const void* store,
     if (mode != MODE_GMAX && row_end <= row_begin) return hipSuccess;
     if (mode == MODE_GMAX && n_sample_tiles <= 0) return hipSuccess;
     const bool subset = ws.extra.row_label != nullptr;
-    if ((tile == 8 || tile == 9) && mode == MODE_DENSE) tile = 1;  // nq_pad is a multiple of 256, which the 128-wide tile divides
+    if (filter_tile_is_persistent(tile) && mode == MODE_DENSE) tile = 1;  // nq_pad is a multiple of 256, which the 128-wide tile divides
+    if (tile == 10 || tile == 11) {  // deep-ring FILTER kernel: `make ABLATION=1 EXPERIMENTS=1` builds only (vodhip_index_set_param refuses the ids otherwise)
+#ifdef VODHIP_EXPERIMENTS
+        if (mode == MODE_FILTER)
+            return launch_filter_ring(store_dtype, tile == 11, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+#endif
+        tile = 8;  // the bootstrap (group maxima of a row sample) runs on the two-slot kernel
+    }
     const int bm = filter_tile_rows(tile);
     FilterLaunch L{store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad,
                    mode == MODE_GMAX ? (int)n_sample_tiles : (int)((row_end - row_begin + bm - 1) / bm), &ws, stream};

@@ -200,7 +200,7 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad,
     }
     const int64_t s_min = std::min(s_max, round_up(std::max<int64_t>(4 * rg * (int64_t)k, 2048), bm));
     int64_t s = std::min(s_max, std::max(s_min, round_up(n / std::max<int64_t>(ix->sample_div, 2), bm)));
-    if (gmax_tile == 8 || gmax_tile == 9) {
+    if (filter_tile_is_persistent(gmax_tile)) {
         // the persistent kernel runs one workgroup per CU: a bootstrap of r.x "rounds" of tiles costs as much as r+1 full ones.
         // Whole rounds only: down when that keeps >= 4k groups (a cheaper bootstrap), up otherwise (a tighter bound for free)
         int dev = 0, n_cu = 256;
@@ -239,7 +239,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
     // ring (few query bytes per corpus byte through the LDS-DMA path); above, the persistent 256x256 tile on
     // v_mfma_f32_16x16x32 (8; variant 9 staggers the two waves of every SIMD by one k-step: measured equal or 1-2 % slower)
     if (tile == 0) tile = ps.nq > 128 ? 8 : (ps.nq > 64 ? 46 : 42);
-    const bool persistent = tile == 8 || tile == 9;
+    const bool persistent = filter_tile_is_persistent(tile);
     const int64_t bn = filter_tile_cols(tile);
 
     std::vector<Stage> stages;
@@ -632,7 +632,12 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
     } else if (!strcmp(key, "profile")) {
         ix->profile = value;
     } else if (!strcmp(key, "tile")) {
-        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 42 && value != 46)
+#ifdef VODHIP_EXPERIMENTS
+        const bool ring_ok = true;  // tiles 10 / 11: the deep-ring FILTER kernel of experiment builds
+#else
+        const bool ring_ok = false;
+#endif
+        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 42 && value != 46 && !(ring_ok && (value == 10 || value == 11)))
             return fail("tile must be 0 (auto) or a filter-kernel variant id: 1, 8, 9, 42, 46 (DESIGN.md 4.1)");
         ix->tile = value;
     } else {
