@@ -91,6 +91,11 @@ def merge_search_results(results: dict[str, tuple], weights: dict[str, float]):
     `results[name] = (scores, indices, labels_or_None)`; returns (scores, indices, labels_or_None, raw_scores dict).
     """
     keys = list(results.keys())
+    if len(keys) == 1:  # a single result set is returned as is, weighted: no union, labels as given (merge.py:18-22)
+        s0, i0, l0 = results[keys[0]]
+        with warnings.catch_warnings(), np.errstate(all="ignore"):
+            warnings.simplefilter("ignore")
+            return s0 * weights[keys[0]], i0, l0, {keys[0]: s0}
     with warnings.catch_warnings(), np.errstate(all="ignore"):
         warnings.simplefilter("ignore")
         s0, i0, _ = results[keys[0]]

@@ -157,6 +157,44 @@ def gen_merge() -> None:
     _save("merge_two_engines", {"cases": params}, **arrays)
 
 
+def gen_merge_corners() -> None:
+    """Corner cases a randomised campaign (tools/fuzz_collate.py) found the oracle restating differently from the reference:
+    ids repeated INSIDE one engine's row (different labels / scores per occurrence) and NaN scores, with 0, 1 and 2 scored
+    engines.  With the lookup alone `merge_search_results` returns it untouched (merge.py:18-22): no union, labels as given."""
+    rng = np.random.default_rng(4242)
+    nq, n_ids = 6, 9
+
+    def eng(k, labels):
+        idx = rng.integers(0, n_ids, size=(nq, k)).astype(np.int64)   # many repeats
+        scr = (rng.normal(size=(nq, k)) * 3).astype(np.float32)
+        pad = rng.uniform(size=(nq, k)) < 0.2
+        idx[pad], scr[pad] = -1, -np.inf
+        scr[0, 1] = np.nan
+        lbl = None
+        if labels:
+            lbl = rng.integers(1, 4, size=(nq, k)).astype(np.int64)
+            lbl[pad] = 0
+        return idx, scr, lbl
+
+    lookup = eng(7, True)
+    dense = eng(8, False)
+    sparse = eng(5, False)
+    arrays = dict(lookup_idx=lookup[0], lookup_scr=lookup[1], lookup_lbl=lookup[2], dense_idx=dense[0], dense_scr=dense[1],
+                  sparse_idx=sparse[0], sparse_scr=sparse[1])
+    cases = {"lookup_only": {}, "one_engine": {"dense": 0.5}, "two_engines": {"dense": 1.0, "sparse": 2.0}}
+    for name, w in cases.items():
+        res = {"lookup": RB(scores=lookup[1].copy(), indices=lookup[0].copy(), labels=lookup[2].copy())}
+        if "dense" in w:
+            res["dense"] = RB(scores=dense[1].copy(), indices=dense[0].copy())
+        if "sparse" in w:
+            res["sparse"] = RB(scores=sparse[1].copy(), indices=sparse[0].copy())
+        merged, raw = M["search"]._merge_search_results(res, dict(w))
+        arrays[f"{name}_out_idx"], arrays[f"{name}_out_scr"], arrays[f"{name}_out_lbl"] = merged.indices, merged.scores, merged.labels
+        for e, r in raw.items():
+            arrays[f"{name}_raw_{e}"] = r
+    _save("merge_corners", {"cases": cases}, **arrays)
+
+
 # ----------------------------------------------------------------------------------------
 def gen_normalize() -> None:
     arrays = {}
@@ -430,7 +468,13 @@ if __name__ == "__main__":
         gen_gradients_aux()
         (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True))
         raise SystemExit(0)
+    if sys.argv[1:] == ["merge_corners"]:
+        manifest.update(json.loads((HERE / "manifest.json").read_text()))
+        gen_merge_corners()
+        (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True))
+        raise SystemExit(0)
     gen_merge()
+    gen_merge_corners()
     gen_normalize()
     gen_gather()
     gen_sampling()

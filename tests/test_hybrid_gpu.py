@@ -38,6 +38,22 @@ def test_merge_matches_reference_golden(name):
     _eq(raw["sparse"], g["raw_sparse"])
 
 
+@pytest.mark.parametrize("case", ["lookup_only", "one_engine", "two_engines"])
+def test_merge_corner_cases_match_reference_golden(case):
+    """Repeated ids inside an engine's row, NaN scores, the lookup alone (returned untouched): reference-generated."""
+    from vod_amd.core.merge import merge_hybrid
+
+    g = np.load(GOLDEN / "merge_corners.npz")
+    w = MANIFEST["merge_corners"]["params"]["cases"][case]
+    engines = {n: (g[f"{n}_idx"], g[f"{n}_scr"]) for n in w}
+    idx, scr, lbl, raw = merge_hybrid(g["lookup_idx"], g["lookup_lbl"], engines, dict(w))
+    _eq(idx, g[f"{case}_out_idx"])
+    _eq(scr, g[f"{case}_out_scr"])
+    _eq(lbl, g[f"{case}_out_lbl"])
+    for n in w:
+        _eq(raw[n], g[f"{case}_raw_{n}"])
+
+
 def test_collate_entry_point_matches_reference_golden():
     """`merge_search_results` (the `_merge_search_results` mirror) on RetrievalBatch inputs."""
     from vod_amd import types as vt

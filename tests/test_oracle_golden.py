@@ -70,6 +70,22 @@ def test_two_engine_merges_match_reference():
         assert lab is None
 
 
+@pytest.mark.parametrize("case", ["lookup_only", "one_engine", "two_engines"])
+def test_hybrid_merge_corner_cases_match_reference(case):
+    """Ids repeated inside one engine's row (different labels / scores per occurrence), NaN scores, and the lookup alone -
+    which the reference returns untouched (merge.py:18-22).  Found by tools/fuzz_collate.py; fixture from the reference."""
+    g = _load("merge_corners")
+    w = MANIFEST["merge_corners"]["params"]["cases"][case]
+    engines = {n: (g[f"{n}_idx"], g[f"{n}_scr"]) for n in w}
+    idx, scr, lbl, raw = ohyb.merge_hybrid((g["lookup_idx"], g["lookup_scr"], g["lookup_lbl"]), engines, dict(w))
+    _eq(idx, g[f"{case}_out_idx"])
+    _eq(scr, g[f"{case}_out_scr"])
+    _eq(lbl, g[f"{case}_out_lbl"])
+    assert set(raw) == set(w)
+    for n in w:
+        _eq(raw[n], g[f"{case}_raw_{n}"])
+
+
 def test_normalize_matches_reference():
     g = _load("normalize")
     p = MANIFEST["normalize"]["params"]

@@ -1,0 +1,192 @@
+"""Randomised parity campaign for the collate-side kernels (hybrid merge, labeled priority sampling, in-batch flattening,
+retrieval loss forward + backward) against the CPU oracle.  Not part of the test suite: run it on a GPU box when those
+kernels change.      python3 tools/fuzz_collate.py [--trials 300] [--seed 1] [--seconds 600]
+"""
+import argparse
+import sys
+import time
+import traceback
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+
+
+LAST = {}
+
+
+def _eq(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, (what, a.shape, b.shape, a.dtype, b.dtype)
+    if not np.array_equal(a, b, equal_nan=(a.dtype.kind == "f")):
+        bad = np.argwhere(~((a == b) | ((a != a) & (b != b)) if a.dtype.kind == "f" else (a == b)))
+        r = int(bad[0][0])
+        raise AssertionError(f"{what}: {len(bad)} entries differ, first at {bad[0].tolist()}\n  got row {a[r].tolist()[:40]}\n  ref row {b[r].tolist()[:40]}")
+
+
+def fuzz_merge(rng):
+    from oracle.hybrid import merge_hybrid as oracle_merge
+    from vod_amd.core.merge import merge_hybrid
+
+    nq = int(rng.choice([1, 2, 7, 64, 130]))
+    kl = int(rng.choice([0, 1, 5, 32, 128, 600]))
+    ks = [int(rng.choice([0, 1, 3, 16, 128, 700])) for _ in range(int(rng.integers(0, 5)))]
+    if kl + sum(ks) > 4000:
+        ks = ks[:1]
+    n_ids = int(rng.choice([5, 40, 300, 100_000]))
+    pad_frac = float(rng.choice([0.0, 0.2, 0.9]))
+    dup = bool(rng.random() < 0.3)
+
+    def eng(k):
+        idx = np.full((nq, k), -1, dtype=np.int64)
+        scr = np.full((nq, k), -np.inf, dtype=np.float32)
+        for r in range(nq):
+            nv = k if rng.uniform() > pad_frac else int(rng.integers(0, k + 1))
+            nv = min(nv, n_ids) if not dup else nv
+            idx[r, :nv] = rng.choice(n_ids, size=nv, replace=dup)
+            scr[r, :nv] = rng.normal(size=nv).astype(np.float32) * 5
+            if nv and rng.random() < 0.2:
+                scr[r, int(rng.integers(0, nv))] = np.nan
+        return idx, scr
+
+    LAST.clear(); LAST.update(kind="merge", nq=nq, kl=kl, ks=ks, n_ids=n_ids, pad=pad_frac, dup=dup)
+    l_idx, l_scr = eng(kl)
+    l_lbl = (l_scr > -np.inf).astype(np.int64) * rng.integers(1, 3, size=l_scr.shape)
+    engs = {f"e{i}": eng(k) for i, k in enumerate(ks)}
+    weights = {n: float(rng.choice([0.0, 0.5, 1.0, 1.7])) for n in engs}
+    idx, scr, lbl, raw = merge_hybrid(l_idx, l_lbl, engs, weights)
+    o_idx, o_scr, o_lbl, o_raw = oracle_merge((l_idx, np.zeros(l_idx.shape, np.float32), l_lbl), engs, weights)
+    _eq(idx, o_idx, "merge idx")
+    _eq(scr, o_scr, "merge scores")
+    _eq(lbl, o_lbl, "merge labels")
+    for n in engs:
+        _eq(raw[n], o_raw[n], f"merge raw {n}")
+    return dict(kind="merge", nq=nq, kl=kl, ks=ks, n_ids=n_ids, pad=pad_frac, dup=dup)
+
+
+def fuzz_sampling(rng):
+    from oracle.sampling import labeled_priority_sampling_2d
+    from vod_amd.core.sample import labeled_priority_sampling_tensors
+
+    nq = int(rng.choice([1, 3, 64, 200]))
+    n = int(rng.choice([1, 2, 9, 40, 385, 1000, 4096]))
+    k_tot = int(rng.choice([1, 2, 8, 32, 64, 128]))
+    k_pos = int(rng.integers(0, k_tot + 1))
+    temp = float(rng.choice([0.0, 0.5, 1.0, 3.0]))
+    support = int(rng.choice([-1, -1, 1, 10, 100, 2000]))
+    LAST.clear(); LAST.update(kind="sampling", nq=nq, n=n, k_pos=k_pos, k_tot=k_tot, temp=temp, support=support)
+    scores = (rng.normal(size=(nq, n)) * 3).astype(np.float32)
+    scores[rng.uniform(size=scores.shape) < float(rng.choice([0.0, 0.1, 0.8]))] = -np.inf
+    labels = rng.uniform(size=scores.shape) < float(rng.choice([0.0, 0.05, 0.5]))
+    noise = rng.exponential(size=scores.shape).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    out = labeled_priority_sampling_tensors(t(scores), t(labels), t(noise), k_pos, k_tot, normalized=True, temperature=temp,
+                                            max_support_size=support)
+    smp, logw, lab, lse = [o.cpu().numpy() for o in out]
+    sup = max(support, k_tot) if support >= 0 else -1
+    r_smp, r_logw, r_lab, r_lse = labeled_priority_sampling_2d(scores, labels, noise, k_pos, k_tot, True, temp, sup)
+    # The reference orders the samples by an fp32 key through an unstable argsort and computes the weights with
+    # log1p(-exp(-exp(log_p - log_tau))) in fp32, which loses ~eps / x relative accuracy for a sample of inclusion
+    # probability x << 1: ids are compared as per-row SETS split by label, weights after aligning by id, and the tolerance
+    # of a weight follows its conditioning, measured as the distance between the oracle run in fp32 and in fp64.
+    r64 = labeled_priority_sampling_2d(scores.astype(np.float64), labels, noise.astype(np.float64), k_pos, k_tot, True, temp, sup)
+    finite = np.isfinite(r_logw)
+    assert np.array_equal(lab, r_lab), "sample labels"
+    assert np.array_equal(smp < 0, r_smp < 0), "sample count"
+    assert np.array_equal(np.isfinite(logw), finite), "finite log weights"
+    for r in range(nq):
+        f = finite[r]
+        for want in (True, False):
+            m = f & (r_lab[r] == want)
+            if sorted(smp[r][m].tolist()) != sorted(r_smp[r][m].tolist()):
+                raise AssertionError(f"sample ids row {r}:\n  got {smp[r].tolist()}\n  ref {r_smp[r].tolist()}")
+        got = dict(zip(smp[r][f].tolist(), logw[r][f].tolist()))
+        ref = dict(zip(r_smp[r][f].tolist(), r_logw[r][f].tolist()))
+        f64 = np.isfinite(r64[1][r])
+        ref64 = dict(zip(r64[0][r][f64].tolist(), r64[1][r][f64].tolist()))
+        ids = sorted(ref)
+        if ids and sorted(ref64) == ids:  # (else the fp64 run drew a different sample: the row sits on a tie)
+            ga, ra, da = (np.array([d[i] for i in ids]) for d in (got, ref, ref64))
+            # (+ the GPU's own 1-2 ulp exp in the same ill-conditioned expression when k << n)
+            tol = 2e-5 + 2e-5 * np.abs(ra) + 4.0 * np.abs(ra - da).max() + (2e-4 if k_tot * 100 < n else 0.0)
+            bad = np.abs(ga - ra) > tol
+            assert not bad.any(), f"log weights row {r}: got {ga[bad][:4]} ref {ra[bad][:4]} fp64 {da[bad][:4]} tol {tol}"
+        v = smp[r][smp[r] >= 0]
+        assert len(set(v.tolist())) == len(v), "duplicate sample"
+    both = np.isfinite(r_lse)
+    assert np.array_equal(np.isfinite(lse), both), "finite lse"
+    np.testing.assert_allclose(lse[both], r_lse[both], rtol=2e-5, atol=2e-5)
+    return dict(kind="sampling", nq=nq, n=n, k_pos=k_pos, k_tot=k_tot, temp=temp, support=support)
+
+
+def fuzz_gradients(rng):
+    from oracle.gradients import retrieval_gradients
+    from vod_amd.gradients import RetrievalGradients
+
+    B = int(rng.choice([1, 3, 16, 64]))
+    D = int(rng.choice([1, 2, 5, 32, 300, 2048]))
+    H = int(rng.choice([1, 17, 64, 768, 1024]))
+    three_d = bool(rng.random() < 0.5) and D <= 512
+    q = (rng.normal(size=(B, H)) / np.sqrt(H) * 3).astype(np.float32)
+    s = rng.normal(size=((B, D, H) if three_d else (D, H))).astype(np.float32)
+    score = rng.normal(size=(B, D)).astype(np.float32)
+    pad = rng.uniform(size=(B, D)) < float(rng.choice([0.0, 0.1, 0.6]))
+    pad[:, 0] = False
+    score[pad] = -np.inf
+    rel = (rng.uniform(size=(B, D)) < float(rng.choice([0.0, 0.05, 0.5]))).astype(np.int64)
+    if B > 1:
+        rel[B // 2] = 0
+    sparse = dense = None
+    if rng.random() < 0.7:
+        sparse = rng.normal(size=(B, D)).astype(np.float32)
+        sparse[rng.uniform(size=(B, D)) < 0.2] = np.nan
+    if rng.random() < 0.5:
+        dense = rng.normal(size=(B, D)).astype(np.float32)
+    up = float(rng.choice([1.0, 2.5]))
+    qt = torch.tensor(q, device="cuda", requires_grad=True)
+    st = torch.tensor(s, device="cuda", requires_grad=True)
+    batch = {"section__score": torch.tensor(score, device="cuda"), "section__relevance": torch.tensor(rel, device="cuda"),
+             "section__sparse": None if sparse is None else torch.tensor(sparse, device="cuda"),
+             "section__dense": None if dense is None else torch.tensor(dense, device="cuda")}
+    out = RetrievalGradients()(batch=batch, query_encoding=qt, section_encoding=st)
+    (out.loss * up).backward()
+    ref = retrieval_gradients(q, s, score, rel, sparse, dense)
+    tol = dict(rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(out.loss.item(), ref["loss"], **tol)
+    np.testing.assert_allclose(out.retriever_scores.cpu().numpy(), ref["retriever_scores"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(qt.grad.cpu().numpy(), up * ref["dq"], **tol)
+    np.testing.assert_allclose(st.grad.cpu().numpy(), up * ref["ds"], **tol)
+    for key in ("kl_score", "kl_sparse", "kl_dense"):
+        if key in ref and ref[key] is not None and key in out.diagnostics:
+            np.testing.assert_allclose(out.diagnostics[key].item(), ref[key], **tol)
+    return dict(kind="gradients", B=B, D=D, H=H, three_d=three_d)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=600.0)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    t0, fails, counts = time.time(), 0, {}
+    for t in range(a.trials):
+        if time.time() - t0 > a.seconds:
+            break
+        fn = [fuzz_merge, fuzz_sampling, fuzz_gradients][t % 3]
+        state = rng.bit_generator.state
+        try:
+            info = fn(rng)
+            counts[info["kind"]] = counts.get(info["kind"], 0) + 1
+        except Exception as e:  # noqa: BLE001
+            fails += 1
+            print(f"FAIL trial {t} ({fn.__name__}) {LAST}: {type(e).__name__}: {str(e)[:1500]}", flush=True)
+            if not isinstance(e, AssertionError):
+                traceback.print_exc()
+    print(f"fuzz_collate: {sum(counts.values())} ok {counts}, {fails} failures, {time.time() - t0:.0f} s, seed {a.seed}")
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
