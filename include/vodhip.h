@@ -129,6 +129,8 @@ int vodhip_index_get_stat(const vodhip_index_t* index, const char* key, int64_t*
  * Replaces: the row-offset + stack of ShardedSearchClient (src/vod_search/sharded_search.py:92-106,
  *           198-203) and faiss IndexShards' host merge (src/vod_search/faiss_search/server.py:51-54).
  * scores/ids: DEVICE [n_shards, nq, k] (ids already global, pads -1).  Output [nq, k_out].
+ * One launch merges up to 8192 entries per query; more (e.g. 8 shards x top-2048) are merged in levels through a
+ * stream-ordered temporary (hipMallocAsync on `stream`); k <= 4096.
  * ------------------------------------------------------------------------------------------- */
 int vodhip_merge_topk(const float* scores, const int64_t* ids, int n_shards, int64_t nq, int k,
                       int k_out, float* out_scores, int64_t* out_ids, void* stream);

@@ -689,3 +689,26 @@ def test_repeated_searches_are_bit_identical(tile, nq):
         ts, ti = torch.topk(full, k, dim=1)
         assert torch.equal(torch.sort(ti, dim=1).values, torch.sort(i0[:16], dim=1).values) or float((ts - s0[:16]).abs().max()) < SCORE_TOL
         assert float((ts - s0[:16]).abs().max()) < SCORE_TOL
+
+
+def test_merge_of_more_than_8192_entries_runs_in_levels():
+    """8 shards x top-2048 (what an 8-GPU index returns for k = 2048) and 16 x 1024: more than one launch can hold in LDS, so
+    the C-ABI merges groups of shards first; the result must equal the one-shot oracle, ties and pads included."""
+    from oracle.flat_ip import merge_shard_topk
+    from vod_amd.index import merge_topk
+
+    rng = np.random.default_rng(88)
+    for S, nq, k, k_out in [(8, 40, 2048, 2048), (16, 33, 1024, 700), (5, 7, 4096, 4096), (9, 12, 1000, 2000)]:
+        scores = (np.round(rng.normal(size=(S, nq, k)) * 4) / 2).astype(np.float32)
+        ids = np.full((S, nq, k), -1, dtype=np.int64)
+        for s_ in range(S):
+            for r in range(nq):
+                nv = k if rng.random() < 0.6 else int(rng.integers(0, k + 1))
+                ids[s_, r, :nv] = s_ * 1_000_000 + rng.choice(200_000, size=nv, replace=False)
+                scores[s_, r, nv:] = -np.inf
+                o = np.lexsort((ids[s_, r, :nv], -scores[s_, r, :nv]))
+                scores[s_, r, :nv], ids[s_, r, :nv] = scores[s_, r, :nv][o], ids[s_, r, :nv][o]
+        gs, gi = merge_topk(torch.from_numpy(scores).cuda(), torch.from_numpy(ids).cuda(), k_out)
+        rs, ri = merge_shard_topk(list(scores), list(ids), k_out)
+        np.testing.assert_array_equal(gi.cpu().numpy(), ri)
+        np.testing.assert_array_equal(gs.cpu().numpy(), rs)

@@ -163,6 +163,36 @@ def fuzz_gradients(rng):
     return dict(kind="gradients", B=B, D=D, H=H, three_d=three_d)
 
 
+def fuzz_merge_topk(rng):
+    """H3: the per-shard lists of a row-sharded search (sorted, padded, global ids) or arbitrary unsorted lists."""
+    from oracle.flat_ip import merge_shard_topk
+    from vod_amd.index import merge_topk
+
+    S = int(rng.choice([1, 2, 3, 8, 16]))
+    nq = int(rng.choice([1, 5, 64, 300]))
+    k = int(rng.choice([1, 2, 10, 100, 128, 200, 512, 2048]))
+    if S * k > 16384:
+        S = max(1, 16384 // k)
+    k_out = int(rng.choice([k, k, max(1, k // 2), min(2048, 2 * k)]))
+    sorted_in = bool(rng.random() < 0.7)
+    LAST.clear(); LAST.update(kind="merge_topk", S=S, nq=nq, k=k, k_out=k_out, sorted=sorted_in)
+    scores = np.round(rng.normal(size=(S, nq, k)) * 4).astype(np.float32) / 2  # many ties
+    ids = np.full((S, nq, k), -1, dtype=np.int64)
+    for s_ in range(S):
+        for r in range(nq):
+            nv = k if rng.random() < 0.7 else int(rng.integers(0, k + 1))
+            ids[s_, r, :nv] = s_ * 1_000_000 + rng.choice(100_000, size=nv, replace=False)
+            scores[s_, r, nv:] = -np.inf
+            if sorted_in and nv:  # (score desc, id asc) like a search result
+                o = np.lexsort((ids[s_, r, :nv], -scores[s_, r, :nv]))
+                scores[s_, r, :nv], ids[s_, r, :nv] = scores[s_, r, :nv][o], ids[s_, r, :nv][o]
+    gs, gi = merge_topk(torch.from_numpy(scores).cuda(), torch.from_numpy(ids).cuda(), k_out)
+    rs, ri = merge_shard_topk(list(scores), list(ids), k_out)
+    _eq(gi.cpu().numpy(), ri, "merge_topk ids")
+    _eq(gs.cpu().numpy(), rs, "merge_topk scores")
+    return dict(LAST)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=300)
@@ -174,7 +204,7 @@ def main():
     for t in range(a.trials):
         if time.time() - t0 > a.seconds:
             break
-        fn = [fuzz_merge, fuzz_sampling, fuzz_gradients][t % 3]
+        fn = [fuzz_merge, fuzz_sampling, fuzz_gradients, fuzz_merge_topk][t % 4]
         state = rng.bit_generator.state
         try:
             info = fn(rng)

@@ -673,24 +673,55 @@ int vodhip_index_get_stat(const vodhip_index_t* ix, const char* key, int64_t* ou
     return 0;
 }
 
+// One merge launch holds n_shards * k entries of a query in LDS (<= 8192).  More than that (e.g. 8 shards x top-2048) is
+// merged in levels: groups of floor(8192 / k) shards -> their top-min(k_out, group size * k) in a stream-ordered temporary
+// (top-k of a union = top-k of the per-part top-k's), then the groups.
+static int merge_topk_levels(const float* scores, int64_t stride_s, const int64_t* ids, int64_t stride_i, int n_shards, int64_t nq,
+                             int k, int k_out, float* out_scores, int64_t* out_ids, hipStream_t stream) {
+    if ((int64_t)n_shards * k <= 8192) {
+        HIP_OK(launch_merge_topk(scores, ids, stride_s, stride_i, n_shards, nq, k, k_out, out_scores, out_ids, stream));
+        return 0;
+    }
+    const int per_group = 8192 / k;
+    if (per_group < 2) return fail("k = %d: lists longer than 4096 entries cannot be merged", k);
+    const int n_groups = (n_shards + per_group - 1) / per_group;
+    const int k_mid = (int)std::min<int64_t>(k_out, (int64_t)per_group * k);
+    float* mid_s = nullptr;
+    int64_t* mid_i = nullptr;
+    const size_t n_mid = (size_t)n_groups * (size_t)nq * (size_t)k_mid;
+    HIP_OK(hipMallocAsync((void**)&mid_s, n_mid * sizeof(float), stream));
+    if (hipError_t e = hipMallocAsync((void**)&mid_i, n_mid * sizeof(int64_t), stream); e != hipSuccess) {
+        (void)hipFreeAsync(mid_s, stream);
+        return fail("HIP error: %s", hipGetErrorString(e));
+    }
+    int rc = 0;
+    for (int g = 0; g < n_groups && rc == 0; ++g) {
+        const int s0 = g * per_group, ns = std::min(per_group, n_shards - s0);
+        if (hipError_t e = launch_merge_topk(scores + (size_t)s0 * stride_s, ids + (size_t)s0 * stride_i, stride_s, stride_i, ns, nq, k, k_mid,
+                                             mid_s + (size_t)g * nq * k_mid, mid_i + (size_t)g * nq * k_mid, stream);
+            e != hipSuccess)
+            rc = fail("HIP error: %s", hipGetErrorString(e));
+    }
+    if (rc == 0) rc = merge_topk_levels(mid_s, nq * k_mid, mid_i, nq * k_mid, n_groups, nq, k_mid, k_out, out_scores, out_ids, stream);
+    (void)hipFreeAsync(mid_s, stream);
+    (void)hipFreeAsync(mid_i, stream);
+    return rc;
+}
+
 int vodhip_merge_topk(const float* scores, const int64_t* ids, int n_shards, int64_t nq, int k, int k_out,
                       float* out_scores, int64_t* out_ids, void* stream) {
     if (n_shards < 1 || k < 1 || k_out < 1 || nq < 0) return fail("invalid sizes");
-    if ((int64_t)n_shards * k > 8192) return fail("n_shards * k = %lld exceeds 8192", (long long)n_shards * k);
     if (nq > 0 && (!scores || !ids || !out_scores || !out_ids)) return fail("NULL argument");
-    HIP_OK(launch_merge_topk(scores, ids, nq * k, nq * k, n_shards, nq, k, k_out, out_scores, out_ids, (hipStream_t)stream));
-    return 0;
+    return merge_topk_levels(scores, nq * k, ids, nq * k, n_shards, nq, k, k_out, out_scores, out_ids, (hipStream_t)stream);
 }
 
 int vodhip_merge_topk_strided(const float* scores, int64_t shard_stride_scores, const int64_t* ids, int64_t shard_stride_ids,
                               int n_shards, int64_t nq, int k, int k_out, float* out_scores, int64_t* out_ids, void* stream) {
     if (n_shards < 1 || k < 1 || k_out < 1 || nq < 0) return fail("invalid sizes");
-    if ((int64_t)n_shards * k > 8192) return fail("n_shards * k = %lld exceeds 8192", (long long)n_shards * k);
     if (nq > 0 && (!scores || !ids || !out_scores || !out_ids)) return fail("NULL argument");
     if (shard_stride_scores < nq * k || shard_stride_ids < nq * k) return fail("shard strides smaller than nq * k");
-    HIP_OK(launch_merge_topk(scores, ids, shard_stride_scores, shard_stride_ids, n_shards, nq, k, k_out, out_scores, out_ids,
-                             (hipStream_t)stream));
-    return 0;
+    return merge_topk_levels(scores, shard_stride_scores, ids, shard_stride_ids, n_shards, nq, k, k_out, out_scores, out_ids,
+                             (hipStream_t)stream);
 }
 
 int vodhip_merge_hybrid(const int64_t* lookup_idx, const int64_t* lookup_lbl, int k_lookup, int n_engines,
