@@ -193,6 +193,40 @@ def fuzz_merge_topk(rng):
     return dict(LAST)
 
 
+def fuzz_flatten(rng):
+    """H7b: in-batch flattening (unique ids of the batch, every attribute gathered by id, first match wins)."""
+    from oracle import sampling as osmp
+    from vod_amd import types as vt
+    from vod_amd.core.in_batch_negatives import flatten_samples
+    from vod_amd.core.sample import PrioritySampledSections
+
+    b = int(rng.choice([1, 2, 7, 64, 130]))
+    n = int(rng.choice([1, 3, 32, 130, 512]))
+    pool = int(rng.choice([1, 5, 200, 3000, 10**9]))
+    LAST.clear(); LAST.update(kind="flatten", b=b, n=n, pool=pool)
+    idx = rng.integers(-1, pool, size=(b, n)).astype(np.int64)
+    scr = rng.standard_normal((b, n)).astype(np.float32)
+    scr[idx < 0] = -np.inf
+    lbl = rng.random((b, n)) < float(rng.choice([0.0, 0.2, 1.0]))
+    logw = rng.standard_normal((b, n)).astype(np.float32)
+    raw = {"dense": rng.standard_normal((b, n)).astype(np.float32),
+           "sparse": np.where(rng.random((b, n)) < 0.3, np.nan, 1.0).astype(np.float32)}
+    if rng.random() < 0.3:
+        raw.pop("sparse")
+    ps = PrioritySampledSections(batch=vt.RetrievalBatch(indices=idx, scores=scr, labels=lbl), log_weights=logw,
+                                 max_sampling_id=np.zeros(b), lse_pos=np.zeros(b), lse_neg=np.zeros(b), raw_scores=raw)
+    for padding in (True, False):
+        out = flatten_samples(ps, padding=padding)
+        ref = osmp.flatten_samples(idx, scr, lbl, logw, raw, padding=padding)
+        _eq(out.batch.indices, ref["indices"], "flatten ids")
+        _eq(out.batch.scores, ref["scores"], "flatten scores")
+        _eq(out.batch.labels, ref["labels"], "flatten labels")
+        _eq(out.log_weights, ref["log_weights"], "flatten log weights")
+        for key in raw:
+            _eq(out.raw_scores[key], ref["raw"][key], f"flatten raw {key}")
+    return dict(LAST)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=300)
@@ -204,7 +238,7 @@ def main():
     for t in range(a.trials):
         if time.time() - t0 > a.seconds:
             break
-        fn = [fuzz_merge, fuzz_sampling, fuzz_gradients, fuzz_merge_topk][t % 4]
+        fn = [fuzz_merge, fuzz_sampling, fuzz_gradients, fuzz_merge_topk, fuzz_flatten][t % 5]
         state = rng.bit_generator.state
         try:
             info = fn(rng)
