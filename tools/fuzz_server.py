@@ -1,0 +1,93 @@
+"""Randomised campaign THROUGH the drop-in boundary: one spawned server (optionally with micro-batching, optionally the
+multi-worker group), several client threads firing random requests - `/search` (JSON lists), `/fast-search` (the reference's
+base64-npy codec), `/raw-search`, with and without subset ids, random batch sizes and k - every answer compared bit for bit
+with the fp64 oracle.      python3 tools/fuzz_server.py [--requests 400] [--threads 8] [--wait-ms 5] [--group]
+"""
+import argparse
+import concurrent.futures
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from oracle.flat_ip import topk_desc_tiebreak  # noqa: E402
+from vod_amd import store  # noqa: E402
+from vod_amd.search.client import HipMipsClient, HipMipsMaster  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--requests", type=int, default=400)
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--wait-ms", type=float, default=5.0)
+    ap.add_argument("--group", action="store_true", help="serve through the worker group (devices=[0, 0], gloo)")
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    n, d = 60_000, 96
+    x = rng.integers(-6, 7, size=(n, d)).astype(np.float32)
+    names = np.array([f"doc{v}" for v in rng.integers(0, 7, size=n)])
+    tmp = tempfile.mkdtemp()
+    store.save_vectors(f"{tmp}/v.npy", x, dtype=np.float16)
+    np.save(f"{tmp}/subsets.npy", names)
+    x64 = x.astype(np.float64)
+
+    class Master(HipMipsMaster):
+        def _make_cmd(self):
+            return super()._make_cmd() + ["--subset-ids-path", f"{tmp}/subsets.npy", "--micro-batch-wait-ms", str(a.wait_ms)]
+
+    kw = dict(devices=[0, 0], group_backend="gloo") if a.group else {}
+    jobs = []
+    for j in range(a.requests):
+        nq = int(rng.choice([1, 1, 2, 5, 17, 64, 130, 300]))
+        k = int(rng.choice([1, 3, 10, 100, 257]))
+        route = str(rng.choice(["json", "fast", "raw"]))
+        subset = None
+        if route == "fast" and rng.random() < 0.4:
+            subset = [[f"doc{int(v)}" for v in rng.choice(8, size=int(rng.integers(0, 3)), replace=False)] for _ in range(nq)]
+        q = rng.integers(-6, 7, size=(nq, d)).astype(np.float32)
+        jobs.append((j, route, q, k, subset))
+
+    def expected(q, k, subset):
+        full = q.astype(np.float64) @ x64.T
+        if subset is not None:
+            for r, allowed in enumerate(subset):
+                if allowed:
+                    full[r, ~np.isin(names, allowed)] = np.nan
+        return topk_desc_tiebreak(full, k)
+
+    t0 = time.time()
+    with Master(f"{tmp}/v.npy", port=-1, logging_level="warning", **kw) as m:
+        clients = {
+            "fast": HipMipsClient(host=m.host, port=m.port, forward_subset_ids=True),
+            "raw": HipMipsClient(host=m.host, port=m.port, binary=True),
+            "json": HipMipsClient(host=m.host, port=m.port),
+        }
+
+        def run(job):
+            j, route, q, k, subset = job
+            try:
+                if route == "json":
+                    res = clients["json"].search_py(q, top_k=k)
+                else:
+                    res = clients[route].search(vector=q, subset_ids=subset, top_k=k)
+                rs, ri = expected(q, k, subset)
+                if not (np.array_equal(np.asarray(res.indices), ri) and np.array_equal(np.asarray(res.scores, dtype=np.float32), rs)):
+                    return f"request {j} ({route}, nq={len(q)}, k={k}, subset={'yes' if subset else 'no'}): result differs from the oracle"
+            except Exception as e:  # noqa: BLE001
+                return f"request {j} ({route}, nq={len(q)}, k={k}): {type(e).__name__}: {str(e)[:300]}"
+            return None
+
+        with concurrent.futures.ThreadPoolExecutor(a.threads) as ex:
+            errs = [e for e in ex.map(run, jobs) if e]
+    for e in errs[:20]:
+        print("FAIL", e)
+    print(f"fuzz_server: {len(jobs)} requests on {a.threads} threads ({'worker group x2' if a.group else 'single process'}, "
+          f"micro-batch wait {a.wait_ms} ms), {len(errs)} failures, {time.time() - t0:.0f} s")
+    sys.exit(1 if errs else 0)
+
+
+if __name__ == "__main__":
+    main()
