@@ -1,0 +1,49 @@
+"""A short, seeded slice of the randomised campaigns (tools/fuzz_search.py, tools/fuzz_collate.py) on every GPU test run: random
+store sizes / dims / batch sizes / k / dtypes / kernel variants / planner knobs / row orders / subset filters for the search,
+random shapes and pad / NaN / duplicate patterns for the collate-side kernels - all against the CPU oracle."""
+import importlib.util
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, ROOT / "tools" / f"{name}.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_search_campaign_slice(seed):
+    fz = _load("fuzz_search")
+    rng = np.random.default_rng(seed)
+    for t in range(60):
+        c = fz.draw(rng)
+        try:
+            fz.run_trial(c)
+        except AssertionError as e:
+            raise AssertionError(f"trial {t}: {c}: {e}") from e
+    # and one configuration that is known to overflow its (tiny) candidate lists: the recovery path must be taken and stay exact
+    c = fz.draw(rng)
+    c.update(n=70000, d=64, nq=300, k=100, dtype="f16", tile=0, data="duplicates", cand_cap=256, dense_rows=0, sample_div=0, growth=0,
+             small_chunk_tiles=-1, subset=False, id_base=0, build="once")
+    assert fz.run_trial(c)["last_safe_reruns"] >= 1
+
+
+@pytest.mark.parametrize("seed", [21])
+def test_collate_campaign_slice(seed):
+    fz = _load("fuzz_collate")
+    rng = np.random.default_rng(seed)
+    fns = [fz.fuzz_merge, fz.fuzz_sampling, fz.fuzz_gradients, fz.fuzz_merge_topk, fz.fuzz_flatten]
+    for t in range(150):
+        fn = fns[t % len(fns)]
+        try:
+            fn(rng)
+        except AssertionError as e:
+            raise AssertionError(f"trial {t} ({fn.__name__}) {fz.LAST}: {e}") from e
