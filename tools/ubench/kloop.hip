@@ -80,6 +80,19 @@ __global__ __launch_bounds__(512, 2) void kloop(const char* __restrict__ X, cons
         for (int i = 0; i < 8; ++i) f.a[i] = *(const u32x4*)(base + a_off + i * 16 * ROW_BYTES + so);
     };
     auto mma = [&](const Frags& f, int i0, int i1) {
+#ifdef KLOOP_JMAJOR  // consecutive MFMAs share the B (query) fragment instead of the A (corpus) fragment
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i >= i0 && i < i1) {
+                    if constexpr (MFMA)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f.a[i]), __builtin_bit_cast(f16x8, f.b[j]), acc[i][j], 0, 0, 0);
+                    else
+                        asm volatile("" ::"v"(f.a[i]), "v"(f.b[j]));
+                }
+        __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -90,6 +103,7 @@ __global__ __launch_bounds__(512, 2) void kloop(const char* __restrict__ X, cons
                     else
                         asm volatile("" ::"v"(f.a[i]), "v"(f.b[j]));
                 }
+#endif
     };
     int kbyte = 0, t_in_tile = 0;
     auto dma = [&](int slot, int piece) {  // piece 0..7 of the slice that lands in `slot`: 4 corpus + 4 query
