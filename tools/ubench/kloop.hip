@@ -379,16 +379,222 @@ __global__ __launch_bounds__(512, 2) void kdeep(const char* __restrict__ X, cons
     out[(size_t)bid * 512 + tid] = s;
 }
 
+
+// ---- mode bit 2048: a 384 (corpus) x 256 (queries) workgroup tile, 8 waves = 4 x 2 of 96 x 128 (192 accumulator registers):
+// 22 % fewer LDS read bytes and 17 % fewer LDS-DMA bytes per flop than 128 x 64 wave tiles.  Two 80 KB slots, the production
+// order inside a k-step (reads B + half of A, pieces, rest of A, MFMAs, pieces, MFMAs), hand-issued SGPR-base LDS-DMA.
+template <bool NT>
+__device__ __forceinline__ void glds16_saddr(const void* sbase, unsigned voff, unsigned lds_addr) {
+    if constexpr (NT)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+constexpr int W_A_BYTES = 384 * 128, W_STAGE = W_A_BYTES + 256 * 128;
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void kwide(const char* __restrict__ X, const char* __restrict__ Q, float* __restrict__ out,
+                                                int ksteps, int n_xtiles, unsigned long long* __restrict__ clk) {
+    constexpr bool BAR = (MODE & 32) != 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3, qt = jj & 3;
+    const int xt0 = (jj >> 2) * 8 + xcd, xt_step = (int)gridDim.x / 4;
+    for (int e = tid; e < 2 * W_STAGE / 4; e += 512) {
+        unsigned h = (unsigned)e * 2654435761u;
+        ((unsigned*)smem)[e] = 0x30003000u | (h & 0x8fff8fffu);
+    }
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4, swz = (fr >> 1) & 7;
+    const int a_off = (wm * 96 + fr) * 128, b_off = W_A_BYTES + (wn * 128 + fr) * 128;
+    // pieces: corpus 48 per slice (6 per wave: rows (wave*6 + t)*8 ..), queries 32 (4 per wave)
+    const char* c_base = X + ((size_t)xt0 * 384 + (size_t)wave * 48) * DIM_BYTES;
+    const char* q_base = Q + ((size_t)qt * 256 + (size_t)wave * 32) * DIM_BYTES;
+    unsigned a_voff[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) a_voff[par] = (unsigned)(lane >> 3) * DIM_BYTES + (unsigned)(((lane & 7) ^ ((4 * par + (lane >> 4)) & 7)) << 4);
+    const size_t tile_step = (size_t)xt_step * 384 * DIM_BYTES;
+    f32x4 acc[6][8];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int kbyte = 0, t_in_tile = 0;
+    auto dma = [&](int slot, int piece) {  // 0..5 corpus, 6..9 queries
+        const unsigned sa = (unsigned)(slot * W_STAGE);
+        if (piece < 6) {
+            // (wave*6 + piece)*8 rows: ((r >> 1) & 7) = ((wave*6 + piece)*4 + (lane >> 4)) & 7 -> parity of (wave*6 + piece) selects the offset
+            glds16_saddr<false>(c_base + kbyte + piece * 8 * DIM_BYTES, a_voff[(wave * 6 + piece) & 1], sa + (wave * 6 + piece) * 8 * 128);
+        } else {
+            const int t = piece - 6;
+            glds16_saddr<false>(q_base + kbyte + t * 8 * DIM_BYTES, a_voff[(wave * 4 + t) & 1], sa + W_A_BYTES + (wave * 4 + t) * 8 * 128);
+        }
+    };
+    u32x4 fa[6], fb[8];
+    auto mma = [&](int i0, int i1) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (i >= i0 && i < i1)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[i]), __builtin_bit_cast(f16x8, fb[j]), acc[i][j], 0, 0, 0);
+    };
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    int g = 0;
+    for (int it = 0; it < ksteps; it += 2, ++g) {
+        const int slot = g & 1, nslot = slot ^ 1;
+        if constexpr (BAR) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const char* base = smem + slot * W_STAGE;
+            const int so = ((4 * ks + fq) ^ swz) << 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fb[j] = *(const u32x4*)(base + b_off + j * 16 * 128 + so);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fa[i] = *(const u32x4*)(base + a_off + i * 16 * 128 + so);
+            dma(nslot, 5 * ks + 0);
+            dma(nslot, 5 * ks + 1);
+#pragma unroll
+            for (int i = 3; i < 6; ++i) fa[i] = *(const u32x4*)(base + a_off + i * 16 * 128 + so);
+            mma(0, 3);
+            dma(nslot, 5 * ks + 2);
+            dma(nslot, 5 * ks + 3);
+            dma(nslot, 5 * ks + 4);
+            mma(3, 6);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        kbyte += 128;
+        if (++t_in_tile == NK) {
+            t_in_tile = 0;
+            kbyte = 0;
+            c_base += tile_step;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) { clk[2 * bid] = t1 - t0; clk[2 * bid + 1] = r1 - r0; }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[(size_t)bid * 512 + tid] = s;
+}
+
+
+// ---- mode bit 4096: the same 384 x 256 tile on a ring of THREE 32-deep slots (corpus 384 x 64 B + queries 256 x 64 B = 40 KB
+// each: 120 KB, which leaves room for the survivor lists), pieces of 16 rows x 64 B requested two k-steps ahead, one
+// vmcnt(5) + s_barrier per k-step.
+constexpr int W3_A = 384 * 64, W3_SLOT = W3_A + 256 * 64;
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void kwide3(const char* __restrict__ X, const char* __restrict__ Q, float* __restrict__ out,
+                                                 int ksteps, int n_xtiles, unsigned long long* __restrict__ clk) {
+    constexpr bool BAR = (MODE & 32) != 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3, qt = jj & 3;
+    const int xt0 = (jj >> 2) * 8 + xcd, xt_step = (int)gridDim.x / 4;
+    for (int e = tid; e < 3 * W3_SLOT / 4; e += 512) {
+        unsigned h = (unsigned)e * 2654435761u;
+        ((unsigned*)smem)[e] = 0x30003000u | (h & 0x8fff8fffu);
+    }
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int gq = (0x78 >> (2 * ((fr >> 2) & 3))) & 3;
+    const int a_off = (wm * 96 + fr) * 64 + ((fq ^ gq) << 4), b_off = W3_A + (wn * 128 + fr) * 64 + ((fq ^ gq) << 4);
+    const char* c_base = X + ((size_t)xt0 * 384 + (size_t)wave * 48) * DIM_BYTES;
+    const char* q_base = Q + ((size_t)qt * 256 + (size_t)wave * 32) * DIM_BYTES;
+    const unsigned voff = (unsigned)(lane >> 2) * DIM_BYTES + (unsigned)(((lane & 3) ^ ((0x78 >> (2 * ((lane >> 4) & 3))) & 3)) << 4);
+    const size_t tile_step = (size_t)xt_step * 384 * DIM_BYTES;
+    f32x4 acc[6][8];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int kbyte = 0, t_in_tile = 0, f_slot = 0;  // fetch cursor
+    auto dma = [&](int piece) {  // 0..2 corpus, 3..4 queries, of the k-step under the fetch cursor
+        const unsigned sa = (unsigned)(f_slot * W3_SLOT);
+        if (piece < 3) glds16_saddr<false>(c_base + kbyte + piece * 16 * DIM_BYTES, voff, sa + (wave * 3 + piece) * 16 * 64);
+        else glds16_saddr<false>(q_base + kbyte + (piece - 3) * 16 * DIM_BYTES, voff, sa + W3_A + (wave * 2 + piece - 3) * 16 * 64);
+    };
+    auto next_fetch = [&]() {
+        kbyte += 64;
+        f_slot = f_slot == 2 ? 0 : f_slot + 1;
+        if (++t_in_tile == 2 * NK) {
+            t_in_tile = 0;
+            kbyte = 0;
+            c_base += tile_step;
+        }
+    };
+    u32x4 fa[6], fb[8];
+    auto mma = [&](int i0, int i1) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (i >= i0 && i < i1)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[i]), __builtin_bit_cast(f16x8, fb[j]), acc[i][j], 0, 0, 0);
+    };
+    for (int p = 0; p < 5; ++p) dma(p);
+    next_fetch();
+    for (int p = 0; p < 5; ++p) dma(p);
+    next_fetch();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    int r_slot = 0;
+    for (int h = 0; h < ksteps; ++h) {
+        if constexpr (BAR) {
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        const char* base = smem + r_slot * W3_SLOT;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fb[j] = *(const u32x4*)(base + b_off + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fa[i] = *(const u32x4*)(base + a_off + i * 16 * 64);
+        dma(0);
+        dma(1);
+#pragma unroll
+        for (int i = 3; i < 6; ++i) fa[i] = *(const u32x4*)(base + a_off + i * 16 * 64);
+        mma(0, 3);
+        dma(2);
+        dma(3);
+        dma(4);
+        mma(3, 6);
+        __builtin_amdgcn_sched_barrier(0);
+        next_fetch();
+        r_slot = r_slot == 2 ? 0 : r_slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) { clk[2 * bid] = t1 - t0; clk[2 * bid + 1] = r1 - r0; }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[(size_t)bid * 512 + tid] = s;
+}
+
 static unsigned long long* g_clk = nullptr;
 template <int MODE>
 float run(const char* X, const char* Q, float* out, int ksteps, int n_xtiles, int reps) {
-    constexpr bool DEEP = (MODE & 128) != 0;
-    const int lds = DEEP ? 3 * C_SLOT + 3 * Q_SLOT : 2 * STAGE_BYTES;
+    constexpr bool DEEP = (MODE & 128) != 0, WIDE = (MODE & 2048) != 0, WIDE3 = (MODE & 4096) != 0;
+    const int lds = WIDE3 ? 3 * W3_SLOT : WIDE ? 2 * W_STAGE : DEEP ? 3 * C_SLOT + 3 * Q_SLOT : 2 * STAGE_BYTES;
     auto launch = [&]() {
-        if constexpr (DEEP) kdeep<MODE><<<256, 512, lds>>>(X, Q, out, ksteps, n_xtiles, g_clk);
+        if constexpr (WIDE3) kwide3<MODE><<<256, 512, lds>>>(X, Q, out, ksteps, n_xtiles, g_clk);
+        else if constexpr (WIDE) kwide<MODE><<<256, 512, lds>>>(X, Q, out, ksteps, n_xtiles, g_clk);
+        else if constexpr (DEEP) kdeep<MODE><<<256, 512, lds>>>(X, Q, out, ksteps, n_xtiles, g_clk);
         else kloop<MODE><<<256, 512, lds>>>(X, Q, out, ksteps, n_xtiles, g_clk);
     };
-    if constexpr (DEEP) hipFuncSetAttribute((const void*)kdeep<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if constexpr (WIDE3) hipFuncSetAttribute((const void*)kwide3<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else if constexpr (WIDE) hipFuncSetAttribute((const void*)kwide<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    else if constexpr (DEEP) hipFuncSetAttribute((const void*)kdeep<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     else hipFuncSetAttribute((const void*)kloop<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -454,7 +660,7 @@ int main(int argc, char** argv) {
             float ms = -1;
             switch (m) {
                 CASE(1) CASE(2) CASE(3) CASE(7) CASE(6) CASE(8) CASE(24) CASE(9) CASE(25) CASE(11) CASE(15) CASE(27) CASE(31)
-                CASE(1083) CASE(699) CASE(703)
+                CASE(1083) CASE(699) CASE(703) CASE(2107) CASE(2075) CASE(4155) CASE(4123)
                 CASE(135) CASE(143) CASE(159) CASE(175) CASE(191) CASE(190) CASE(134) CASE(187) CASE(315) CASE(319) CASE(447) CASE(443) CASE(287) CASE(415)
                 CASE(43) CASE(47) CASE(59) CASE(63) CASE(35) CASE(39) CASE(67) CASE(71) CASE(127) CASE(123) CASE(95) CASE(91) CASE(79) CASE(75)
                 default: printf("mode %d not instantiated\n", m); continue;
@@ -468,10 +674,13 @@ int main(int argc, char** argv) {
                 std::sort(v.begin(), v.end());
                 if (!v.empty()) ghz = v[v.size() / 2];
             }
-            const double tf = 256.0 * 8 * ksteps * 32 * 16384.0 / (ms * 1e-3) / 1e12;
+            const bool wide = (m & (2048 | 4096)) != 0;
+            const double tf = 256.0 * 8 * ksteps * (wide ? 48 : 32) * 16384.0 / (ms * 1e-3) / 1e12;
+            const double c3k = wide ? 26042.0 * 4 / 256 * 24 : c3_ksteps;
             printf("mode %3d  %s%s%s%s%s%s%s  %.3f ms  = %.2f ms per C3 batch  (%.0f TFLOP/s-equivalent)\n", m, (m & 1) ? "mfma " : "", (m & 2) ? "read " : "",
                    (m & 4) ? "prefetch " : "", (m & 8) ? "dma " : "", (m & 16) ? "stream " : "", (m & 32) ? "barrier " : "", (m & 64) ? "skew " : "",
-                   ms, ms * c3_ksteps / ksteps, tf);
+                   ms, ms * c3k / ksteps, tf);
+            if (wide) printf("          384 x 256 workgroup tile, 96 x 128 wave tiles%s\n", (m & 4096) ? ", ring of three 32-deep slots (120 KB)" : "");
             if (m & (512 | 1024)) printf("          %s%s\n", (m & 512) ? "barrier every other k-step (timing only); " : "", (m & 1024) ? "production order inside a k-step" : "");
             printf("          %s%sin-kernel clock %.3f GHz (median over workgroups)\n", (m & 128) ? "deep ring; " : "", (m & 256) ? "one query tile (per nq=256 batch: ms / 4); " : "", ghz);
         }

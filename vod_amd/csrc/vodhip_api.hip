@@ -349,7 +349,7 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
     ix->dim = dim;
     ix->dim_pad = round_up(dim, 64);
     ix->capacity = capacity_rows;
-    ix->capacity_pad = round_up(capacity_rows, ROW_ALIGN) + ROW_ALIGN;
+    ix->capacity_pad = round_up(capacity_rows, ROW_ALIGN) + 2 * ROW_ALIGN;  // the last tile (up to 384 rows from a 256-aligned start) never reads past the allocation
     ix->dtype = store_dtype;
     const size_t bytes = (size_t)ix->capacity_pad * ix->dim_pad * 2;
     hipError_t e = hipMalloc((void**)&ix->data, bytes);
@@ -633,11 +633,11 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
         ix->profile = value;
     } else if (!strcmp(key, "tile")) {
 #ifdef VODHIP_EXPERIMENTS
-        const bool ring_ok = true;  // tiles 10 / 11: the deep-ring FILTER kernel of experiment builds
+        const bool ring_ok = true;  // tiles 10 / 11 / 12: the FILTER kernels of experiment builds
 #else
         const bool ring_ok = false;
 #endif
-        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 42 && value != 46 && !(ring_ok && (value == 10 || value == 11)))
+        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 42 && value != 46 && !(ring_ok && value >= 10 && value <= 12))
             return fail("tile must be 0 (auto) or a filter-kernel variant id: 1, 8, 9, 42, 46 (DESIGN.md 4.1)");
         ix->tile = value;
     } else {

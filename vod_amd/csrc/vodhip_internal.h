@@ -71,9 +71,12 @@ hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int64_t st
 // the FILTER stage on the deeper LDS ring (kernels_mips_ring.hip; tiles 10 = plain, 11 = fragments read one k-step ahead)
 hipError_t launch_filter_ring(int store_dtype, bool pipe, const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin,
                               int64_t row_end, int64_t nq, int64_t nq_pad, const SearchWorkspace& ws, hipStream_t stream);
+// the FILTER stage on the 384 x 256 workgroup tile (kernels_mips_wide.hip; tile 12)
+hipError_t launch_filter_wide(int store_dtype, const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin, int64_t row_end,
+                              int64_t nq, int64_t nq_pad, const SearchWorkspace& ws, hipStream_t stream);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel): it is a driver call on the launch path
 hipError_t allow_dynamic_lds(const void* kernel, int bytes);
-inline bool filter_tile_is_persistent(int tile) { return tile >= 8 && tile <= 11; }  // one 256 x 256 workgroup per CU walking tiles
+inline bool filter_tile_is_persistent(int tile) { return tile >= 8 && tile <= 12; }  // one 256 x 256 workgroup per CU walking tiles
 int filter_tile_rows(int tile);  // BM of the tile config
 int filter_tile_cols(int tile);  // BN of the tile config
 int filter_group_rows(int tile); // rows per GMAX group (one lane's rows of one column block)
