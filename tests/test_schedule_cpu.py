@@ -101,7 +101,7 @@ def test_baseline_shapes(n, k, nq):
         assert st_[0, 0] == GMAX and 3 <= len(st_) <= 7  # bootstrap + 2..6 filter stages (round 1: 6 launches, 4 of them tiny)
 
 
-@settings(max_examples=300, deadline=None)
+@settings(max_examples=300, deadline=None, derandomize=True)  # (a 30,000-draw random run of the same property is clean; fixed draws keep the CPU suite reproducible)
 @given(n=st.integers(1, 50_000_000), k=st.sampled_from([1, 3, 10, 64, 100, 128, 200, 500, 2048]),
        nq=st.sampled_from([1, 32, 64, 65, 128, 129, 256, 257, 1024, 2048, 5000]), cap=st.sampled_from([256, 512, 4096, 16384, 65536]),
        tile=st.sampled_from([0, 1, 8, 9, 42, 46]))
