@@ -1,6 +1,6 @@
 """Randomised parity campaign for the collate-side kernels (hybrid merge, labeled priority sampling, in-batch flattening,
 retrieval loss forward + backward) against the CPU oracle.  Not part of the test suite: run it on a GPU box when those
-kernels change.      python3 tools/fuzz_collate.py [--trials 300] [--seed 1] [--seconds 600]
+kernels change.      python3 tests/fuzz/fuzz_collate.py [--trials 300] [--seed 1] [--seconds 600]
 """
 import argparse
 import sys
@@ -10,7 +10,7 @@ import traceback
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[2]))  # the repo root
 
 
 LAST = {}

@@ -4,7 +4,7 @@ force overflow recovery, small sample divisors / growth change the stage list) a
 an incremental build or a reset-and-refill, and compares ids AND scores bit for bit with the fp64 oracle (integer-valued
 rows: every partial sum is exact in fp32, ties everywhere).
 
-    python3 tools/fuzz_search.py [--trials 400] [--seed 1] [--seconds 600]
+    python3 tests/fuzz/fuzz_search.py [--trials 400] [--seed 1] [--seconds 600]
 """
 import argparse
 import sys
@@ -14,7 +14,7 @@ import traceback
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[2]))  # the repo root
 from oracle.flat_ip import topk_desc_tiebreak  # noqa: E402
 from vod_amd.index import HipFlatIndex  # noqa: E402
 

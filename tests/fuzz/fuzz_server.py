@@ -1,7 +1,7 @@
 """Randomised campaign THROUGH the drop-in boundary: one spawned server (optionally with micro-batching, optionally the
 multi-worker group), several client threads firing random requests - `/search` (JSON lists), `/fast-search` (the reference's
 base64-npy codec), `/raw-search`, with and without subset ids, random batch sizes and k - every answer compared bit for bit
-with the fp64 oracle.      python3 tools/fuzz_server.py [--requests 400] [--threads 8] [--wait-ms 5] [--group]
+with the fp64 oracle.      python3 tests/fuzz/fuzz_server.py [--requests 400] [--threads 8] [--wait-ms 5] [--group]
 """
 import argparse
 import concurrent.futures
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[2]))  # the repo root
 from oracle.flat_ip import topk_desc_tiebreak  # noqa: E402
 from vod_amd import store  # noqa: E402
 from vod_amd.search.client import HipMipsClient, HipMipsMaster  # noqa: E402

@@ -158,7 +158,7 @@ def gen_merge() -> None:
 
 
 def gen_merge_corners() -> None:
-    """Corner cases a randomised campaign (tools/fuzz_collate.py) found the oracle restating differently from the reference:
+    """Corner cases a randomised campaign (tests/fuzz/fuzz_collate.py) found the oracle restating differently from the reference:
     ids repeated INSIDE one engine's row (different labels / scores per occurrence) and NaN scores, with 0, 1 and 2 scored
     engines.  With the lookup alone `merge_search_results` returns it untouched (merge.py:18-22): no union, labels as given."""
     rng = np.random.default_rng(4242)

@@ -1,4 +1,4 @@
-"""A short, seeded slice of the randomised campaigns (tools/fuzz_search.py, tools/fuzz_collate.py) on every GPU test run: random
+"""A short, seeded slice of the randomised campaigns (tests/fuzz/fuzz_search.py, tests/fuzz/fuzz_collate.py) on every GPU test run: random
 store sizes / dims / batch sizes / k / dtypes / kernel variants / planner knobs / row orders / subset filters for the search,
 random shapes and pad / NaN / duplicate patterns for the collate-side kernels - all against the CPU oracle."""
 import importlib.util
@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _load(name):
-    spec = importlib.util.spec_from_file_location(name, ROOT / "tools" / f"{name}.py")
+    spec = importlib.util.spec_from_file_location(name, ROOT / "tests" / "fuzz" / f"{name}.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod

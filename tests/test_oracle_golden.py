@@ -73,7 +73,7 @@ def test_two_engine_merges_match_reference():
 @pytest.mark.parametrize("case", ["lookup_only", "one_engine", "two_engines"])
 def test_hybrid_merge_corner_cases_match_reference(case):
     """Ids repeated inside one engine's row (different labels / scores per occurrence), NaN scores, and the lookup alone -
-    which the reference returns untouched (merge.py:18-22).  Found by tools/fuzz_collate.py; fixture from the reference."""
+    which the reference returns untouched (merge.py:18-22).  Found by tests/fuzz/fuzz_collate.py; fixture from the reference."""
     g = _load("merge_corners")
     w = MANIFEST["merge_corners"]["params"]["cases"][case]
     engines = {n: (g[f"{n}_idx"], g[f"{n}_scr"]) for n in w}
