@@ -50,6 +50,9 @@ def test_product_has_no_cpu_fallback_and_never_imports_the_oracle():
     for path in (ROOT / "vod_amd").rglob("*.py"):
         text = path.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{path} imports the oracle"
+    # the measurement / profiling helpers are not test infrastructure either: only tests/, smoke() and bench.py's CPU baseline use it
+    for path in list((ROOT / "tools").rglob("*.py")) + list((ROOT / "tools").rglob("*.sh")):
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", path.read_text(), flags=re.M), f"{path} imports the oracle"
     import torch
 
     if not torch.cuda.is_available():
