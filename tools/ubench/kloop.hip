@@ -13,6 +13,8 @@
 //   512 (deep ring) the barrier only in front of every other k-step (TIMING ONLY: the ring is not safe like that)
 //   1024 (two-slot loop) the production kernel's order inside a k-step: reads B + A[0..3], 2 pieces, reads A[4..7], 16 MFMAs,
 //        2 pieces, 16 MFMAs
+//   8192 a pause at every tile end (24 k-steps) that differs between workgroups: ~2,000 + (hash % 2,048) cycles, what the epilogue
+//        and its survivors do to the four workgroups that share a corpus tile through L2
 //   256 ONE query tile: every workgroup streams its own corpus tiles (nothing shared through L2), corpus pieces with nt
 #include <hip/hip_runtime.h>
 
@@ -29,6 +31,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROW_BYTES = 128, A_BYTES = 256 * ROW_BYTES, STAGE_BYTES = 2 * A_BYTES;
 constexpr int DIM_BYTES = 1536, NK = 12;  // 768 fp16 per row, 12 slices of 64
+
+
+__device__ __forceinline__ void tile_end_pause(int bid, int tile_no) {
+    unsigned h = (unsigned)(bid * 2654435761u) ^ (unsigned)(tile_no * 40503u);
+    h ^= h >> 13;
+    const unsigned long long until = __builtin_amdgcn_s_memtime() + 2000ull + (h & 2047u);
+    while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(2);
+}
 
 struct Frags {
     u32x4 b[4], a[8];
@@ -203,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void kloop(const char* __restrict__ X, cons
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 next_slice();
+                if constexpr ((MODE & 8192) != 0) { if (t_in_tile == 0) tile_end_pause(bid, g); }
                 continue;
             }
 #pragma unroll
@@ -366,6 +377,7 @@ __global__ __launch_bounds__(512, 2) void kdeep(const char* __restrict__ X, cons
         rc = rc == 2 ? 0 : rc + 1;
         kstep(f1, f0, 0, true);
         rq = rq == 2 ? 0 : rq + 1;
+        if constexpr ((MODE & 8192) != 0) { if (((h >> 1) + 1) % NK == 0) tile_end_pause(bid, h); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -569,6 +581,7 @@ __global__ __launch_bounds__(512, 2) void kwide3(const char* __restrict__ X, con
         __builtin_amdgcn_sched_barrier(0);
         next_fetch();
         r_slot = r_slot == 2 ? 0 : r_slot + 1;
+        if constexpr ((MODE & 8192) != 0) { if ((h + 1) % (2 * NK) == 0) tile_end_pause(bid, h); }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -660,7 +673,7 @@ int main(int argc, char** argv) {
             float ms = -1;
             switch (m) {
                 CASE(1) CASE(2) CASE(3) CASE(7) CASE(6) CASE(8) CASE(24) CASE(9) CASE(25) CASE(11) CASE(15) CASE(27) CASE(31)
-                CASE(1083) CASE(699) CASE(703) CASE(2107) CASE(2075) CASE(4155) CASE(4123)
+                CASE(1083) CASE(699) CASE(703) CASE(2107) CASE(2075) CASE(4155) CASE(4123) CASE(9275) CASE(8383) CASE(12347)
                 CASE(135) CASE(143) CASE(159) CASE(175) CASE(191) CASE(190) CASE(134) CASE(187) CASE(315) CASE(319) CASE(447) CASE(443) CASE(287) CASE(415)
                 CASE(43) CASE(47) CASE(59) CASE(63) CASE(35) CASE(39) CASE(67) CASE(71) CASE(127) CASE(123) CASE(95) CASE(91) CASE(79) CASE(75)
                 default: printf("mode %d not instantiated\n", m); continue;
@@ -681,6 +694,7 @@ int main(int argc, char** argv) {
                    (m & 4) ? "prefetch " : "", (m & 8) ? "dma " : "", (m & 16) ? "stream " : "", (m & 32) ? "barrier " : "", (m & 64) ? "skew " : "",
                    ms, ms * c3k / ksteps, tf);
             if (wide) printf("          384 x 256 workgroup tile, 96 x 128 wave tiles%s\n", (m & 4096) ? ", ring of three 32-deep slots (120 KB)" : "");
+            if (m & 8192) printf("          tile-end pause (2,000 + hash %% 2,048 cycles, different per workgroup)\n");
             if (m & (512 | 1024)) printf("          %s%s\n", (m & 512) ? "barrier every other k-step (timing only); " : "", (m & 1024) ? "production order inside a k-step" : "");
             printf("          %s%sin-kernel clock %.3f GHz (median over workgroups)\n", (m & 128) ? "deep ring; " : "", (m & 256) ? "one query tile (per nq=256 batch: ms / 4); " : "", ghz);
         }
