@@ -12,7 +12,9 @@ ranks (strong scaling: the corpus is fixed, each rank holds N_total / N rows).  
 per-shard top-k, merge.  Inputs are synthetic N(0,1) embeddings generated on the device (corpus seed 1234,
 query seed 4321); queries are resident in HBM when the timed region starts.  `--data clustered` sorts the
 rows by topic cluster and draws the queries from the LAST clusters (documents ingested in topic order:
-the row order a real corpus has, /root/reference/src/vod_search/faiss_search/build.py:65-73).
+the row order a real corpus has, /root/reference/src/vod_search/faiss_search/build.py:65-73); `--data duplicates`
+repeats ONE section over the last tenth of the store and aims every query at it (candidate-list overflow and
+per-query recovery on the rank that holds those rows, and only there).
 
 Prints ONE JSON line on rank 0 (see the keys below); `roofline` is for the dominant kernel
 (`mips_filter16p_kernel`: MFMA-bound above ~312 queries per batch, HBM-bound below), `cpu_baseline` is the
@@ -32,7 +34,6 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 GEN_CHUNK = 250_000  # rows per generation chunk; shard boundaries are multiples of it so the corpus is the same for every N
-RIDGE_NQ = 312       # 2.5 PFLOP/s / 8 TB/s: batches below this many queries are HBM-bound
 
 
 def parse_args() -> argparse.Namespace:
@@ -45,14 +46,20 @@ def parse_args() -> argparse.Namespace:
     p.add_argument("--nq", type=int, default=1024)
     p.add_argument("--k", type=int, default=100)
     p.add_argument("--dtype", choices=["f16", "bf16"], default="f16")
-    p.add_argument("--data", choices=["iid", "clustered"], default="iid")
+    p.add_argument("--data", choices=["iid", "clustered", "duplicates"], default="iid")
     p.add_argument("--tile", type=int, default=0)
     p.add_argument("--growth", type=int, default=0, help="stage growth factor x100 (0 = library default)")
     p.add_argument("--force-collective", action="store_true",
                    help="run the multi-GPU step (RCCL all-gather of the packed top-k + merge) even with one rank: exercises the N > 1 code on a 1-GPU box")
-    p.add_argument("--param", action="append", default=[], metavar="KEY=VALUE", help="library tunable (vodhip_index_set_param), repeatable")
+    p.add_argument("--param", action="append", default=[], metavar="KEY=VALUE[@RANK]",
+                   help="library tunable (vodhip_index_set_param), repeatable; with @RANK only on that rank")
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                   help="process-group backend.  nccl (= RCCL) is the product path; gloo stages the packed all-gather through the host and "
+                        "lets several ranks share one GPU (RCCL refuses that): tests of the N > 1 step sequence on a 1-GPU box")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
+    p.add_argument("--no-side", action="store_true",
+                   help="skip the side workloads (C2, nq = 256, clustered C3, the 1.25 M-row shard with the exchange) the default 1-GPU run appends as `side`")
     p.add_argument("--verify-queries", type=int, default=64)
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     p.add_argument("--launch-check", action="store_true",
@@ -139,6 +146,9 @@ def make_rows(torch, dev, tdt, data: str, chunk: int, rows: int, d: int, n_total
         centers = cluster_centers(torch, dev, n_clusters, d)
         ridx = torch.arange(chunk * GEN_CHUNK, chunk * GEN_CHUNK + rows, device=dev, dtype=torch.int64)
         x = 0.6 * x + 0.8 * centers[(ridx * n_clusters) // n_total]  # unit variance, sorted by cluster
+    if data == "duplicates":  # the last tenth of the store is ONE section repeated: every query ties > cand_cap rows at its top score
+        ridx = torch.arange(chunk * GEN_CHUNK, chunk * GEN_CHUNK + rows, device=dev, dtype=torch.int64)
+        x = torch.where((ridx >= n_total - n_total // 10)[:, None], cluster_centers(torch, dev, 1, d)[0][None, :], x)
     return x.to(tdt)
 
 
@@ -155,7 +165,294 @@ def make_queries(torch, dev, tdt, data: str, nq: int, d: int, n_total: int):
         centers = cluster_centers(torch, dev, n_clusters, d)
         late = n_clusters - 1 - torch.randint(0, max(1, n_clusters // 10), (nq,), generator=g, device=dev)
         q = 0.6 * q + 0.8 * centers[late]
+    if data == "duplicates":  # every query scores the repeated section far above any other row
+        q = 0.6 * q + 0.8 * cluster_centers(torch, dev, 1, d)[0][None, :]
     return q.to(tdt)
+
+
+PRACTICAL_MFMA = 1.24e15   # flop/s a streaming fp16 contraction holds on this part (power-limited; DESIGN.md 5, MI355X_MICROARCH "DVFS give-back")
+PRACTICAL_HBM = 6.29e12    # B/s of a streaming copy (MI355X_MICROARCH.md:34-43)
+
+
+class Rig:
+    """Process-wide state of one bench process: device, rank, the (lazily created) process group."""
+
+    def __init__(self, torch, dev, rank, world, backend="nccl"):
+        self.torch, self.dev, self.rank, self.world, self.backend = torch, dev, rank, world, backend
+        self.dist = None
+
+    def ensure_group(self):
+        if self.dist is None:
+            import torch.distributed as dist  # noqa: PLC0415
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+
+                os.environ["MASTER_PORT"] = str(_free_rendezvous_port(socket))
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev, rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            self.dist = dist
+        return self.dist
+
+    def all_gather(self, dst, src) -> None:
+        """ONE all-gather of the packed per-rank record (RCCL: device buffers; gloo: staged through the host)."""
+        if self.backend == "nccl":
+            self.dist.all_gather_into_tensor(dst, src)
+        else:
+            host = self.torch.empty(dst.shape, dtype=dst.dtype)
+            self.dist.all_gather_into_tensor(host, src.cpu())
+            dst.copy_(host)
+
+    def all_reduce_scalar(self, value: float, op: str) -> float:
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return float(t.item())
+
+
+def build_index(rig: Rig, *, rows: int, dim: int, dtype: str, data: str, tile: int = 0, growth: int = 0, params=()):
+    """This rank's contiguous row shard (generation-chunk boundaries) of the synthetic corpus, resident in HBM."""
+    from vod_amd.index import HipFlatIndex
+
+    torch, dev = rig.torch, rig.dev
+    tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+    n_chunks = (rows + GEN_CHUNK - 1) // GEN_CHUNK
+    c_lo = (n_chunks * rig.rank) // rig.world
+    c_hi = (n_chunks * (rig.rank + 1)) // rig.world
+    row_lo = min(rows, c_lo * GEN_CHUNK)
+    row_hi = min(rows, c_hi * GEN_CHUNK)
+    index = HipFlatIndex(dim, max(row_hi - row_lo, 1), dtype=tdt, device=dev.index)
+    if tile:
+        index.set_param("tile", tile)
+    if growth:
+        index.set_param("growth", growth)
+    for kv in params:
+        kv, _, only_rank = kv.partition("@")
+        key, _, val = kv.partition("=")
+        if not only_rank or int(only_rank) == rig.rank:
+            index.set_param(key, int(val))
+    t0 = time.perf_counter()
+    for c in range(c_lo, c_hi):
+        index.add(make_rows(torch, dev, tdt, data, c, min(GEN_CHUNK, rows - c * GEN_CHUNK), dim, rows))
+    torch.cuda.synchronize()
+    assert index.ntotal == row_hi - row_lo
+    return index, row_lo, time.perf_counter() - t0
+
+
+def run_workload(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, k: int, dtype: str, data: str, multi: bool,
+                 steps: int, warmup: int, verify_queries: int, tile: int = 0) -> dict:
+    """W untimed + K timed steps of one workload on an index already resident in HBM; returns the measurements.
+
+    One step = one batch through the hot path.  The host runs ONE step ahead of the device: step i+1 is enqueued before
+    step i's exactness flag is checked (`finish` waits for that search alone), so the device never idles between batches.
+    Every step's check (and recovery, if a candidate list overflowed) happens inside the timed region.
+
+    Multi-rank steps are collective-safe by construction: a rank finishes (and, if needed, recovers) its LOCAL search of
+    step i first and only then issues step i's exchange, so every rank issues exactly one all-gather + merge per step
+    whether its shard overflowed or not (round 2 re-exchanged on the overflowing ranks only: mismatched collectives).
+    The exchange of step i is enqueued behind the local search of step i+1, which keeps the device busy while the host
+    waits for step i's flag; the two steps use alternating result records.
+    (Overlapping the all-gather with the next search on RCCL's own stream was measured and dropped in round 2: the
+    persistent filter kernel owns every CU, the collective's workgroups wait for one anyway: +11 % on the stage kernels.)
+    """
+    from vod_amd.index import PackedTopk, merge_topk
+
+    torch, dev, world = rig.torch, rig.dev, rig.world
+    dist = rig.ensure_group() if multi else None
+    tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+    n_local = index.ntotal
+    queries = make_queries(torch, dev, tdt, data, nq, dim, rows)
+    packed = [PackedTopk(nq, k, dev) for _ in range(2)]  # [scores | ids] records: the exchange is ONE all-gather of 12*nq*k bytes
+    gathered = torch.empty((world * packed[0].nbytes,), dtype=torch.uint8, device=dev) if multi else None
+    state = {"pending": [], "n": 0, "ns": 0, "launches": 0, "recovery_passes": 0, "recovery_ns": 0, "res": None}
+
+    def step():
+        p = packed[state["n"] % 2]
+        state["n"] += 1
+        index.search_async(queries, k, id_base=row_lo, out=(p.scores, p.ids))
+        state["pending"].append(p)
+        while len(state["pending"]) > 1:
+            finish_one()
+
+    def finish_one():
+        p = state["pending"].pop(0)
+        index.finish()  # waits for THIS search only; recovery passes (if any) run here, before the exchange
+        state["ns"] += index.get_stat("last_filter_ns")
+        state["launches"] += index.get_stat("last_filter_launches")
+        state["recovery_passes"] += index.get_stat("last_safe_reruns")
+        state["recovery_ns"] += index.get_stat("last_recovery_ns")
+        if multi:
+            rig.all_gather(gathered, p.buffer)
+            state["res"] = p.merge_gathered(gathered, world)
+        else:
+            state["res"] = (p.scores, p.ids)
+
+    def drain():
+        while state["pending"]:
+            finish_one()
+
+    def fence():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    drain()
+    index.set_param("profile", 1)
+    for key in ("ns", "launches", "recovery_passes", "recovery_ns"):
+        state[key] = 0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    drain()
+    fence()
+    elapsed = time.perf_counter() - t0
+    index.set_param("profile", 0)
+    if multi:
+        elapsed = rig.all_reduce_scalar(elapsed, "MAX")
+        state["recovery_passes"] = int(rig.all_reduce_scalar(state["recovery_passes"], "SUM"))  # over all ranks
+
+    # ---- post-run verification (outside the timed region): exactness on a query sample ----
+    verify = None
+    if verify_queries > 0:
+        fs, fi = state["res"]
+        n_v = min(nq, max(1, verify_queries))
+        sample = [int(round(j * (nq - 1) / max(1, n_v - 1))) for j in range(n_v)] if n_v > 1 else [0]
+        sample = sorted(set(sample))
+        # local brute force on this rank's shard with torch (fp32 matmul on the stored rows), merged over ranks
+        kk = min(k, n_local)
+        ls = torch.full((len(sample), kk), float("-inf"), device=dev)
+        li = torch.full((len(sample), kk), -1, dtype=torch.int64, device=dev)
+        qs = queries[sample].float()
+        for lo in range(0, n_local, 1_000_000):  # stable sorts: ties keep the smaller id first, like the product
+            blk = index.stored_rows(lo, min(1_000_000, n_local - lo)).float()
+            ts, ti = torch.sort(qs @ blk.T, dim=1, descending=True, stable=True)
+            ts, ti = ts[:, :kk], ti[:, :kk]
+            cs, ci = torch.cat([ls, ts], dim=1), torch.cat([li, ti + (lo + row_lo)], dim=1)
+            top = torch.sort(cs, dim=1, descending=True, stable=True)
+            ls, li = top.values[:, :kk], torch.gather(ci, 1, top.indices[:, :kk])
+            del blk
+        if multi:
+            pad_s = torch.full((len(sample), k), float("-inf"), device=dev)
+            pad_i = torch.full((len(sample), k), -1, dtype=torch.int64, device=dev)
+            pad_s[:, : ls.shape[1]] = ls
+            pad_i[:, : li.shape[1]] = li
+            as_ = torch.empty((world * len(sample), k), device=dev)
+            ai_ = torch.empty((world * len(sample), k), dtype=torch.int64, device=dev)
+            rig.all_gather(as_, pad_s)
+            rig.all_gather(ai_, pad_i)
+            ls, li = merge_topk(as_.view(world, len(sample), k), ai_.view(world, len(sample), k))
+        got_i = fi[sample].cpu()
+        ref_i = li.cpu()
+        hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got_i, ref_i))
+        verify = {
+            "recall_at_k_vs_torch_fp32": hits / float(ref_i.numel()),
+            "rows_with_identical_ids": float((got_i[:, : ref_i.shape[1]] == ref_i).all(dim=1).float().mean()),
+            "max_abs_score_diff": float((fs[sample][:, : ls.shape[1]].cpu() - ls.cpu()).abs().max()),
+            "queries_checked": len(sample),
+        }
+    return {"elapsed": elapsed, "filter_ns": state["ns"], "filter_launches": state["launches"], "recovery_passes": state["recovery_passes"],
+            "recovery_ns": state["recovery_ns"], "verify": verify, "n_local": n_local, "steps": steps, "warmup": warmup,
+            "rows": rows, "dim": dim, "nq": nq, "k": k, "dtype": dtype, "data": data, "multi": multi, "tile": tile}
+
+
+def _m(v: int) -> str:
+    return f"{v // 1_000_000}M" if v % 1_000_000 == 0 else (f"{v / 1e6:g}M" if v >= 1_000_000 else str(v))
+
+
+def roofline_of(m: dict, world: int) -> dict:
+    """Roofline record of the dominant kernel (the filter launches of a step) from live HIP-event durations.
+
+    Both fractions are always reported.  `bound` = the roof that binds at the ceilings this part actually holds (1.24 PFLOP/s
+    for a streaming fp16 contraction - power-limited - and 6.29 TB/s for a streaming read): nq = 256 on 10 M rows is
+    MFMA-bound by that measure (3.2 ms of MFMA against 2.4 ms of HBM) although the nameplate ridge (312 queries) says HBM.
+    `peak` stays the guide's nameplate figure of that roof.  Recovery launches, if any, are part of the kernel time."""
+    rows, d, nq, k, steps = m["rows"], m["dim"], m["nq"], m["k"], m["steps"]
+    n_local = m["n_local"]
+    flops = 2.0 * nq * n_local * d                       # algorithmic flops of this rank's filter launches per step
+    byts = n_local * d * 2.0 + nq * d * 2.0 + nq * k * 12.0
+    kern_s = (m["filter_ns"] + m["recovery_ns"]) * 1e-9
+    mfma_bound = flops / PRACTICAL_MFMA >= byts / PRACTICAL_HBM
+    tflops = flops * steps / kern_s / 1e12 if kern_s > 0 else None
+    gbps = byts * steps / kern_s / 1e9 if kern_s > 0 else None
+    achieved = tflops if mfma_bound else gbps
+    peak = 2500.0 if mfma_bound else 8000.0
+    traffic, traffic_src = None, None
+    tfile = ROOT / "profiles" / "hbm_traffic.json"
+    if tfile.exists():  # HBM bytes per step from this round's rocprofv3 --pmc passes of the same workload (tools/pmc.sh)
+        try:
+            ent = json.loads(tfile.read_text()).get(f"{rows}x{d}x{nq}@{world}" + ("" if m["data"] == "iid" else "/" + m["data"]))
+            if isinstance(ent, dict):
+                traffic, traffic_src = ent.get("bytes"), ent.get("source")
+            else:
+                traffic = ent
+        except Exception:
+            traffic = None
+    return {
+        "bound": "mfma" if mfma_bound else "hbm",
+        "bound_basis": "practical ceilings: 1.24 PFLOP/s streaming fp16 MFMA (power-limited), 6.29 TB/s streaming HBM read",
+        "kernel": "mips_filter16p_kernel" if (m["tile"] in (0, 8, 9) and nq > 128) else f"mips_filter_kernel[tile={m['tile']}]",
+        "achieved": achieved,
+        "peak": peak,
+        "unit": "TFLOP/s" if mfma_bound else "GB/s",
+        "frac": (achieved / peak) if achieved else None,
+        "traffic": traffic,
+        "traffic_source": traffic_src,
+        "launches_per_step": m["filter_launches"] / steps,
+        "kernel_ms_per_step": kern_s / steps * 1e3,
+        "includes_recovery_launches": m["recovery_ns"] > 0,
+        "algorithmic_flops_per_step": flops,
+        "algorithmic_bytes_per_step": byts,
+        "mfma_frac_of_2.5PF": (tflops / 2500.0) if tflops else None,
+        "hbm_frac_at_8TBps": (gbps / 8000.0) if gbps else None,
+    }
+
+
+def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
+    """The regimes next to the headline, timed by the same process in the same run (a few seconds): BASELINE configs[1]
+    (C2), the 1.25 M-row shard each of 8 GPUs holds of C3 with the exchange step on RCCL (one rank gathers from itself),
+    nq = 256 on the headline store (one q-tile) and C3 with rows sorted by topic cluster.  Each entry carries ms/batch,
+    q/s and the same roofline record as the headline; a failing side run is reported as {"error": ...} and never touches
+    the headline fields."""
+    out = []
+
+    def one(name, *, rows, nq, data="iid", multi=False, steps, warmup, index=None, row_lo=0):
+        try:
+            own = index is None
+            t_build = None
+            if own:
+                index, row_lo, t_build = build_index(rig, rows=rows, dim=args.dim, dtype=args.dtype, data=data)
+            try:
+                m = run_workload(rig, index, row_lo, rows=rows, dim=args.dim, nq=nq, k=args.k, dtype=args.dtype, data=data,
+                                 multi=multi, steps=steps, warmup=warmup, verify_queries=args.verify_queries)
+            finally:
+                if own:
+                    index.close()
+            out.append({
+                "name": name,
+                "workload": f"{rows} sections x {args.dim} {args.dtype}, batch {nq} queries, top-{args.k}" + ("" if data == "iid" else ", rows sorted by topic cluster")
+                            + (", + RCCL all-gather (1 rank) + merge" if multi else ""),
+                "steps": steps, "warmup": warmup,
+                "ms_per_step": m["elapsed"] / steps * 1e3,
+                "value": nq * steps / m["elapsed"],
+                "unit": "queries/s",
+                "recovery_passes": m["recovery_passes"],
+                "index_build_s": None if t_build is None else round(t_build, 3),
+                "roofline": roofline_of(m, rig.world),
+                "verify": m["verify"],
+            })
+        except Exception as exc:  # noqa: BLE001 - a side line must never take the headline down
+            out.append({"name": name, "error": f"{type(exc).__name__}: {exc}"[:400]})
+
+    one("C2", rows=1_000_000, nq=256, steps=200, warmup=20)
+    one("C3_nq256", rows=args.rows, nq=256, steps=50, warmup=5, index=headline_index, row_lo=headline_row_lo)
+    one("C3_clustered", rows=args.rows, nq=args.nq, data="clustered", steps=max(5, args.steps), warmup=3)
+    one("C3_shard_of_8_with_exchange", rows=args.rows // 8, nq=args.nq, multi=True, steps=100, warmup=10)
+    return out
 
 
 def main() -> None:
@@ -174,176 +471,33 @@ def main() -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if args.backend == "gloo":  # test rig: the ranks may share a GPU
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
     multi = world > 1 or args.force_collective  # the exchange step runs (with one rank it gathers from itself)
     if rank != 0:  # only rank 0 reports: keep the other ranks' library banners out of the launcher's merged stdout
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    rig = Rig(torch, dev, rank, world, args.backend)
     if multi:
-        import torch.distributed as dist  # noqa: PLC0415
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        rig.ensure_group()
 
-    from vod_amd.index import HipFlatIndex, PackedTopk, merge_topk
-
-    tdt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     n_total, d, nq, k = args.rows, args.dim, args.nq, args.k
-    # contiguous row sharding on generation-chunk boundaries
-    n_chunks = (n_total + GEN_CHUNK - 1) // GEN_CHUNK
-    c_lo = (n_chunks * rank) // world
-    c_hi = (n_chunks * (rank + 1)) // world
-    row_lo = min(n_total, c_lo * GEN_CHUNK)
-    row_hi = min(n_total, c_hi * GEN_CHUNK)
-    n_local = row_hi - row_lo
+    index, row_lo, t_build = build_index(rig, rows=n_total, dim=d, dtype=args.dtype, data=args.data, tile=args.tile, growth=args.growth,
+                                         params=args.param)
+    m = run_workload(rig, index, row_lo, rows=n_total, dim=d, nq=nq, k=k, dtype=args.dtype, data=args.data, multi=multi,
+                     steps=args.steps, warmup=args.warmup, verify_queries=0 if args.no_verify else args.verify_queries, tile=args.tile)
+    default_workload = (n_total, d, nq, k, args.dtype, args.data, args.tile, args.growth, tuple(args.param)) == (10_000_000, 768, 1024, 100, "f16", "iid", 0, 0, ())
+    side = None
+    if world == 1 and not args.force_collective and not args.no_side and default_workload:
+        side = side_workloads(rig, args, index, row_lo)
+    index.close()
 
-    index = HipFlatIndex(d, max(n_local, 1), dtype=tdt, device=local_rank)
-    if args.tile:
-        index.set_param("tile", args.tile)
-    if args.growth:
-        index.set_param("growth", args.growth)
-    for kv in args.param:
-        key, _, val = kv.partition("=")
-        index.set_param(key, int(val))
-    t_build0 = time.perf_counter()
-    for c in range(c_lo, c_hi):
-        index.add(make_rows(torch, dev, tdt, args.data, c, min(GEN_CHUNK, n_total - c * GEN_CHUNK), d, n_total))
-    torch.cuda.synchronize()
-    t_build = time.perf_counter() - t_build0
-    assert index.ntotal == n_local
-    queries = make_queries(torch, dev, tdt, args.data, nq, d, n_total)
-
-    packed = PackedTopk(nq, k, dev)  # [scores | ids] record of this rank: the exchange is ONE all-gather of 12*nq*k bytes
-    out_s, out_i = packed.scores, packed.ids
-    if multi:
-        gathered = torch.empty((world * packed.nbytes,), dtype=torch.uint8, device=dev)
-
-    # One step = one batch through the hot path.  The host runs ONE step ahead of the device: step i+1 is enqueued
-    # before step i's exactness flag is checked (`finish` waits for that search alone), so the device never idles
-    # between batches.  Every step's check (and recovery, if a candidate list overflowed) happens inside the timed
-    # region; a recovered step re-sends its (now complete) local result through the exchange.
-    # (Overlapping the all-gather of batch i with the search of batch i+1 on RCCL's stream was measured and dropped: the
-    # persistent filter kernel owns every CU, the collective's workgroups wait for one anyway and slow the stage kernels
-    # by 11 %: 1.936 ms per batch against 1.929 for this plain sequence on a 1.25 M-row shard.)
-    state = {"in_flight": 0, "ns": 0, "launches": 0, "recovery_passes": 0, "res": None}
-
-    def exchange():
-        dist.all_gather_into_tensor(gathered, packed.buffer)
-        return packed.merge_gathered(gathered, world)
-
-    def step():
-        index.search_async(queries, k, id_base=row_lo, out=(out_s, out_i))
-        state["in_flight"] += 1
-        state["res"] = exchange() if multi else (out_s, out_i)
-        while state["in_flight"] > 1:
-            finish_one()
-
-    def finish_one():
-        index.finish()
-        state["in_flight"] -= 1
-        state["ns"] += index.get_stat("last_filter_ns")
-        state["launches"] += index.get_stat("last_filter_launches")
-        passes = index.get_stat("last_safe_reruns")
-        if passes:
-            state["recovery_passes"] += passes
-            if multi:  # every step searches the same queries: the recovered local result replaces the exchanged one
-                state["res"] = exchange()
-
-    def drain():
-        while state["in_flight"]:
-            finish_one()
-
-    def fence():
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    drain()
-    index.set_param("profile", 1)
-    state["ns"] = state["launches"] = state["recovery_passes"] = 0
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    fence()
-    elapsed = time.perf_counter() - t0
-    filter_ns, filter_launches = state["ns"], state["launches"]
-    index.set_param("profile", 0)
-    if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- post-run verification (outside the timed region): exactness on a query sample ----
-    verify = None
-    if not args.no_verify:
-        fs, fi = state["res"]
-        n_v = min(nq, max(1, args.verify_queries))
-        sample = [int(round(j * (nq - 1) / max(1, n_v - 1))) for j in range(n_v)] if n_v > 1 else [0]
-        sample = sorted(set(sample))
-        # local brute force on this rank's shard with torch (fp32 matmul on the stored rows), merged over ranks
-        kk = min(k, n_local)
-        ls = torch.full((len(sample), kk), float("-inf"), device=dev)
-        li = torch.full((len(sample), kk), -1, dtype=torch.int64, device=dev)
-        qs = queries[sample].float()
-        for lo in range(0, n_local, 1_000_000):
-            blk = index.stored_rows(lo, min(1_000_000, n_local - lo)).float()
-            ts, ti = torch.topk(qs @ blk.T, min(kk, blk.shape[0]), dim=1)
-            cs, ci = torch.cat([ls, ts], dim=1), torch.cat([li, ti + (lo + row_lo)], dim=1)
-            top = torch.topk(cs, kk, dim=1)
-            ls, li = top.values, torch.gather(ci, 1, top.indices)
-            del blk
-        if multi:
-            pad_s = torch.full((len(sample), k), float("-inf"), device=dev)
-            pad_i = torch.full((len(sample), k), -1, dtype=torch.int64, device=dev)
-            pad_s[:, : ls.shape[1]] = ls
-            pad_i[:, : li.shape[1]] = li
-            as_ = torch.empty((world * len(sample), k), device=dev)
-            ai_ = torch.empty((world * len(sample), k), dtype=torch.int64, device=dev)
-            dist.all_gather_into_tensor(as_, pad_s)
-            dist.all_gather_into_tensor(ai_, pad_i)
-            ls, li = merge_topk(as_.view(world, len(sample), k), ai_.view(world, len(sample), k))
-        got_i = fi[sample].cpu()
-        ref_i = li.cpu()
-        hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got_i, ref_i))
-        verify = {
-            "recall_at_k_vs_torch_fp32": hits / float(ref_i.numel()),
-            "max_abs_score_diff": float((fs[sample][:, : ls.shape[1]].cpu() - ls.cpu()).abs().max()),
-            "queries_checked": len(sample),
-        }
-
+    line = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
+        elapsed = m["elapsed"]
         qps = nq * args.steps / elapsed
-        flops_per_step = 2.0 * nq * n_local * d          # algorithmic flops of this rank's filter launches per step
-        bytes_per_step = n_local * d * 2.0 + nq * d * 2.0 + nq * k * 12.0
-        filt_s = filter_ns * 1e-9
-        mfma_bound = nq >= RIDGE_NQ
-        if filt_s > 0:
-            achieved = flops_per_step * args.steps / filt_s / 1e12 if mfma_bound else bytes_per_step * args.steps / filt_s / 1e9
-        else:
-            achieved = None
-        peak = 2500.0 if mfma_bound else 8000.0
-        traffic, traffic_src = None, None
-        tfile = ROOT / "profiles" / "hbm_traffic.json"
-        if tfile.exists():  # HBM bytes per step from this round's rocprofv3 --pmc passes of the same command (tools/pmc.sh)
-            try:
-                ent = json.loads(tfile.read_text()).get(f"{n_total}x{d}x{nq}@{world}" + ("" if args.data == "iid" else "/clustered"))
-                if isinstance(ent, dict):
-                    traffic, traffic_src = ent.get("bytes"), ent.get("source")
-                else:
-                    traffic = ent
-            except Exception:
-                traffic = None
-
-        def _m(v: int) -> str:
-            return f"{v // 1_000_000}M" if v % 1_000_000 == 0 else (f"{v / 1e6:g}M" if v >= 1_000_000 else str(v))
-
         line = {
             "metric": f"queries/sec brute-force top-k ({_m(n_total)}x{d} {'fp16' if args.dtype == 'f16' else 'bf16'})",
             "value": qps,
@@ -351,47 +505,34 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic" if args.data == "iid" else "synthetic, rows sorted by topic cluster, queries from the last clusters",
+            "data": {"iid": "synthetic", "clustered": "synthetic, rows sorted by topic cluster, queries from the last clusters",
+                     "duplicates": "synthetic, one section repeated over the last tenth of the store, every query aimed at it"}[args.data],
             "config": {
                 "workload": f"{n_total} sections x {d} {args.dtype}, batch {nq} queries, top-{k}, exact brute force",
-                "rows_per_gpu": n_local,
-                "parallelism": f"row-sharded x{world} + RCCL all-gather of per-shard top-k" if multi else "single GPU",
+                "rows_per_gpu": m["n_local"],
+                "parallelism": (f"row-sharded x{world} + {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} all-gather of per-shard top-k") if multi else "single GPU",
                 "index_build_s": round(t_build, 3),
-                "recovery_passes": state["recovery_passes"],
+                "recovery_passes": m["recovery_passes"],
             },
-            "roofline": {
-                "bound": "mfma" if mfma_bound else "hbm",
-                "kernel": "mips_filter16p_kernel" if (args.tile in (0, 8, 9) and nq > 128) else f"mips_filter_kernel[tile={args.tile}]",
-                "achieved": achieved,
-                "peak": peak,
-                "unit": "TFLOP/s" if mfma_bound else "GB/s",
-                "frac": (achieved / peak) if achieved else None,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "launches_per_step": filter_launches / args.steps,
-                "kernel_ms_per_step": filt_s / args.steps * 1e3,
-                "algorithmic_flops_per_step": flops_per_step,
-                "algorithmic_bytes_per_step": bytes_per_step,
-                "mfma_frac_of_2.5PF": (flops_per_step * args.steps / filt_s / 2.5e15) if filt_s > 0 else None,
-                "hbm_frac_at_8TBps": (bytes_per_step * args.steps / filt_s / 8e12) if filt_s > 0 else None,
-            },
+            "roofline": roofline_of(m, world),
         }
-        if verify is not None:
-            line["verify"] = verify
+        if m["verify"] is not None:
+            line["verify"] = m["verify"]
+        if side is not None:
+            line["side"] = side
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_baseline import time_cpu_baseline  # the reported CPU baseline, never the product path
 
             line["cpu_baseline"] = time_cpu_baseline(d, nq, k, n_total, target_seconds=args.cpu_seconds)
             line["speedup_vs_cpu_baseline"] = qps / line["cpu_baseline"]["value"]
-    index.close()
-    if multi:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rig.dist is not None:
+        rig.dist.barrier()
+        rig.dist.destroy_process_group()
     if rank == 0:
         # RCCL writes a version banner through C stdio (block-buffered when stdout is a pipe): flush it first so that
         # the JSON line is the LAST line of rank 0's stdout

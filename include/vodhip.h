@@ -114,14 +114,16 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
  *   every filter launch), "kflags" (timing knobs of diagnostic builds).
  * stats (of the search completed by the last vodhip_index_search_finish): "last_overflow" (a candidate list overflowed),
  *   "last_safe_reruns" (recovery passes run), "last_recovered_queries" (queries the first recovery pass re-searched),
- *   "last_chunks" (stages), "last_filter_launches", "last_filter_ns" (with "profile"). */
+ *   "last_chunks" (stages), "last_filter_launches", "last_filter_ns" (with "profile"), "last_recovery_launches",
+ *   "last_recovery_ns" (the filter launches of the recovery passes, accounted separately). */
 int vodhip_index_set_param(vodhip_index_t* index, const char* key, int64_t value);
-/* Host-side planning only (no device is touched): the stage list a search of `nq` queries for the top `k` of `ntotal` rows
- * would run, with the given tunables (<= 0 = library default; tile 0 = auto; recovery_pass 0 = the normal schedule).
+/* Host-side planning only (no device and no HIP runtime call): the stage list a search of `nq` queries for the top `k` of
+ * `ntotal` rows would run on a device with `n_cu` compute units (<= 0 = 256, the MI355X), with the given tunables (<= 0 =
+ * library default; tile 0 = auto; recovery_pass 0 = the normal schedule).  An index reads its device's CU count once, at create.
  * out: int64 [max_stages][6] = {kind (0 FILTER, 1 DENSE, 2 GMAX bootstrap), row_begin, row_end, sampled tiles, sample row
  * stride, sample groups}.  Returns the number of stages, or -1. */
 int vodhip_debug_schedule(int64_t ntotal, int k, int64_t nq, int64_t cand_cap, int64_t dense_rows, int64_t sample_div,
-                          int64_t growth_x100, int tile, int recovery_pass, int64_t* out, int max_stages);
+                          int64_t growth_x100, int tile, int recovery_pass, int n_cu, int64_t* out, int max_stages);
 int vodhip_index_get_stat(const vodhip_index_t* index, const char* key, int64_t* out);
 
 /* ---------------------------------------------------------------------------------------------

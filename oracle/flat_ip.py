@@ -83,9 +83,15 @@ def flat_ip_topk(q: np.ndarray, x: np.ndarray, k: int, block: int = 65536, id_ba
         new_s = np.empty((nq, keep), dtype=np.float64)
         new_i = np.empty((nq, keep), dtype=np.int64)
         for r in range(nq):
-            order = np.lexsort((ci[r], -cs[r]))[:keep]
-            new_s[r] = cs[r, order]
-            new_i[r] = ci[r, order]
+            row_s, row_i = cs[r], ci[r]
+            if row_s.size > 4 * keep:
+                # only entries >= the keep-th largest value can be selected (every tie of that value is kept)
+                kth = np.partition(row_s, row_s.size - keep)[row_s.size - keep]
+                sel = np.nonzero(row_s >= kth)[0]
+                row_s, row_i = row_s[sel], row_i[sel]
+            order = np.lexsort((row_i, -row_s))[:keep]
+            new_s[r] = row_s[order]
+            new_i[r] = row_i[order]
         best_s, best_i = new_s, new_i
     out_s = np.full((nq, k), -np.inf, dtype=np.float32)
     out_i = np.full((nq, k), -1, dtype=np.int64)

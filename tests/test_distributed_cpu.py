@@ -92,6 +92,8 @@ def _group_worker(rank, world, port, out_dir):
         lo, hi = bounds[rank], bounds[rank + 1]
 
         def local_search(queries, kk, base, subset=None):
+            if kk == 1999:  # stands for an argument error the library raises on EVERY rank before its collective
+                raise ValueError("injected: every rank refuses k = 1999")
             q = queries.numpy()
             if subset is None:
                 s, i = flat_ip_topk(q, x[lo:hi], kk, id_base=base)
@@ -109,12 +111,31 @@ def _group_worker(rank, world, port, out_dir):
             s, i = merge_shard_topk(list(gs.numpy()), list(gi.numpy()), gs.shape[-1])
             return torch.from_numpy(s), torch.from_numpy(i)
 
-        disp = GroupDispatcher(ShardedFlatIndex(None, lo, local_search=local_search, merge=merge), rank, world, torch.device("cpu"))
+        disp = GroupDispatcher(ShardedFlatIndex(None, lo, local_search=local_search, merge=merge), rank, world, torch.device("cpu"), dim=d)
         if rank != 0:
             served = disp.worker_loop()
-            np.save(os.path.join(out_dir, f"served_{rank}.npy"), np.array([served]))
+            np.save(os.path.join(out_dir, f"served_{rank}.npy"), np.array([served, disp.errors]))
             return
         ok = True
+        # requests the library would refuse are stopped on rank 0 BEFORE any broadcast (round-2 advisor: one such request
+        # killed every worker of the group server); the workers never see them and the next search is served normally
+        q_ok = rng.integers(-4, 5, size=(3, d)).astype(np.float32)
+        refused = 0
+        for bad_q, bad_k, bad_sub in [(q_ok, 0, None), (q_ok, 5000, None), (q_ok, -3, None), (q_ok[0], 5, None), (q_ok[:, :5], 5, None),
+                                      (q_ok, 5, np.zeros((3, 65), np.int32)), (q_ok, 5, np.zeros((2, 4), np.int32))]:
+            try:
+                disp.search(bad_q, bad_k, subset=bad_sub)
+            except ValueError:
+                refused += 1
+        ok = ok and refused == 7
+        es, ei = disp.search(q_ok[:0], 4)
+        ok = ok and es.shape == (0, 4) and ei.shape == (0, 4)
+        # an error that every rank raises inside its local search: rank 0 reports it, the workers log it and keep serving
+        try:
+            disp.search(q_ok, 1999)
+            ok = False
+        except ValueError:
+            pass
         for nq, k, with_subset in [(7, 10, False), (1, 3, False), (33, 50, True), (5, 2000, False)]:
             q = rng.integers(-4, 5, size=(nq, d)).astype(np.float32)
             sub = None
@@ -141,4 +162,29 @@ def test_group_dispatcher_two_ranks_gloo(tmp_path):
     search, rank 0's merged answers equal the oracle on the whole store, the stop word ends rank 1's loop."""
     mp.spawn(_group_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert np.load(tmp_path / "ok_0.npy")[0] == 1
-    assert np.load(tmp_path / "served_1.npy")[0] == 4
+    assert np.load(tmp_path / "served_1.npy").tolist() == [5, 1]  # 4 good searches + the one every rank refused; 7 bad ones never left rank 0
+
+
+def test_group_dispatcher_eight_ranks_gloo(tmp_path):
+    """The same dispatch at the node's full width: 8 ranks (375 rows each), rank 0 drives, 7 workers serve."""
+    mp.spawn(_group_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
+    assert np.load(tmp_path / "ok_0.npy")[0] == 1
+    for r in range(1, 8):
+        assert np.load(tmp_path / f"served_{r}.npy").tolist() == [5, 1]
+
+
+def test_bench_launcher_eight_ranks():
+    """`python bench.py --gpus 8 --launch-check`: the self-launcher at the driver's widest configuration (8 fresh children,
+    gloo rendezvous on 127.0.0.1, only rank 0 reports)."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--launch-check"], capture_output=True, text=True,
+                         timeout=600, env=env, cwd=str(ROOT))
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"launch_check": "ok", "world": 8, "rank_sum": 28.0}

@@ -669,6 +669,43 @@ def test_full_size_c4_properties():
     _full_size_properties(40_000_000, 1024, 512, 200, "bfloat16")
 
 
+# ---- round 3: BASELINE configs[1] (C2) at its full size ------------------------------------------------------------------
+
+
+def test_full_size_c2_properties():
+    """BASELINE configs[1]: 1 M x 768 fp16, batch 256, top-100 on one GPU (the single-q-tile / `nt` cache-policy path of the
+    persistent kernel, different code from C3's four q-tiles)."""
+    _full_size_properties(1_000_000, 768, 256, 100, "float16", n_check=256)
+
+
+@pytest.fixture(scope="module")
+def c2_integer_case():
+    """C2-sized integer-valued store (every partial sum exact in fp32, many ties) + the blocked fp64 oracle's answer."""
+    rng = np.random.default_rng(2002)
+    n, d, nq = 1_000_000, 768, 256
+    x = np.empty((n, d), dtype=np.float16)
+    for lo in range(0, n, 100_000):  # int8 draws, chunked: an int64 draw of the whole store would take 6 GB
+        x[lo : lo + 100_000] = rng.integers(-8, 9, size=(100_000, d), dtype=np.int8)
+    q = rng.integers(-8, 9, size=(nq, d), dtype=np.int8).astype(np.float16)
+    rs, ri = _oracle(q, x, 100)
+    return q, x, rs, ri
+
+
+@pytest.mark.parametrize("tile", [0, 8, 9])
+def test_c2_shape_exact_integer(c2_integer_case, tile):
+    """C2 (1 M x 768 fp16, nq 256, k 100) bit for bit against the oracle: ids and scores, production tiles."""
+    q, x, rs, ri = c2_integer_case
+    with _index(x, tile=tile) as ix:
+        s, i = ix.search(torch.from_numpy(q).cuda(), 100)
+        assert ix.get_stat("last_chunks") >= 3  # bootstrap + filter stages, not the dense schedule
+        np.testing.assert_array_equal(i.cpu().numpy(), ri)
+        np.testing.assert_array_equal(s.cpu().numpy(), rs)
+        # the same rows as two shards + merge, and with an id base
+        s2, i2 = ix.search(torch.from_numpy(q).cuda(), 100, id_base=7_000_000)
+        np.testing.assert_array_equal(i2.cpu().numpy(), ri + 7_000_000)
+        np.testing.assert_array_equal(s2.cpu().numpy(), rs)
+
+
 @pytest.mark.parametrize("tile,nq", [(8, 1024), (9, 1024), (8, 200), (46, 100), (42, 33)])
 def test_repeated_searches_are_bit_identical(tile, nq):
     """Candidates reach the lists in a different order on every run (atomics, wave timing); the answer may not depend on it.

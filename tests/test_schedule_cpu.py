@@ -19,13 +19,13 @@ from hypothesis import strategies as st
 FILTER, DENSE, GMAX = 0, 1, 2
 
 
-def _schedule(n, k, nq, cap=0, dense=0, sdiv=0, growth=0, tile=0, recovery=0):
+def _schedule(n, k, nq, cap=0, dense=0, sdiv=0, growth=0, tile=0, recovery=0, n_cu=256):
     from vod_amd import _native
 
     lib = _native.load_library()
     max_stages = 1 << 18  # a 256-entry candidate list on a 40 M-row store is legal and plans > 100 k stages
     out = (ctypes.c_int64 * (max_stages * 6))()
-    r = lib.vodhip_debug_schedule(n, k, nq, cap, dense, sdiv, growth, tile, recovery, out, max_stages)
+    r = lib.vodhip_debug_schedule(n, k, nq, cap, dense, sdiv, growth, tile, recovery, n_cu, out, max_stages)
     assert r >= 0, _native.last_error() if hasattr(_native, "last_error") else r
     return np.array(out[: r * 6], dtype=np.int64).reshape(r, 6)
 

@@ -4,6 +4,8 @@ picklable HTTP client queries it -- the counterpart of /root/reference/examples/
 import os
 import pickle
 
+import time
+
 import numpy as np
 import pytest
 
@@ -205,7 +207,20 @@ def test_multi_gpu_group_server_three_workers_sharing_the_gpu(tmp_path):
             rs, ri = flat_ip_topk(q[lo:hi], x, kk)
             np.testing.assert_array_equal(res.indices, ri)
             np.testing.assert_array_equal(res.scores, rs)
+        # malformed requests (round-2 advisor: they killed every worker of the group) come back as HTTP 500 and the group keeps serving
+        import requests
+
+        for bad_k in (0, 5000):
+            with pytest.raises(requests.HTTPError):
+                c.search(vector=q[:4], top_k=bad_k)
+        with pytest.raises(requests.HTTPError):
+            c.search(vector=q[:4, :7], top_k=5)
+        with pytest.raises(requests.HTTPError):
+            c.search(vector=q[:2], subset_ids=[[f"doc{j}" for j in range(70)], []], top_k=5)
+        assert c.ping()
         res = c.search(vector=q[:40], subset_ids=subset_ids, top_k=20)
+        t_exit = time.monotonic()
+    assert time.monotonic() - t_exit < 20, "orderly shutdown: rank 0 stops the workers, nobody waits for the kill timeout"
     assert not m.get_client().ping()
     masked = q[:40].astype(np.float64) @ x.astype(np.float64).T
     for r, names_r in enumerate(subset_ids):

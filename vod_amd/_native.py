@@ -54,7 +54,7 @@ SIGNATURES: dict[str, tuple] = {
     "vodhip_index_set_row_labels": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "vodhip_index_set_query_labels": (_i32, [_vp, _vp, _i32]),
     "vodhip_index_set_param": (_i32, [_vp, _c.c_char_p, _i64]),
-    "vodhip_debug_schedule": (_i32, [_i64, _i32, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _c.POINTER(_i64), _i32]),
+    "vodhip_debug_schedule": (_i32, [_i64, _i32, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _c.POINTER(_i64), _i32]),
     "vodhip_index_get_stat": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i64)]),
     "vodhip_merge_topk": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "vodhip_merge_topk_strided": (_i32, [_vp, _i64, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),

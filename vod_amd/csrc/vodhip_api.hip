@@ -89,10 +89,12 @@ struct vodhip_index {
     int64_t tile = 0;
     int64_t kflags = 0;
     int64_t small_chunk_tiles = 256;  // launches with fewer 256x256 tiles than this (less than one per CU) use the 128x128 kernel
+    int n_cu = 256;       // compute units of `device` (read once at create; the planner never touches the runtime)
     int64_t profile = 0;  // 1: bracket every filter launch with HIP events (bench / roofline accounting)
     // stats
     int64_t last_overflow = 0, last_chunks = 0, last_safe_reruns = 0, last_recovered_queries = 0;
     int64_t last_filter_launches = 0, last_filter_ns = 0;
+    int64_t last_recovery_launches = 0, last_recovery_ns = 0;  // filter launches of the recovery passes (with "profile")
     std::vector<hipEvent_t> ev_pool;  // pairs (start, stop), reused across searches
     size_t ev_used = 0;
 };
@@ -203,8 +205,7 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad,
     if (filter_tile_is_persistent(gmax_tile)) {
         // the persistent kernel runs one workgroup per CU: a bootstrap of r.x "rounds" of tiles costs as much as r+1 full ones.
         // Whole rounds only: down when that keeps >= 4k groups (a cheaper bootstrap), up otherwise (a tighter bound for free)
-        int dev = 0, n_cu = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        const int64_t n_cu = std::max(1, ix->n_cu);
         const int64_t per_round = std::max<int64_t>(1, n_cu / std::max<int64_t>(1, nq_pad / 256)) * bm;  // sampled rows per round
         const int64_t down = s / per_round * per_round, up = round_up(s, per_round);
         if (down >= s_min) s = down;
@@ -351,6 +352,7 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
     ix->capacity = capacity_rows;
     ix->capacity_pad = round_up(capacity_rows, ROW_ALIGN) + 2 * ROW_ALIGN;  // the last tile (up to 384 rows from a 256-aligned start) never reads past the allocation
     ix->dtype = store_dtype;
+    if (hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ix->n_cu < 1) ix->n_cu = 256;
     const size_t bytes = (size_t)ix->capacity_pad * ix->dim_pad * 2;
     hipError_t e = hipMalloc((void**)&ix->data, bytes);
     if (e != hipSuccess) {
@@ -536,6 +538,8 @@ int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
     ix->last_overflow = 0;
     ix->last_safe_reruns = 0;
     ix->last_recovered_queries = 0;
+    ix->last_recovery_launches = 0;
+    ix->last_recovery_ns = 0;
     if (ps.nq > 0) {
         HIP_OK(hipEventSynchronize(ix->done[ps.slot]));  // this search only: younger ones keep the device busy
         // A candidate list overflowed: the result is valid (real rows, real scores) but may miss hits.  Recovery
@@ -563,10 +567,17 @@ int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
                     rs.nq = (int64_t)rows.size();
                 }
             }
-            const size_t ev_keep = ix->ev_used;
+            const size_t ev_first = ix->ev_used;  // behind the events of every younger search in flight
             if (enqueue_search(ix, rs, false, pass, stream)) return -1;
-            ix->ev_used = ev_keep;  // recovery passes are not part of the launch accounting
             HIP_OK(hipStreamSynchronize(stream));
+            // the recovery launches are accounted separately ("last_recovery_ns"): the time they take is real
+            for (size_t e = ev_first; e + 1 < ix->ev_used; e += 2) {
+                float ms = 0.f;
+                HIP_OK(hipEventElapsedTime(&ms, ix->ev_pool[e], ix->ev_pool[e + 1]));
+                ix->last_recovery_ns += (int64_t)((double)ms * 1e6);
+                ++ix->last_recovery_launches;
+            }
+            ix->ev_used = ev_first;
         }
     }
     ix->last_filter_launches = (int64_t)((ps.ev_end - ps.ev_begin) / 2);
@@ -586,10 +597,11 @@ int vodhip_index_search(vodhip_index_t* ix, const void* queries, int q_dtype, in
 }
 
 int vodhip_debug_schedule(int64_t ntotal, int k, int64_t nq, int64_t cand_cap, int64_t dense_rows, int64_t sample_div,
-                          int64_t growth_x100, int tile, int recovery_pass, int64_t* out, int max_stages) {
+                          int64_t growth_x100, int tile, int recovery_pass, int n_cu, int64_t* out, int max_stages) {
     if (!out || max_stages < 1 || k < 1 || nq < 1 || ntotal < 0) return fail("invalid arguments");
     vodhip_index tmp;  // host-side planning only: no device call uses it
     tmp.ntotal = ntotal;
+    tmp.n_cu = n_cu > 0 ? n_cu : 256;
     if (cand_cap > 0) tmp.cand_cap = cand_cap;
     if (dense_rows > 0) tmp.dense_rows = round_up(dense_rows, ROW_ALIGN);
     if (sample_div > 0) tmp.sample_div = sample_div;
@@ -660,6 +672,10 @@ int vodhip_index_get_stat(const vodhip_index_t* ix, const char* key, int64_t* ou
         *out = ix->last_filter_launches;
     else if (!strcmp(key, "last_filter_ns"))
         *out = ix->last_filter_ns;
+    else if (!strcmp(key, "last_recovery_launches"))
+        *out = ix->last_recovery_launches;
+    else if (!strcmp(key, "last_recovery_ns"))
+        *out = ix->last_recovery_ns;
     else if (!strcmp(key, "cand_cap"))
         *out = ix->cand_cap;
     else if (!strcmp(key, "dense_rows"))

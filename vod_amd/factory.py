@@ -26,8 +26,9 @@ class HipMipsFactoryConfig:
     metric: str = "inner_product"   # src/vod_configs/search.py:130
     dtype: str = "float16"          # HBM storage type (float16 | bfloat16)
     host: str = "http://localhost"
-    port: int = 6637                # the reference's default (faiss_search/client.py:124); < 0 = pick a free one, which only
-                                    # works when ONE process resolves it and tells the others - see `resolve_port`
+    port: int = -1                  # the reference config's default (src/vod_configs/search.py:134): < 0 = pick a free port, so two
+                                    # default-config indexes on one host (hybrid set-ups, shards, two jobs) never collide; ONE
+                                    # process resolves it and tells the others - see `resolve_port` / `broadcast_fn`
     logging_level: str = "CRITICAL"
     device: int = 0
     devices: tuple[int, ...] | None = None  # row-shard the store over these GPUs behind one address

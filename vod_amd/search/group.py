@@ -14,16 +14,22 @@ under RCCL, the CPU under gloo (tests, `--group-backend gloo`); `search_device` 
 """
 from __future__ import annotations
 
+import logging
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
 OP_STOP, OP_SEARCH = 0, 1
+MAX_K = 2048              # VODHIP_MAX_K (include/vodhip.h)
+MAX_SUBSET_LABELS = 64    # vodhip_index_set_query_labels
 
 
 class GroupDispatcher:
     def __init__(self, sharded, rank: int, world: int, device: torch.device, group: dist.ProcessGroup | None = None,
-                 search_device: torch.device | None = None):
+                 search_device: torch.device | None = None, dim: int | None = None):
+        self.dim = dim  # query dimension of the store, checked on rank 0 before a request is broadcast
+        self.errors = 0
         self.sharded = sharded  # ShardedFlatIndex-like: .search(queries, k, subset=None) -> (scores, ids), collective
         self.rank, self.world, self.device, self.group = rank, world, device, group
         # where the shard lives when that is not where the broadcast tensors live (gloo group in front of GPU shards)
@@ -32,6 +38,25 @@ class GroupDispatcher:
     # -- rank 0 ------------------------------------------------------------------------------------
     def search(self, query_vec: np.ndarray, top_k: int, subset: np.ndarray | None = None) -> tuple[np.ndarray, np.ndarray]:
         assert self.rank == 0, "only rank 0 drives the group"
+        # Everything that can fail is checked HERE, before the first broadcast: a request the library would refuse
+        # (k outside [1, VODHIP_MAX_K], more than 64 subset labels per query, a malformed batch) raises on rank 0 alone and
+        # becomes this request's HTTP 500 - the workers never see it and the collective sequence stays in step.
+        query_vec = np.asarray(query_vec)
+        if query_vec.ndim != 2:
+            raise ValueError(f"Expected 2D array, got {query_vec.ndim}D array")
+        top_k = int(top_k)
+        if not 1 <= top_k <= MAX_K:
+            raise ValueError(f"top_k={top_k} out of range [1, {MAX_K}]")
+        if self.dim is not None and query_vec.shape[1] != self.dim:
+            raise ValueError(f"query dimension {query_vec.shape[1]} != index dimension {self.dim}")
+        if subset is not None:
+            subset = np.asarray(subset)
+            if subset.ndim != 2 or subset.shape[0] != query_vec.shape[0]:
+                raise ValueError(f"expected subset labels of shape [{query_vec.shape[0]}, S], got {subset.shape}")
+            if not 1 <= subset.shape[1] <= MAX_SUBSET_LABELS:
+                raise ValueError(f"{subset.shape[1]} subset labels per query: the limit is {MAX_SUBSET_LABELS}")
+        if query_vec.shape[0] == 0:  # nothing to search: answered locally, no collective
+            return np.empty((0, top_k), dtype=np.float32), np.empty((0, top_k), dtype=np.int64)
         q = torch.from_numpy(np.ascontiguousarray(query_vec, dtype=np.float32)).to(self.device)
         sub = None
         if subset is not None:
@@ -73,5 +98,12 @@ class GroupDispatcher:
             if n_sub:
                 sub = torch.empty((nq, n_sub), dtype=torch.int32, device=self.device)
                 dist.broadcast(sub, 0, group=self.group)
-            self._local(q, k, sub)
+            try:
+                self._local(q, k, sub)
+            except Exception:  # noqa: BLE001
+                # rank 0 validated the request before broadcasting it, so what is left are argument errors that every
+                # rank raises alike BEFORE its collective (rank 0 turns its own into that request's HTTP 500): log and keep
+                # serving - one bad request must not take the group down
+                logging.getLogger(__name__).exception("rank %d: search failed; still serving", self.rank)
+                self.errors += 1
             served += 1

@@ -324,7 +324,18 @@ def run_owner(args: argparse.Namespace, argv: list[str]) -> int:
     procs = [subprocess.Popen([sys.executable, "-m", "vod_amd.search.server", *argv, "--rank", str(r), "--master-port", str(port)],
                               env=env, preexec_fn=_die_with_parent) for r in range(len(devices))]
 
+    state = {"stop_at": None}
+
     def _stop(*_):
+        # Orderly shutdown: only rank 0 is signalled.  Its uvicorn drains, then it broadcasts OP_STOP and the workers leave
+        # `worker_loop` on their own (terminating every rank at once left rank 0 broadcasting to dead peers: a hang under
+        # RCCL, an error exit under gloo).  Whoever is still alive after the grace period is terminated below.
+        if state["stop_at"] is None:
+            state["stop_at"] = time.monotonic() + 10.0
+            if procs[0].poll() is None:
+                procs[0].terminate()
+
+    def _kill_all():
         for p in procs:
             if p.poll() is None:
                 p.terminate()
@@ -333,11 +344,14 @@ def run_owner(args: argparse.Namespace, argv: list[str]) -> int:
     signal.signal(signal.SIGINT, _stop)
     rc = 0
     while any(p.poll() is None for p in procs):
-        time.sleep(0.1)
+        time.sleep(0.05)
+        if state["stop_at"] is not None and time.monotonic() > state["stop_at"]:
+            _kill_all()
+            state["stop_at"] = time.monotonic() + 5.0
         for p in procs:
-            if p.poll() not in (None, 0) and rc == 0:  # a worker died: the group cannot answer any more
+            if p.poll() not in (None, 0) and rc == 0 and state["stop_at"] is None:  # a worker died: the group cannot answer any more
                 rc = p.returncode if p.returncode > 0 else 1
-                _stop()
+                _kill_all()
     return rc
 
 
@@ -363,7 +377,8 @@ def run_worker(args: argparse.Namespace) -> None:
     local = HipEngine(args.vectors_path, dtype=args.dtype, device=devices[rank], subset_ids_path=args.subset_ids_path,
                       row_range=(bounds[rank], bounds[rank + 1]))
     sharded = ShardedFlatIndex(local.index, row_offset=bounds[rank], always_exchange=True)
-    dispatcher = GroupDispatcher(sharded, rank, world, dev if args.group_backend == "nccl" else torch.device("cpu"), search_device=dev)
+    dispatcher = GroupDispatcher(sharded, rank, world, dev if args.group_backend == "nccl" else torch.device("cpu"), search_device=dev,
+                                 dim=local.index.dim)
     dist.barrier()  # every shard is resident before rank 0 starts answering (the master's ping loop waits for that)
     if rank != 0:
         dispatcher.worker_loop()
@@ -373,8 +388,19 @@ def run_worker(args: argparse.Namespace) -> None:
             uvicorn.run(create_app(GroupHipEngine(local, dispatcher), micro_batch_wait_ms=args.micro_batch_wait_ms), host=host,
                         port=args.port, workers=1, log_level=args.logging_level.lower())
         finally:
-            dispatcher.stop()
-    dist.destroy_process_group()
+            _bounded(dispatcher.stop, 5.0)  # peers that already died (owner gone: PDEATHSIG reaches every rank) cannot hang the exit
+    _bounded(dist.destroy_process_group, 5.0)
+
+
+def _bounded(fn, seconds: float) -> None:
+    """Run a shutdown step that talks to the other ranks; if they are gone and it blocks, leave without it."""
+    import os
+
+    t = threading.Thread(target=fn, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        os._exit(0)
 
 
 def main(argv=None) -> None:
