@@ -480,7 +480,13 @@ def test_factory_port_is_resolved_once_for_all_ranks(tmp_path):
     assert m1.port == m0.port and m1.get_client().port == m0.port
     with pytest.raises(ValueError, match="resolve the port once"):
         factory.build_hip_mips_index(vecs, config=cfg, cache_dir=tmp_path, skip_setup=True)
-    assert factory.HipMipsFactoryConfig().port == 6637  # the reference's default (faiss_search/client.py:124)
+    # the CONFIG default is the reference config's -1 = "pick a free port" (src/vod_configs/search.py:134): two default-config
+    # indexes on one host do not collide; 6637 is only the master's constructor default (faiss_search/client.py:124)
+    assert factory.HipMipsFactoryConfig().port == -1
+    a = factory.build_hip_mips_index(vecs, cache_dir=tmp_path)
+    b = factory.build_hip_mips_index(vecs, cache_dir=tmp_path)
+    assert a.port > 0 and b.port > 0
+    assert vclient.HipMipsMaster(tmp_path / "v.npy", skip_setup=True).port == 6637
 
 
 def test_master_command_line_for_a_multi_gpu_group(tmp_path):
