@@ -351,7 +351,7 @@ def run_workload(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, 
         hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got_i, ref_i))
         verify = {
             "recall_at_k_vs_torch_fp32": hits / float(ref_i.numel()),
-            "rows_with_identical_ids": float((got_i[:, : ref_i.shape[1]] == ref_i).all(dim=1).float().mean()),
+            "rows_with_identical_id_order": float((got_i[:, : ref_i.shape[1]] == ref_i).all(dim=1).float().mean()),
             "max_abs_score_diff": float((fs[sample][:, : ls.shape[1]].cpu() - ls.cpu()).abs().max()),
             "queries_checked": len(sample),
         }

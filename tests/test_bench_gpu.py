@@ -148,7 +148,7 @@ def test_bench_two_ranks_only_one_shard_overflows_stays_collective_safe():
                      "--warmup", "1", "--data", "duplicates", "--no-cpu-baseline", "--verify-queries", "64")
     assert rec["n_gpus"] == 2 and rec["config"]["recovery_passes"] >= 4   # every step recovered on rank 1
     assert rec["verify"]["recall_at_k_vs_torch_fp32"] == 1.0
-    assert rec["verify"]["rows_with_identical_ids"] == 1.0
+    assert rec["verify"]["rows_with_identical_id_order"] == 1.0
     assert rec["verify"]["max_abs_score_diff"] < 1e-3
 
 

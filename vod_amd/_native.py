@@ -92,6 +92,11 @@ def load_library() -> ctypes.CDLL:
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C vod_amd/csrc`.  vod_amd has no CPU fallback."
             )
+        # PyTorch-ROCm ships its own libamdhip64.so.7 + libhsa-runtime64; libvodhip.so needs the same SONAME.  Whichever is
+        # loaded first serves both, and the system runtime loaded FIRST next to torch's HSA runtime finds no device
+        # ("no ROCm-capable device is detected"): make sure torch's copy is the one in the process.
+        import torch  # noqa: F401
+
         try:
             lib = ctypes.CDLL(str(path))
         except OSError as exc:  # pragma: no cover - depends on the machine
