@@ -125,6 +125,11 @@ int vodhip_index_set_param(vodhip_index_t* index, const char* key, int64_t value
 int vodhip_debug_schedule(int64_t ntotal, int k, int64_t nq, int64_t cand_cap, int64_t dense_rows, int64_t sample_div,
                           int64_t growth_x100, int tile, int recovery_pass, int n_cu, int64_t* out, int max_stages);
 int vodhip_index_get_stat(const vodhip_index_t* index, const char* key, int64_t* out);
+/* Diagnostic builds only (make ABLATION=1; production returns -1): phase stamps of workgroup 0 of the last launch of a
+ * collate-side kernel (which: 0 = hybrid merge, 1 = priority sampling, 2 = in-batch flattening) as 64 pairs
+ * (shader-clock cycles, 10 ns ticks of the constant 100 MHz counter), then the (begin, end) ticks of workgroups 0..63;
+ * out holds n >= 256 values. */
+int vodhip_debug_read_probe(int which, int64_t* out, int n);
 
 /* ---------------------------------------------------------------------------------------------
  * H3  merge of per-shard top-k lists (multi-GPU exchange step, after the RCCL all-gather).
@@ -150,9 +155,11 @@ int vodhip_merge_topk_strided(const float* scores, int64_t shard_stride_scores, 
  * All pointers are DEVICE pointers.  lookup_idx/lookup_lbl [nq, k_lookup] (lookup scores are discarded
  * by the reference, search.py:92).  engine e: idx[e] int64 [nq, k_e], scr[e] float32 [nq, k_e].
  * Outputs have `out_stride` = k_lookup + sum(k_e) + 1 columns allocated.  The reference cuts its buffer to
- * `[: max_cursor + 1]` after every pairwise fold (merge.py:160-162); out_width (device int32[VODHIP_MAX_ENGINES])
- * receives, per engine e, the maximum over rows of the cursor after engine e was folded in, from which the
+ * `[: max_cursor + 1]` after every pairwise fold (merge.py:160-162); out_width (device int32[VODHIP_MAX_ENGINES], may be
+ * NULL) receives, per engine e, the maximum over rows of the cursor after engine e was folded in, from which the
  * caller derives the reference's final width: W = k_lookup; for e: W = min(out_width[e] + 1, W + k_e).
+ * out_row_cursor (device int32 [nq, VODHIP_MAX_ENGINES], may be NULL) receives the same cursors per row with plain stores
+ * (no cleared buffer, no atomics: one launch): vodhip_priority_sample_merged takes the maximum itself.
  *   out_idx  int64  : union of ids in first-seen order, -1 padded
  *   out_scr  float32: sum_e w_e * (s_e - rowmin_e), -inf padded
  *   out_lbl  int64  : lookup label of the id, -1 if absent (pad column: see SURVEY quirk Q3)
@@ -163,7 +170,7 @@ int vodhip_merge_hybrid(const int64_t* lookup_idx, const int64_t* lookup_lbl, in
                         int n_engines, const int64_t* const* engine_idx, const float* const* engine_scr,
                         const int* engine_k, const float* engine_weight, int64_t nq,
                         int64_t* out_idx, float* out_scr, int64_t* out_lbl, float* const* out_raw,
-                        int out_stride, int32_t* out_width, void* stream);
+                        int out_stride, int32_t* out_width, int32_t* out_row_cursor, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * H5  in-batch retrieval scoring + log-prob / loss combination, forward and backward fused.
@@ -218,6 +225,25 @@ int vodhip_priority_sample(const float* scores, const uint8_t* labels, const flo
                            int64_t* out_samples, float* out_log_weights, uint8_t* out_labels, float* out_lse,
                            void* stream);
 
+/* The same sampling fed straight from vodhip_merge_hybrid's full-stride outputs, with the gathers and the rank diagnostic of
+ * sample_search_results (src/vod_dataloaders/core/sample.py:22-84) as an epilogue: the collate's merge -> sample chain stays on
+ * the device (reference flow src/vod_dataloaders/realm_collate.py:110-122).
+ * DEVICE pointers.  ids int64 / scores float32 / labels int64 (> 0 = positive; the merge's lookup labels) / raw[e] float32, all
+ * [nq, stride]; noise float32 rows of `noise_stride` elements.  `width` >= 0: the columns in use; `width` < 0: the reference's cut
+ * (merge.py:160-162) is derived ON THE DEVICE from merge_width (the merge's out_width) or merge_row_cursor (its out_row_cursor;
+ * one of the two), k_lookup and engine_k - no host sync between the two launches.  `raw` / `out_raw` are HOST arrays of n_raw (<= VODHIP_MAX_ENGINES) device pointers.
+ * Outputs [nq, k_total]: out_samples (column index, -1 pad), out_ids / out_scores / out_raw[e] = take_along_axis by the sampled
+ * columns (a -1 pad takes the LAST column in use, as NumPy does), out_log_weights, out_labels uint8; out_lse float32 [nq, 2];
+ * out_max_sampling_id float32 [nq] = number of finite negatives of the pool scoring >= the lowest sampled finite negative. */
+int vodhip_priority_sample_merged(const int64_t* ids, const float* scores, const int64_t* labels, int n_raw,
+                                  const float* const* raw, const float* noise, int64_t noise_stride, int64_t nq, int stride,
+                                  int width, const int32_t* merge_width, const int32_t* merge_row_cursor, int k_lookup,
+                                  int n_engines, const int* engine_k,
+                                  int k_positive, int k_total, float temperature, int max_support_size, int normalized,
+                                  int64_t* out_samples, int64_t* out_ids, float* out_scores, float* out_log_weights,
+                                  uint8_t* out_labels, float* const* out_raw, float* out_lse, float* out_max_sampling_id,
+                                  void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Gather by id: flattening of the sampled sections of a batch into ONE in-batch section set.
  * Replaces: gather_values_by_indices / gather_values_2d / _nopy_gather_values_{1d,2d}
@@ -231,6 +257,66 @@ int vodhip_priority_sample(const float* scores, const uint8_t* labels, const flo
  * ------------------------------------------------------------------------------------------- */
 int vodhip_gather_by_id(const int64_t* queries, int64_t n_queries, const int64_t* keys, int64_t n_rows, int n_keys,
                         int n_values, const float* const* values, const float* fill, float* const* outs, void* stream);
+
+/* flatten_samples (src/vod_dataloaders/core/in_batch_negatives.py:10-52) in ONE launch: the sorted distinct ids of the whole
+ * [n_rows, n_keys] batch, padded to U = n_rows * n_keys entries with the reference's constant 1 (out_unique int64 [U];
+ * *out_n_unique = number of distinct ids, may be NULL), and every value array gathered onto that list (outs[v] float32
+ * [n_rows, U], first occurrence wins, fill[v] where the row does not hold the id).  `labels` uint8 [n_rows, n_keys] (non-zero =
+ * positive; may be NULL) is gathered the same way into out_labels uint8 [n_rows, U] with the reference's fill 0.
+ * DEVICE pointers; `values` / `outs` HOST arrays of n_values (<= 8) device pointers; U <= 8192. */
+int vodhip_flatten_inbatch(const int64_t* ids, int64_t n_rows, int n_keys, int n_values, const float* const* values,
+                           const float* fill, float* const* outs, const uint8_t* labels, uint8_t* out_labels,
+                           int64_t* out_unique, int32_t* out_n_unique, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The collate-side chain in ONE call: hybrid merge -> labeled priority sampling (+ gathers, rank diagnostic) -> optional
+ * in-batch flattening = the three launches above enqueued back to back on `stream`, no host synchronisation.
+ * Replaces the sequence RealmCollate.__call__ runs on the host (src/vod_dataloaders/realm_collate.py:110-139):
+ *   _merge_search_results (core/search.py:79-125) -> sample_search_results (core/sample.py:22-84) -> flatten_samples
+ *   (core/in_batch_negatives.py:10-52).
+ * Every pointer is a DEVICE pointer owned by the caller.  stride = k_lookup + sum(engine_k) + 1 (n_engines >= 1).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vodhip_collate_args {
+    /* the three engines' replies (core/search.py:42-62) */
+    const int64_t* lookup_idx;                        /* [nq, k_lookup] */
+    const int64_t* lookup_lbl;                        /* [nq, k_lookup] or NULL */
+    const int64_t* engine_idx[VODHIP_MAX_ENGINES];    /* [nq, engine_k[e]] */
+    const float* engine_scr[VODHIP_MAX_ENGINES];      /* [nq, engine_k[e]] */
+    float engine_weight[VODHIP_MAX_ENGINES];
+    int32_t engine_k[VODHIP_MAX_ENGINES];
+    int32_t k_lookup, n_engines;
+    int64_t nq;
+    const float* noise;                               /* Exp(1) draws, rows of noise_stride >= stride elements (sample.py:398) */
+    int64_t noise_stride;
+    /* sampling parameters (sample_search_results' arguments) */
+    int32_t k_positive, k_total, max_support_size, in_batch_negatives;
+    float temperature;
+    int32_t reserved;
+    /* workspace: the merged rows at full stride (also an output: what _merge_search_results returns, uncut) */
+    int64_t* merged_idx;                              /* [nq, stride] */
+    int64_t* merged_lbl;                              /* [nq, stride] */
+    float* merged_scr;                                /* [nq, stride] */
+    float* merged_raw[VODHIP_MAX_ENGINES];            /* [nq, stride] each */
+    int32_t* row_cursor;                              /* [nq, VODHIP_MAX_ENGINES] */
+    /* sampled sections [nq, k_total] */
+    int64_t* out_local;                               /* column of the merged row, -1 pad */
+    int64_t* out_ids;
+    float* out_scores;
+    float* out_log_weights;
+    uint8_t* out_labels;
+    float* out_raw[VODHIP_MAX_ENGINES];
+    float* out_lse_pos;                               /* [nq] */
+    float* out_lse_neg;                               /* [nq] */
+    float* out_max_sampling_id;                       /* [nq] */
+    /* flattened batch (in_batch_negatives != 0): U = nq * k_total <= 8192 */
+    int64_t* flat_ids;                                /* [U] */
+    float* flat_scores;                               /* [nq, U] */
+    float* flat_log_weights;                          /* [nq, U] */
+    uint8_t* flat_labels;                             /* [nq, U] */
+    float* flat_raw[VODHIP_MAX_ENGINES];              /* [nq, U] each */
+    int32_t* flat_n_unique;                           /* [1] or NULL */
+} vodhip_collate_args_t;
+int vodhip_collate(const vodhip_collate_args_t* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Wire codec helper (HOST memory, no device work): urlsafe base64 of `head || data` and back.

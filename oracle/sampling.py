@@ -1,12 +1,13 @@
 """Oracle (test infrastructure): CPU restatement of the reference's labeled priority sampling.
 
-Pinned by `sampling_fixed_noise.npz` / `flatten_inbatch.npz` (produced by running the reference).
+Pinned by `sampling_fixed_noise.npz` / `flatten_inbatch.npz` / `collate_chain.npz` (produced by running the reference).
 
 Follows (paths relative to /root/reference/src/vod_dataloaders/core):
   * `log_softmax_1d_`, `max_1d`, `_logsumexp_1d`   numpy_ops.py:162-216
   * `_priority_sampling_1d`                         sample.py:160-219
   * `_labeled_priority_sampling_1d_`                sample.py:245-320
   * `flatten_samples`                               in_batch_negatives.py:10-52
+  * `sample_search_results`                         sample.py:22-84 (with the Exp(1) draw passed in: sample.py:398)
 
 Reference behaviours kept on purpose: Q8 -- support truncation masks the entries
 `>= threshold` (it REMOVES the top `max_support_size` entries), and the "not enough positives"
@@ -112,4 +113,26 @@ def flatten_samples(indices, scores, labels, log_weights, raw_scores: dict, padd
         "labels": gather_values(uq, indices, labels, fill_value=0),
         "log_weights": gather_values(uq, indices, log_weights),
         "raw": {k: gather_values(uq, indices, v) for k, v in raw_scores.items()},
+    }
+
+
+def sample_search_results(indices, scores, labels, raw_scores: dict, noise, total, max_pos_sections, temperature=1.0, max_support_size=None):
+    """sample.py:22-84 with the noise of sample.py:398 passed in.  Returns a dict of the `PrioritySampledSections` fields."""
+    total = total or scores.shape[-1]
+    max_pos_sections = max_pos_sections or total
+    labels_ref = np.zeros_like(scores, dtype=np.bool_) if labels is None else labels > 0
+    max_support_size = max_support_size or -1          # sample.py:123-128
+    if max_support_size >= 0:
+        max_support_size = max(max_support_size, total)
+    with np.errstate(all="ignore"):
+        local, logw, lab, lse = labeled_priority_sampling_2d(scores, labels_ref, noise, max_pos_sections, total, True, temperature,
+                                                             max_support_size)
+    take = lambda a: np.take_along_axis(a, local, axis=-1)  # noqa: E731  (-1 pads take the LAST column, as NumPy indexes)
+    smp_scores = take(scores)
+    min_neg = np.amin(np.where((lab <= 0) & np.isfinite(smp_scores), smp_scores, np.inf), axis=-1, keepdims=True)
+    larger = (labels_ref <= 0) & np.isfinite(scores) & (scores >= min_neg)
+    return {
+        "local": local, "indices": take(indices), "scores": smp_scores, "labels": lab, "log_weights": logw,
+        "lse_pos": lse[..., 0], "lse_neg": lse[..., 1], "max_sampling_id": np.sum(larger.astype(np.float32), axis=-1),
+        "raw": {k: take(v) for k, v in raw_scores.items()},
     }

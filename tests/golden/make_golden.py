@@ -14,6 +14,7 @@ The reference functions exercised (paths relative to /root/reference/src):
   gather       vod_dataloaders/core/numpy_ops.py:126-143 (gather_values_by_indices)
   sampling     vod_dataloaders/core/sample.py:323-352 (_labeled_priority_sampling_2d_)
   flatten      vod_dataloaders/core/in_batch_negatives.py:10-52
+  collate      merge -> vod_dataloaders/core/sample.py:22-84 (sample_search_results) -> flatten, chained as realm_collate.py:110-139
   shard        vod_search/sharded_search.py:65-106,176-203
   stack        vod_types/retrieval.py:259-287
   io           vod_search/io.py:17-32
@@ -303,6 +304,50 @@ def gen_sampling() -> None:
 
 
 # ----------------------------------------------------------------------------------------
+# the collate chain end to end: merge -> sample_search_results -> flatten_samples (realm_collate.py:110-139)
+# ----------------------------------------------------------------------------------------
+def gen_collate_chain() -> None:
+    """The reference's own three functions chained as `RealmCollate.__call__` chains them, with `np.random` seeded so that
+    the Exp(1) draw inside `labeled_priority_sampling` (sample.py:398) is reproducible: the fixture stores that draw
+    (`noise`, re-drawn with the same seed and shape) next to every intermediate and final array."""
+    smp = M["sample"]
+    cases = [
+        # nq, k per engine, id pool, pad_frac, overlap, total, max_pos, temperature, support, weights
+        (6, 16, 60, 0.3, 0.4, 8, 2, 1.0, None, {"dense": 1.0, "sparse": 0.5}),
+        (5, 24, 40, 0.2, 0.6, 16, 4, 0.0, None, {"dense": 1.0, "sparse": 1.0}),
+        (12, 128, 3000, 0.1, 0.3, 32, 8, 1.0, 100, {"dense": 1.0, "sparse": 1.0}),   # shipped training shape (C5): W ~ 385, support 100
+        (4, 12, 30, 0.5, 0.5, 48, 6, 1.0, None, {"dense": 0.0, "sparse": 1.0}),      # fewer candidates than `total`
+    ]
+    params = []
+    arrays = {}
+    for c, (nq, kk, n_ids, pad_frac, overlap, total, max_pos, temp, support, weights) in enumerate(cases):
+        rng = np.random.default_rng(900 + c)
+        lookup, dense, sparse = _hybrid_case(rng, nq, kk, n_ids, pad_frac, overlap)
+        with np.errstate(all="ignore"):
+            merged, raw = _run_hybrid(lookup, dense, sparse, weights)
+            seed = 4000 + c
+            np.random.seed(seed)
+            noise = np.random.exponential(size=merged.scores.shape).astype(merged.scores.dtype)
+            np.random.seed(seed)
+            sampled = smp.sample_search_results(search_results=merged, raw_scores=raw, total=total, max_pos_sections=max_pos,
+                                                temperature=temp, max_support_size=support)
+            flat = M["in_batch_negatives"].flatten_samples(sampled, padding=True)
+        arrays.update({
+            f"l_idx_{c}": lookup[0], f"l_lbl_{c}": lookup[2], f"d_idx_{c}": dense[0], f"d_scr_{c}": dense[1],
+            f"s_idx_{c}": sparse[0], f"s_scr_{c}": sparse[1], f"noise_{c}": noise,
+            f"m_idx_{c}": merged.indices, f"m_scr_{c}": merged.scores, f"m_lbl_{c}": merged.labels,
+            f"smp_idx_{c}": sampled.batch.indices, f"smp_scr_{c}": sampled.batch.scores, f"smp_lbl_{c}": sampled.batch.labels,
+            f"smp_logw_{c}": sampled.log_weights, f"smp_lse_pos_{c}": sampled.lse_pos, f"smp_lse_neg_{c}": sampled.lse_neg,
+            f"smp_max_id_{c}": sampled.max_sampling_id, f"smp_dense_{c}": sampled.raw_scores["dense"], f"smp_sparse_{c}": sampled.raw_scores["sparse"],
+            f"flat_idx_{c}": flat.batch.indices, f"flat_scr_{c}": flat.batch.scores, f"flat_lbl_{c}": flat.batch.labels,
+            f"flat_logw_{c}": flat.log_weights, f"flat_dense_{c}": flat.raw_scores["dense"], f"flat_sparse_{c}": flat.raw_scores["sparse"],
+        })
+        params.append({"total": total, "max_pos_sections": max_pos, "temperature": temp, "max_support_size": support, "weights": weights,
+                       "seed": seed})
+    _save("collate_chain", {"cases": params}, **arrays)
+
+
+# ----------------------------------------------------------------------------------------
 def gen_search_plumbing() -> None:
     ss = M["sharded_search"]
     base = M["base"]
@@ -468,6 +513,11 @@ if __name__ == "__main__":
         gen_gradients_aux()
         (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True))
         raise SystemExit(0)
+    if sys.argv[1:] == ["collate_chain"]:
+        manifest.update(json.loads((HERE / "manifest.json").read_text()))
+        gen_collate_chain()
+        (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True))
+        raise SystemExit(0)
     if sys.argv[1:] == ["merge_corners"]:
         manifest.update(json.loads((HERE / "manifest.json").read_text()))
         gen_merge_corners()
@@ -478,6 +528,7 @@ if __name__ == "__main__":
     gen_normalize()
     gen_gather()
     gen_sampling()
+    gen_collate_chain()
     gen_search_plumbing()
     gen_gradients()
     gen_gradients_aux()

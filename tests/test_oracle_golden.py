@@ -270,3 +270,43 @@ def test_c_restatement_agrees_with_the_numpy_oracle(n, d, nq, k, id_base):
     rs, ri = flat_ip_topk(q, x, k, id_base=id_base)
     _eq(i, ri)
     _eq(s, rs)
+
+
+def test_collate_chain_matches_reference():
+    """merge -> sample_search_results -> flatten_samples, the chain `RealmCollate.__call__` runs (realm_collate.py:110-139),
+    restated by the oracle and compared with what the reference's own functions produced for the same inputs and the same
+    Exp(1) draw: ids / labels / -inf / NaN positions exact, float32 weights to 2e-5 (sequential vs NumPy summation order)."""
+    from oracle.hybrid import merge_hybrid
+
+    g = _load("collate_chain")
+    for c, p in enumerate(MANIFEST["collate_chain"]["params"]["cases"]):
+        lookup = (g[f"l_idx_{c}"], np.zeros(g[f"l_idx_{c}"].shape, np.float32), g[f"l_lbl_{c}"])
+        m_idx, m_scr, m_lbl, m_raw = merge_hybrid(lookup, {"dense": (g[f"d_idx_{c}"], g[f"d_scr_{c}"]), "sparse": (g[f"s_idx_{c}"], g[f"s_scr_{c}"])},
+                                                  p["weights"])
+        np.testing.assert_array_equal(m_idx, g[f"m_idx_{c}"])
+        np.testing.assert_array_equal(m_scr, g[f"m_scr_{c}"])
+        np.testing.assert_array_equal(m_lbl, g[f"m_lbl_{c}"])
+        out = osmp.sample_search_results(m_idx, m_scr, m_lbl, m_raw, g[f"noise_{c}"], p["total"], p["max_pos_sections"], p["temperature"],
+                                         p["max_support_size"])
+        fin = np.isfinite(g[f"smp_logw_{c}"])
+        np.testing.assert_array_equal(out["indices"][fin], g[f"smp_idx_{c}"][fin])
+        np.testing.assert_array_equal(out["labels"], g[f"smp_lbl_{c}"])
+        np.testing.assert_array_equal(out["scores"][fin], g[f"smp_scr_{c}"][fin])
+        np.testing.assert_array_equal(np.isfinite(out["log_weights"]), fin)
+        np.testing.assert_allclose(out["log_weights"][fin], g[f"smp_logw_{c}"][fin], rtol=2e-5, atol=2e-5)
+        for key, ref in (("lse_pos", g[f"smp_lse_pos_{c}"]), ("lse_neg", g[f"smp_lse_neg_{c}"])):
+            both = np.isfinite(ref)
+            np.testing.assert_array_equal(np.isfinite(out[key]), both)
+            np.testing.assert_allclose(out[key][both], ref[both], rtol=2e-5, atol=2e-5)
+        np.testing.assert_array_equal(out["max_sampling_id"], g[f"smp_max_id_{c}"])
+        np.testing.assert_array_equal(out["raw"]["dense"][fin], g[f"smp_dense_{c}"][fin])
+        np.testing.assert_array_equal(out["raw"]["sparse"][fin], g[f"smp_sparse_{c}"][fin])
+        # the flattening of the REFERENCE's sampled sections (exact inputs -> exact outputs)
+        flat = osmp.flatten_samples(g[f"smp_idx_{c}"], g[f"smp_scr_{c}"], g[f"smp_lbl_{c}"], g[f"smp_logw_{c}"],
+                                    {"dense": g[f"smp_dense_{c}"], "sparse": g[f"smp_sparse_{c}"]})
+        np.testing.assert_array_equal(flat["indices"], g[f"flat_idx_{c}"])
+        np.testing.assert_array_equal(flat["scores"], g[f"flat_scr_{c}"])
+        np.testing.assert_array_equal(flat["labels"], g[f"flat_lbl_{c}"])
+        np.testing.assert_array_equal(flat["log_weights"], g[f"flat_logw_{c}"])
+        np.testing.assert_array_equal(flat["raw"]["dense"], g[f"flat_dense_{c}"])
+        np.testing.assert_array_equal(flat["raw"]["sparse"], g[f"flat_sparse_{c}"])

@@ -56,12 +56,13 @@ SIGNATURES: dict[str, tuple] = {
     "vodhip_index_set_param": (_i32, [_vp, _c.c_char_p, _i64]),
     "vodhip_debug_schedule": (_i32, [_i64, _i32, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _c.POINTER(_i64), _i32]),
     "vodhip_index_get_stat": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i64)]),
+    "vodhip_debug_read_probe": (_i32, [_i32, _c.POINTER(_i64), _i32]),
     "vodhip_merge_topk": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "vodhip_merge_topk_strided": (_i32, [_vp, _i64, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "vodhip_merge_hybrid": (
         _i32,
         [_vp, _vp, _i32, _i32, _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_i32), _c.POINTER(_c.c_float), _i64,
-         _vp, _vp, _vp, _c.POINTER(_vp), _i32, _vp, _vp],
+         _vp, _vp, _vp, _c.POINTER(_vp), _i32, _vp, _vp, _vp],
     ),
     "vodhip_retrieval_forward": (
         _i32, [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -73,11 +74,37 @@ SIGNATURES: dict[str, tuple] = {
     "vodhip_priority_sample": (
         _i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _c.c_float, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     ),
+    "vodhip_priority_sample_merged": (
+        _i32, [_vp, _vp, _vp, _i32, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _c.c_float, _i32, _i32,
+               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    ),
+    "vodhip_collate": (_i32, [_vp, _vp]),
+    "vodhip_flatten_inbatch": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vodhip_retrieval_backward": (_i32, [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "vodhip_gather_by_id": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vodhip_b64url_encode": (_i64, [_vp, _i64, _vp, _i64, _vp]),
     "vodhip_b64url_decode": (_i64, [_vp, _i64, _vp]),
 }
+
+
+class CollateArgs(ctypes.Structure):
+    """`vodhip_collate_args_t` (include/vodhip.h), field for field."""
+
+    _fields_ = [
+        ("lookup_idx", _vp), ("lookup_lbl", _vp),
+        ("engine_idx", _vp * MAX_ENGINES), ("engine_scr", _vp * MAX_ENGINES),
+        ("engine_weight", _c.c_float * MAX_ENGINES), ("engine_k", _c.c_int32 * MAX_ENGINES),
+        ("k_lookup", _c.c_int32), ("n_engines", _c.c_int32),
+        ("nq", _i64),
+        ("noise", _vp), ("noise_stride", _i64),
+        ("k_positive", _c.c_int32), ("k_total", _c.c_int32), ("max_support_size", _c.c_int32), ("in_batch_negatives", _c.c_int32),
+        ("temperature", _c.c_float), ("reserved", _c.c_int32),
+        ("merged_idx", _vp), ("merged_lbl", _vp), ("merged_scr", _vp), ("merged_raw", _vp * MAX_ENGINES), ("row_cursor", _vp),
+        ("out_local", _vp), ("out_ids", _vp), ("out_scores", _vp), ("out_log_weights", _vp), ("out_labels", _vp),
+        ("out_raw", _vp * MAX_ENGINES), ("out_lse_pos", _vp), ("out_lse_neg", _vp), ("out_max_sampling_id", _vp),
+        ("flat_ids", _vp), ("flat_scores", _vp), ("flat_log_weights", _vp), ("flat_labels", _vp), ("flat_raw", _vp * MAX_ENGINES),
+        ("flat_n_unique", _vp),
+    ]
 
 
 def load_library() -> ctypes.CDLL:
@@ -142,4 +169,10 @@ def numpy_dtype_code(dtype) -> int:
 def current_stream_ptr(device=None) -> int:
     import torch
 
-    return int(torch.cuda.current_stream(device).cuda_stream)
+    if device is None:
+        return int(torch.cuda.current_stream().cuda_stream)
+    idx = device if isinstance(device, int) else device.index
+    try:  # the raw handle without building a Stream object (this sits on the launch path of latency-bound kernels)
+        return int(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx))
+    except AttributeError:  # pragma: no cover - private API absent
+        return int(torch.cuda.current_stream(device).cuda_stream)

@@ -52,6 +52,8 @@ def flatten_samples(samples: PrioritySampledSections, padding: bool = True, devi
     if samples.batch.labels is None:
         raise ValueError("The `search_results` must have labels.")
     dev = torch.device("cuda", device)
+    if 0 < samples.batch.indices.size <= 8192 and len(samples.raw_scores) <= 5 and samples.batch.indices.ndim == 2:
+        return _flatten_one_launch(samples, padding, dev)
     indices = torch.from_numpy(np.ascontiguousarray(samples.batch.indices)).to(dev)
     unique = torch.unique(indices)  # sorted, like np.unique
     if padding:
@@ -76,6 +78,37 @@ def flatten_samples(samples: PrioritySampledSections, padding: bool = True, devi
         max_sampling_id=samples.max_sampling_id,
         raw_scores={k: host[k].astype(np.asarray(samples.raw_scores[k]).dtype, copy=False) for k in samples.raw_scores},
         log_weights=host["log_weights"].astype(np.asarray(samples.log_weights).dtype, copy=False),
+        lse_pos=samples.lse_pos,
+        lse_neg=samples.lse_neg,
+    )
+
+
+def _flatten_one_launch(samples: PrioritySampledSections, padding: bool, dev: torch.device) -> PrioritySampledSections:
+    """The whole flattening (distinct ids + padding + every gather) in one launch of `vodhip_flatten_inbatch`."""
+    from vod_amd.core.collate import DeviceSampledSections, flatten_on_device
+
+    up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)  # noqa: E731
+    B = samples.batch.indices.shape[0]
+    zero = torch.zeros((B,), dtype=torch.float32, device=dev)
+    # label VALUES (the reference gathers whatever dtype the labels have, fill 0) travel as one more float array
+    flat = flatten_on_device(DeviceSampledSections(
+        indices=up(samples.batch.indices, np.int64), scores=up(samples.batch.scores, np.float32), labels=up(samples.batch.labels != 0, np.bool_),
+        log_weights=up(samples.log_weights, np.float32), lse_pos=zero, lse_neg=zero, max_sampling_id=zero,
+        raw_scores={**{k: up(v, np.float32) for k, v in samples.raw_scores.items()}, "__label_values__": up(samples.batch.labels, np.float32)},
+    ))
+    n = None if padding else int(flat.n_unique.item())
+    host = lambda t: t[..., :n].cpu().numpy()  # noqa: E731
+    label_values = np.nan_to_num(host(flat.raw_scores.pop("__label_values__")), nan=0.0)
+    return PrioritySampledSections(
+        batch=vt.RetrievalBatch(
+            indices=host(flat.indices).astype(samples.batch.indices.dtype, copy=False),
+            scores=host(flat.scores).astype(samples.batch.scores.dtype, copy=False),
+            labels=label_values.astype(samples.batch.labels.dtype),
+            allow_unsafe=True,
+        ),
+        max_sampling_id=samples.max_sampling_id,
+        raw_scores={k: host(flat.raw_scores[k]).astype(np.asarray(samples.raw_scores[k]).dtype, copy=False) for k in samples.raw_scores},
+        log_weights=host(flat.log_weights).astype(np.asarray(samples.log_weights).dtype, copy=False),
         lse_pos=samples.lse_pos,
         lse_neg=samples.lse_neg,
     )

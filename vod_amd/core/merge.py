@@ -10,6 +10,7 @@ absent), raw per-engine scores min-subtracted with NaN for "not returned by this
 from __future__ import annotations
 
 import ctypes
+import dataclasses
 
 import numpy as np
 import torch
@@ -17,20 +18,55 @@ import torch
 from vod_amd import _native
 
 
-def merge_hybrid_tensors(
+@dataclasses.dataclass
+class MergedOnDevice:
+    """`vodhip_merge_hybrid`'s outputs as they lie in HBM: full-stride rows + the per-stage cursor maxima.
+
+    The reference cuts its buffer to `[: max_cursor + 1]` after every pairwise fold (merge.py:160-162); that width is a
+    function of `stage_max` (device int32) and the static engine widths.  Consumers on the device
+    (`vodhip_priority_sample_merged`) derive it there; `width()` reads it back (a host sync) for the NumPy wrappers."""
+
+    indices: torch.Tensor                 # int64 [nq, stride]
+    scores: torch.Tensor                  # float32 [nq, stride]
+    labels: torch.Tensor | None           # int64 [nq, stride]
+    raw: dict[str, torch.Tensor]          # float32 [nq, stride] per scored engine
+    stage_max: torch.Tensor | None        # int32 [MAX_ENGINES] cursor maxima over rows, or None
+    k_lookup: int
+    engine_k: list[int]
+    row_cursor: torch.Tensor | None = None  # int32 [nq, MAX_ENGINES] cursors per row (the consumer takes the maximum), or None
+
+    @property
+    def stride(self) -> int:
+        return int(self.indices.shape[1])
+
+    def width(self) -> int:
+        if self.stage_max is None and self.row_cursor is None:
+            return self.k_lookup
+        maxima = (self.stage_max if self.stage_max is not None else self.row_cursor.amax(dim=0)).tolist()
+        w = self.k_lookup
+        for k_e, m in zip(self.engine_k, maxima):
+            w = min(m + 1, w + k_e)
+        return w
+
+    def cut(self) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None, dict[str, torch.Tensor]]:
+        w = self.width()
+        return (self.indices[:, :w], self.scores[:, :w], None if self.labels is None else self.labels[:, :w],
+                {n: t[:, :w] for n, t in self.raw.items()})
+
+
+def merge_hybrid_device(
     lookup_idx: torch.Tensor,
     lookup_lbl: torch.Tensor | None,
     engines: dict[str, tuple[torch.Tensor, torch.Tensor]],
     weights: dict[str, float],
-) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None, dict[str, torch.Tensor]]:
-    """Device-tensor API.  lookup_idx int64 [nq, kl]; engines[name] = (idx int64 [nq, k], scores f32 [nq, k]).
+) -> MergedOnDevice:
+    """Device-tensor API without any host synchronisation: ONE launch, outputs left at full stride.
 
-    Returns (indices, scores, labels, raw_scores) already cut to the reference's width.
-    """
+    lookup_idx int64 [nq, kl]; engines[name] = (idx int64 [nq, k], scores f32 [nq, k])."""
     lib = _native.load_library()
     dev = lookup_idx.device
     if dev.type != "cuda":
-        raise _native.NativeLibraryError("merge_hybrid_tensors needs device tensors (there is no CPU path)")
+        raise _native.NativeLibraryError("merge_hybrid_device needs device tensors (there is no CPU path)")
     names = list(engines)
     if len(names) > _native.MAX_ENGINES:
         raise ValueError(f"at most {_native.MAX_ENGINES} scored engines are supported, got {len(names)}")
@@ -38,7 +74,7 @@ def merge_hybrid_tensors(
     if not names:
         # a single result set is returned as is, weighted (merge.py:18-22): no union, no pad column
         zeros = torch.zeros((nq, kl), dtype=torch.float32, device=dev)
-        return lookup_idx, zeros, lookup_lbl, {}
+        return MergedOnDevice(lookup_idx, zeros, lookup_lbl, {}, None, int(kl), [])
     lookup_idx = lookup_idx.contiguous().long()
     if lookup_lbl is not None:
         lookup_lbl = lookup_lbl.contiguous().long()
@@ -53,7 +89,10 @@ def merge_hybrid_tensors(
     out_scr = torch.empty((nq, stride), dtype=torch.float32, device=dev)
     out_lbl = torch.empty((nq, stride), dtype=torch.int64, device=dev) if lookup_lbl is not None else None
     out_raw = [torch.empty((nq, stride), dtype=torch.float32, device=dev) for _ in names]
-    width = torch.zeros((_native.MAX_ENGINES,), dtype=torch.int32, device=dev)
+    # the per-stage cursors that fix the reference's cut width: per row (plain stores, ONE launch; the sampling kernel takes
+    # the maximum) - or, for very tall batches, the maxima themselves (cleared by the library on the stream + atomics)
+    per_row = nq <= 4096
+    cursors = torch.empty((nq, _native.MAX_ENGINES) if per_row else (_native.MAX_ENGINES,), dtype=torch.int32, device=dev)
 
     n_e = len(names)
     VP = ctypes.c_void_p
@@ -68,16 +107,24 @@ def merge_hybrid_tensors(
                 lookup_idx.data_ptr(), lookup_lbl.data_ptr() if lookup_lbl is not None else None, kl, n_e,
                 arr_idx, arr_scr, arr_k, arr_w, nq,
                 out_idx.data_ptr(), out_scr.data_ptr(), out_lbl.data_ptr() if out_lbl is not None else None,
-                arr_raw, stride, width.data_ptr(), _native.current_stream_ptr(dev),
+                arr_raw, stride, None if per_row else cursors.data_ptr(), cursors.data_ptr() if per_row else None,
+                _native.current_stream_ptr(dev),
             )
         )
-    # the reference truncates to `max_cursor + 1` after every pairwise fold (merge.py:160-162)
-    stage_max = width.tolist()
-    w = kl
-    for e in range(n_e):
-        w = min(stage_max[e] + 1, w + ks[e])
-    raw = {n: t[:, :w] for n, t in zip(names, out_raw)}
-    return out_idx[:, :w], out_scr[:, :w], (out_lbl[:, :w] if out_lbl is not None else None), raw
+    return MergedOnDevice(out_idx, out_scr, out_lbl, dict(zip(names, out_raw)), None if per_row else cursors, int(kl), ks,
+                          cursors if per_row else None)
+
+
+def merge_hybrid_tensors(
+    lookup_idx: torch.Tensor,
+    lookup_lbl: torch.Tensor | None,
+    engines: dict[str, tuple[torch.Tensor, torch.Tensor]],
+    weights: dict[str, float],
+) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor | None, dict[str, torch.Tensor]]:
+    """Device-tensor API.  Returns (indices, scores, labels, raw_scores) already cut to the reference's width
+    (`[: max_cursor + 1]` after every pairwise fold, merge.py:160-162): reading the width back is one host sync -
+    `merge_hybrid_device` / `vod_amd.core.collate.collate_on_device` avoid it."""
+    return merge_hybrid_device(lookup_idx, lookup_lbl, engines, weights).cut()
 
 
 def merge_hybrid(

@@ -76,37 +76,37 @@ def sample_search_results(
     device: int = 0,
 ) -> PrioritySampledSections:
     """Sample positive and negative sections with per-label priority sampling (sample.py:22-84)."""
+    from vod_amd.core.collate import sample_merged_on_device
+    from vod_amd.core.merge import MergedOnDevice
+
     total = total or search_results.shape[-1]
     max_pos_sections = max_pos_sections or total
     dev = torch.device("cuda", device)
     scores_ref = np.ascontiguousarray(search_results.scores, dtype=np.float32)
-    indices_ref = search_results.indices
-    labels_ref = np.zeros_like(scores_ref, dtype=np.bool_) if search_results.labels is None else search_results.labels > 0
-    noise = np.random.exponential(size=scores_ref.shape).astype(scores_ref.dtype)  # same draw as the reference
-    t_scores = torch.from_numpy(scores_ref).to(dev)
-    local, logw, labels, lse = labeled_priority_sampling_tensors(
-        t_scores, torch.from_numpy(labels_ref).to(dev), torch.from_numpy(noise).to(dev), max_pos_sections, total,
-        normalized=True, temperature=temperature, max_support_size=max_support_size,
+    nq, width = scores_ref.shape
+    if width > 4096 or total > 4096:
+        raise ValueError(f"{width} candidates / {total} samples per row: the sampling kernel holds at most 4096")
+    if nq == 0 or width == 0:
+        raise ValueError("cannot sample from an empty candidate pool")
+    labels_ref = np.zeros(scores_ref.shape, dtype=np.int64) if search_results.labels is None else (search_results.labels > 0).astype(np.int64)
+    noise = np.random.exponential(size=scores_ref.shape).astype(scores_ref.dtype)  # same draw as the reference (sample.py:398)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    # ONE launch: selection + take_along_axis of ids / scores / raw scores + the rank diagnostic (sample.py:52-70)
+    merged = MergedOnDevice(
+        indices=up(search_results.indices.astype(np.int64, copy=False)), scores=up(scores_ref), labels=up(labels_ref),
+        raw={k: up(np.asarray(v, dtype=np.float32)) for k, v in raw_scores.items()}, stage_max=None, k_lookup=width, engine_k=[],
     )
-    width = scores_ref.shape[1]
-    gidx = torch.where(local < 0, local + width, local)  # np.take_along_axis semantics for the -1 pads (last column)
-    take = lambda a: torch.gather(torch.from_numpy(np.ascontiguousarray(a)).to(dev), 1, gidx)  # noqa: E731
-    indices = take(indices_ref)
-    scores = torch.gather(t_scores, 1, gidx)
-    sampled_raw = {k: take(v).cpu().numpy() for k, v in raw_scores.items()}
-    # rank diagnostic (sample.py:64-70): negatives of the pool scoring at least the lowest sampled finite negative
-    neg_finite = (~labels) & torch.isfinite(scores)
-    min_neg = torch.where(neg_finite, scores, torch.full_like(scores, float("inf"))).amin(dim=-1, keepdim=True)
-    t_labels_ref = torch.from_numpy(labels_ref).to(dev)
-    larger = (~t_labels_ref) & torch.isfinite(t_scores) & (t_scores >= min_neg)
-    max_sampling_id = larger.float().sum(dim=-1)
+    out = sample_merged_on_device(merged, up(noise), total=total, max_pos_sections=max_pos_sections, temperature=temperature,
+                                  max_support_size=max_support_size, width=width)
+    host = lambda t: t.cpu().numpy()  # noqa: E731
     return PrioritySampledSections(
-        batch=vt.RetrievalBatch(indices=indices.cpu().numpy(), scores=scores.cpu().numpy(), labels=labels.cpu().numpy()),
-        max_sampling_id=max_sampling_id.cpu().numpy(),
-        lse_pos=lse[:, 0].cpu().numpy(),
-        lse_neg=lse[:, 1].cpu().numpy(),
-        log_weights=logw.cpu().numpy(),
-        raw_scores=sampled_raw,
+        batch=vt.RetrievalBatch(indices=host(out.indices).astype(search_results.indices.dtype, copy=False), scores=host(out.scores),
+                                labels=host(out.labels)),
+        max_sampling_id=host(out.max_sampling_id),
+        lse_pos=host(out.lse_pos),
+        lse_neg=host(out.lse_neg),
+        log_weights=host(out.log_weights),
+        raw_scores={k: host(v).astype(np.asarray(raw_scores[k]).dtype, copy=False) for k, v in out.raw_scores.items()},
     )
 
 

@@ -743,7 +743,7 @@ int vodhip_merge_topk_strided(const float* scores, int64_t shard_stride_scores, 
 int vodhip_merge_hybrid(const int64_t* lookup_idx, const int64_t* lookup_lbl, int k_lookup, int n_engines,
                         const int64_t* const* engine_idx, const float* const* engine_scr, const int* engine_k,
                         const float* engine_weight, int64_t nq, int64_t* out_idx, float* out_scr, int64_t* out_lbl,
-                        float* const* out_raw, int out_stride, int32_t* out_width, void* stream) {
+                        float* const* out_raw, int out_stride, int32_t* out_width, int32_t* out_row_cursor, void* stream) {
     if (n_engines < 0 || n_engines > VODHIP_MAX_ENGINES) return fail("n_engines=%d out of range", n_engines);
     if (k_lookup < 0 || nq < 0) return fail("invalid sizes");
     HybridArgs a;
@@ -770,7 +770,8 @@ int vodhip_merge_hybrid(const int64_t* lookup_idx, const int64_t* lookup_lbl, in
     a.out_lbl = out_lbl;
     a.out_stride = out_stride;
     a.out_width = out_width;
-    if (!out_idx || !out_scr || !out_width) return fail("NULL output");
+    a.out_row_cursor = out_row_cursor;
+    if (!out_idx || !out_scr) return fail("NULL output");
     HIP_OK(launch_merge_hybrid(a, (hipStream_t)stream));
     return 0;
 }
@@ -840,6 +841,175 @@ int vodhip_priority_sample(const float* scores, const uint8_t* labels, const flo
     return 0;
 }
 
+int vodhip_priority_sample_merged(const int64_t* ids, const float* scores, const int64_t* labels, int n_raw, const float* const* raw,
+                                  const float* noise, int64_t noise_stride, int64_t nq, int stride, int width,
+                                  const int32_t* merge_width, const int32_t* merge_row_cursor, int k_lookup, int n_engines,
+                                  const int* engine_k, int k_positive,
+                                  int k_total, float temperature, int max_support_size, int normalized, int64_t* out_samples,
+                                  int64_t* out_ids, float* out_scores, float* out_log_weights, uint8_t* out_labels,
+                                  float* const* out_raw, float* out_lse, float* out_max_sampling_id, void* stream) {
+    if (nq < 0 || stride < 0 || k_total < 1 || k_positive < 0) return fail("invalid sizes");
+    if (stride > 4096 || width > stride) return fail("stride=%d / width=%d: at most 4096 candidates per row, width <= stride", stride, width);
+    if (k_total > 4096) return fail("k_total=%d exceeds 4096", k_total);
+    if (n_raw < 0 || n_raw > VODHIP_MAX_ENGINES || (n_raw && (!raw || !out_raw))) return fail("n_raw=%d out of range / NULL raw arrays", n_raw);
+    if (noise_stride < (width >= 0 ? width : stride)) return fail("noise rows are shorter than the candidate rows");
+    if (nq == 0) return 0;
+    if (!ids || !scores || !labels || !noise || !out_samples || !out_ids || !out_scores || !out_log_weights || !out_labels || !out_lse)
+        return fail("NULL argument");
+    SampleMergedArgs m{};
+    if (width < 0) {
+        if ((n_engines > 0 && !merge_width && !merge_row_cursor) || !engine_k || n_engines < 0 || n_engines > VODHIP_MAX_ENGINES || k_lookup < 0)
+            return fail("width < 0 needs merge_width or merge_row_cursor, k_lookup and engine_k of the merge that produced the rows");
+        int64_t w_max = k_lookup;
+        for (int e = 0; e < n_engines; ++e) {
+            if (engine_k[e] < 0) return fail("engine %d: negative k", e);
+            m.engine_k[e] = engine_k[e];
+            w_max += engine_k[e];
+        }
+        if (n_engines > 0 && stride < w_max + 1) return fail("stride=%d < k_lookup + sum(k_e) + 1 = %lld", stride, (long long)w_max + 1);
+        if (n_engines == 0 && stride < w_max) return fail("stride=%d < k_lookup", stride);
+    }
+    m.ids = ids;
+    m.scores = scores;
+    m.labels = labels;
+    m.noise = noise;
+    m.nq = nq;
+    m.stride = stride;
+    m.noise_stride = noise_stride;
+    m.width = width;
+    m.merge_width = merge_width;
+    m.row_cursor = merge_row_cursor;
+    m.k_lookup = k_lookup;
+    m.n_engines = width < 0 ? n_engines : 0;
+    m.k_positive = k_positive;
+    m.k_total = k_total;
+    m.temperature = temperature;
+    m.max_support = max_support_size;
+    m.normalized = normalized;
+    m.n_raw = n_raw;
+    for (int e = 0; e < n_raw; ++e) {
+        if (!raw[e] || !out_raw[e]) return fail("NULL raw array %d", e);
+        m.raw[e] = raw[e];
+        m.out_raw[e] = out_raw[e];
+    }
+    m.out_samples = out_samples;
+    m.out_ids = out_ids;
+    m.out_scores = out_scores;
+    m.out_logw = out_log_weights;
+    m.out_labels = out_labels;
+    m.out_lse = out_lse;
+    m.lse_row_stride = 2;
+    m.lse_cls_stride = 1;
+    m.out_max_sampling_id = out_max_sampling_id;
+    HIP_OK(launch_priority_sample_merged(m, (hipStream_t)stream));
+    return 0;
+}
+
+int vodhip_flatten_inbatch(const int64_t* ids, int64_t n_rows, int n_keys, int n_values, const float* const* values, const float* fill,
+                           float* const* outs, const uint8_t* labels, uint8_t* out_labels, int64_t* out_unique, int32_t* out_n_unique,
+                           void* stream) {
+    if (n_rows < 0 || n_keys < 0 || n_values < 0 || n_values > 8) return fail("invalid sizes (n_values <= 8)");
+    if ((labels == nullptr) != (out_labels == nullptr)) return fail("labels and out_labels go together");
+    if (n_rows * (int64_t)n_keys > 8192) return fail("%lld ids in the batch: the one-launch flattening holds at most 8192", (long long)(n_rows * n_keys));
+    if (n_rows == 0 || n_keys == 0) return 0;
+    if (!ids || !out_unique || (n_values && (!values || !fill || !outs))) return fail("NULL argument");
+    for (int v = 0; v < n_values; ++v)
+        if (!outs[v] || !values[v]) return fail("NULL value / output array %d", v);
+    HIP_OK(launch_flatten_inbatch(ids, n_rows, n_keys, n_values, values, fill, outs, labels, out_labels, out_unique, out_n_unique,
+                                  (hipStream_t)stream));
+    return 0;
+}
+
+int vodhip_collate(const vodhip_collate_args_t* c, void* stream_) {
+    if (!c) return fail("args is NULL");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (c->n_engines < 1 || c->n_engines > VODHIP_MAX_ENGINES) return fail("n_engines=%d out of range [1, %d]", c->n_engines, VODHIP_MAX_ENGINES);
+    if (c->k_lookup < 0 || c->nq < 0 || c->k_total < 1 || c->k_positive < 0) return fail("invalid sizes");
+    int64_t stride = c->k_lookup + 1;
+    for (int e = 0; e < c->n_engines; ++e) {
+        if (c->engine_k[e] < 0 || (c->engine_k[e] > 0 && (!c->engine_idx[e] || !c->engine_scr[e]))) return fail("engine %d: invalid arguments", e);
+        if (!c->merged_raw[e] || !c->out_raw[e]) return fail("engine %d: NULL raw-score workspace / output", e);
+        stride += c->engine_k[e];
+    }
+    if (stride - 1 > 4096) return fail("total width %lld exceeds 4096", (long long)stride - 1);
+    if (c->k_total > 4096) return fail("k_total=%d exceeds 4096", c->k_total);
+    if (c->noise_stride < stride) return fail("noise rows (%lld) are shorter than the merged rows (%lld)", (long long)c->noise_stride, (long long)stride);
+    if (c->nq == 0) return 0;
+    if ((c->k_lookup && !c->lookup_idx) || !c->noise || !c->merged_idx || !c->merged_lbl || !c->merged_scr || !c->row_cursor || !c->out_local ||
+        !c->out_ids || !c->out_scores || !c->out_log_weights || !c->out_labels || !c->out_lse_pos || !c->out_lse_neg)
+        return fail("NULL argument");
+    HybridArgs h;
+    memset(&h, 0, sizeof(h));
+    h.lookup_idx = c->lookup_idx;
+    h.lookup_lbl = c->lookup_lbl;
+    h.k_lookup = c->k_lookup;
+    h.n_engines = c->n_engines;
+    for (int e = 0; e < c->n_engines; ++e) {
+        h.engine_idx[e] = c->engine_idx[e];
+        h.engine_scr[e] = c->engine_scr[e];
+        h.engine_k[e] = c->engine_k[e];
+        h.engine_w[e] = c->engine_weight[e];
+        h.out_raw[e] = c->merged_raw[e];
+    }
+    h.nq = c->nq;
+    h.out_idx = c->merged_idx;
+    h.out_scr = c->merged_scr;
+    h.out_lbl = c->merged_lbl;
+    h.out_stride = (int)stride;
+    h.out_row_cursor = c->row_cursor;
+    HIP_OK(launch_merge_hybrid(h, stream));
+    SampleMergedArgs m{};
+    m.ids = c->merged_idx;
+    m.scores = c->merged_scr;
+    m.labels = c->merged_lbl;
+    m.noise = c->noise;
+    m.nq = c->nq;
+    m.stride = stride;
+    m.noise_stride = c->noise_stride;
+    m.width = -1;
+    m.row_cursor = c->row_cursor;
+    m.k_lookup = c->k_lookup;
+    m.n_engines = c->n_engines;
+    m.n_raw = c->n_engines;
+    for (int e = 0; e < c->n_engines; ++e) {
+        m.engine_k[e] = c->engine_k[e];
+        m.raw[e] = c->merged_raw[e];
+        m.out_raw[e] = c->out_raw[e];
+    }
+    m.k_positive = c->k_positive;
+    m.k_total = c->k_total;
+    m.temperature = c->temperature;
+    m.max_support = c->max_support_size;
+    m.normalized = 1;
+    m.out_samples = c->out_local;
+    m.out_ids = c->out_ids;
+    m.out_scores = c->out_scores;
+    m.out_logw = c->out_log_weights;
+    m.out_labels = c->out_labels;
+    // lse_pos / lse_neg are two [nq] arrays: class stride = their distance (any two arrays of the same type can be addressed so)
+    m.out_lse = c->out_lse_pos;
+    m.lse_row_stride = 1;
+    m.lse_cls_stride = c->out_lse_neg - c->out_lse_pos;
+    m.out_max_sampling_id = c->out_max_sampling_id;
+    HIP_OK(launch_priority_sample_merged(m, stream));
+    if (!c->in_batch_negatives) return 0;
+    if (c->nq * (int64_t)c->k_total > 8192) return fail("%lld ids in the batch: the one-launch flattening holds at most 8192", (long long)(c->nq * c->k_total));
+    if (!c->flat_ids || !c->flat_scores || !c->flat_log_weights || !c->flat_labels) return fail("NULL flattened output");
+    const float* values[8];
+    float* outs[8];
+    float fill[8];
+    int nv = 0;
+    values[nv] = c->out_scores, outs[nv] = c->flat_scores, fill[nv++] = __builtin_nanf("");
+    values[nv] = c->out_log_weights, outs[nv] = c->flat_log_weights, fill[nv++] = __builtin_nanf("");
+    for (int e = 0; e < c->n_engines; ++e) {
+        if (!c->flat_raw[e]) return fail("engine %d: NULL flattened raw-score output", e);
+        values[nv] = c->out_raw[e], outs[nv] = c->flat_raw[e], fill[nv++] = __builtin_nanf("");
+    }
+    HIP_OK(launch_flatten_inbatch(c->out_ids, c->nq, c->k_total, nv, values, fill, outs, c->out_labels, c->flat_labels, c->flat_ids,
+                                  c->flat_n_unique, stream));
+    return 0;
+}
+
 int vodhip_gather_by_id(const int64_t* queries, int64_t n_queries, const int64_t* keys, int64_t n_rows, int n_keys,
                         int n_values, const float* const* values, const float* fill, float* const* outs, void* stream) {
     if (n_queries < 0 || n_rows < 0 || n_keys < 0 || n_values < 1 || n_values > 8) return fail("invalid sizes (1 <= n_values <= 8)");
@@ -850,6 +1020,15 @@ int vodhip_gather_by_id(const int64_t* queries, int64_t n_queries, const int64_t
     for (int v = 0; v < n_values; ++v)
         if (!outs[v] || (n_keys && !values[v])) return fail("NULL value / output array %d", v);
     HIP_OK(launch_gather_by_id(queries, n_queries, keys, n_rows, n_keys, n_values, values, fill, outs, (hipStream_t)stream));
+    return 0;
+}
+
+int vodhip_debug_read_probe(int which, int64_t* out, int n) {
+    if (!out || n < 256) return fail("out must hold 256 values");
+    static_assert(sizeof(long long) == sizeof(int64_t), "probe words are 64-bit");
+    const hipError_t e = which == 0 ? read_probe_hybrid((long long*)out) : read_probe_sample(which, (long long*)out);
+    if (e == hipErrorNotSupported) return fail("phase stamps exist in diagnostic builds only (make ABLATION=1)");
+    if (e != hipSuccess) return fail("HIP error: %s", hipGetErrorString(e));
     return 0;
 }
 

@@ -3,7 +3,35 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Diagnostic builds (`make ABLATION=1`): phase stamps of workgroup 0 of the collate-side kernels - shader-clock cycles
+// (s_memtime) and the constant 100 MHz counter (s_memrealtime) - read back with vodhip_debug_read_probe.  Nothing in production.
+#ifdef VODHIP_ABLATION
+#define VODHIP_PROBE(buf, i)                                                  \
+    do {                                                                      \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                            \
+            (buf)[2 * (i)] = (long long)__builtin_amdgcn_s_memtime();         \
+            (buf)[2 * (i) + 1] = (long long)__builtin_amdgcn_s_memrealtime(); \
+        }                                                                     \
+    } while (0)
+// begin / end stamp of EVERY workgroup (blocks 0..63 of the launch): buf[128 + 2 * block] = begin tick, + 1 = end tick
+#define VODHIP_PROBE_WG(buf, end)                                                                                   \
+    do {                                                                                                            \
+        if (blockIdx.x < 64 && threadIdx.x == 0) (buf)[128 + 2 * blockIdx.x + (end)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define VODHIP_PROBE_WG(buf, end) \
+    do {                          \
+    } while (0)
+#define VODHIP_PROBE(buf, i) \
+    do {                     \
+    } while (0)
+#endif
+
 namespace vodhip {
+
+// which: 0 = merge_hybrid_kernel, 1 = priority_sample_kernel, 2 = flatten_inbatch_kernel; out: 256 words = 64 (cycles, 10 ns ticks) phase pairs + 64 (begin, end) workgroup pairs
+hipError_t read_probe_hybrid(long long* out);
+hipError_t read_probe_sample(int which, long long* out);
 
 // 64-bit order-preserving result key: high 32 bits = monotone image of the fp32 score, low 32 bits =
 // 0xFFFFFFFF - local row id.  Larger key == better hit (higher score; on equal score the smaller id).
@@ -97,7 +125,8 @@ struct HybridArgs {
     int64_t* out_lbl;
     float* out_raw[4];
     int out_stride;
-    int32_t* out_width;
+    int32_t* out_width;        // [4] maximum over rows of the cursor after each engine (atomics; cleared by the launcher), or NULL
+    int32_t* out_row_cursor;   // [nq, 4] the same cursors per row (plain stores), or NULL
 };
 hipError_t launch_merge_hybrid(const HybridArgs& a, hipStream_t stream);
 
@@ -123,6 +152,37 @@ hipError_t launch_priority_sample(const float* scores, const uint8_t* labels, co
                                   int k_positive, int k_total, float temperature, int max_support_size, int normalized,
                                   int64_t* out_samples, float* out_log_weights, uint8_t* out_labels, float* out_lse,
                                   hipStream_t stream);
+
+// sampling straight from the merge's full-stride outputs + the gather epilogue (device-resident collate)
+struct SampleMergedArgs {
+    const int64_t* ids;
+    const float* scores;
+    const int64_t* labels;   // > 0 = positive
+    const float* noise;
+    int64_t nq, stride, noise_stride;
+    int width;               // >= 0: columns in use; < 0: derived on the device from merge_width / k_lookup / engine_k
+    const int* merge_width;  // [n_engines] maxima over rows, or NULL
+    const int* row_cursor;   // [nq, 4] per-row cursors (the kernel takes the maximum), or NULL
+    int k_lookup, n_engines, engine_k[4];
+    int k_positive, k_total;
+    float temperature;
+    int max_support, normalized;
+    int n_raw;
+    const float* raw[4];
+    int64_t* out_samples;
+    int64_t* out_ids;
+    float* out_scores;
+    float* out_logw;
+    uint8_t* out_labels;
+    float* out_raw[4];
+    float* out_lse;          // lse of class c of row r at out_lse[r * lse_row_stride + c * lse_cls_stride]
+    int64_t lse_row_stride, lse_cls_stride;
+    float* out_max_sampling_id;
+};
+hipError_t launch_priority_sample_merged(const SampleMergedArgs& m, hipStream_t stream);
+hipError_t launch_flatten_inbatch(const int64_t* ids, int64_t n_rows, int n_keys, int n_values, const float* const* values,
+                                  const float* fill, float* const* outs, const uint8_t* labels, uint8_t* out_labels,
+                                  int64_t* out_unique, int* out_n_unique, hipStream_t stream);
 
 hipError_t launch_gather_by_id(const int64_t* queries, int64_t n_queries, const int64_t* keys, int64_t n_rows, int n_keys,
                                int n_values, const float* const* values, const float* fill, float* const* outs,
