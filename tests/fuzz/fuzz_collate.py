@@ -227,6 +227,81 @@ def fuzz_flatten(rng):
     return dict(LAST)
 
 
+def fuzz_chain(rng):
+    """The device-resident chain (`collate_on_device` = vodhip_collate: merge -> sampling + gathers + rank diagnostic -> in-batch
+    flattening, no host sync) against the oracle's restatement of the reference chain, stage by stage."""
+    from oracle import sampling as osmp
+    from oracle.hybrid import merge_hybrid
+    from vod_amd.core.collate import collate_on_device
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    nq = int(rng.choice([1, 3, 16, 64, 200]))
+    kl = int(rng.choice([0, 1, 4, 32, 128]))
+    ks = [int(rng.choice([1, 3, 16, 128, 400])) for _ in range(int(rng.integers(1, 5)))]
+    pool = int(rng.choice([6, 50, 400, 100_000]))
+    total = int(rng.choice([1, 4, 32, 100]))
+    kpos = int(rng.choice([1, 2, 8, total]))
+    temp = float(rng.choice([0.0, 0.5, 1.0, 3.0]))
+    support = None if rng.random() < 0.5 else int(rng.choice([1, 10, 100, 1000]))
+    dup = float(rng.choice([0.0, 0.0, 0.5]))
+    flat = bool(rng.random() < 0.5) and nq * total <= 8192
+    LAST.clear(); LAST.update(kind="chain", nq=nq, kl=kl, ks=ks, pool=pool, total=total, kpos=kpos, temp=temp, support=support, dup=dup, flat=flat)
+
+    def eng(k):
+        idx = np.full((nq, k), -1, dtype=np.int64)
+        scr = np.full((nq, k), -np.inf, dtype=np.float32)
+        for r in range(nq):
+            nv = k if rng.random() > 0.2 else int(rng.integers(0, k + 1))
+            idx[r, :nv] = rng.choice(pool, size=nv, replace=pool < nv)
+            if nv and rng.random() < dup:
+                src = rng.integers(0, nv, size=max(1, nv // 8))
+                idx[r, rng.integers(0, nv, size=len(src))] = idx[r, src]
+            scr[r, :nv] = -np.sort(-(rng.normal(size=nv) * 3).astype(np.float32))
+        return idx, scr
+
+    l_idx, _ = eng(kl)
+    l_lbl = np.where(l_idx >= 0, rng.integers(0, 3, size=l_idx.shape), 0).astype(np.int64)
+    names = [f"e{j}" for j in range(len(ks))]
+    engs = [eng(k) for k in ks]
+    weights = {n: float(rng.choice([0.0, 0.5, 1.0, 2.0])) for n in names}
+    with np.errstate(all="ignore"):
+        m_idx, m_scr, m_lbl, m_raw = merge_hybrid((l_idx, np.zeros(l_idx.shape, np.float32), l_lbl), dict(zip(names, engs)), weights)
+    w = m_idx.shape[1]
+    noise = rng.exponential(size=(nq, kl + sum(ks) + 1)).astype(np.float32)
+    ref = osmp.sample_search_results(m_idx, m_scr, m_lbl, m_raw, noise[:, :w], total, kpos, temp, support)
+    engines = {n: (t(i), t(sc)) for n, (i, sc) in zip(names, engs)}
+    out = collate_on_device(t(l_idx), t(l_lbl), engines, weights, t(noise), total=total, max_pos_sections=kpos, temperature=temp,
+                            max_support_size=support)
+    fin = np.isfinite(ref["log_weights"])
+    got_w = out.log_weights.cpu().numpy()
+    _eq(np.isfinite(got_w), fin, "chain finite weights")
+    _eq(out.indices.cpu().numpy()[fin], ref["indices"][fin], "chain ids")
+    _eq(out.labels.cpu().numpy(), ref["labels"], "chain labels")
+    _eq(out.scores.cpu().numpy()[fin], ref["scores"][fin], "chain scores")
+    np.testing.assert_allclose(got_w[fin], ref["log_weights"][fin], rtol=2e-4, atol=2e-4)
+    for key in ("lse_pos", "lse_neg"):
+        both = np.isfinite(ref[key])
+        got = getattr(out, key).cpu().numpy()
+        _eq(np.isfinite(got), both, key)
+        np.testing.assert_allclose(got[both], ref[key][both], rtol=2e-4, atol=2e-4)
+    settled = (fin | (ref["local"] < 0)).all(axis=1)
+    _eq(out.max_sampling_id.cpu().numpy()[settled], ref["max_sampling_id"][settled], "chain rank diagnostic")
+    for n in names:
+        _eq(out.raw_scores[n].cpu().numpy()[fin], ref["raw"][n][fin], f"chain raw {n}")
+    if flat:
+        fl = collate_on_device(t(l_idx), t(l_lbl), engines, weights, t(noise), total=total, max_pos_sections=kpos, temperature=temp,
+                               max_support_size=support, in_batch_negatives=True)
+        rf = osmp.flatten_samples(out.indices.cpu().numpy(), out.scores.cpu().numpy(), out.labels.cpu().numpy(), out.log_weights.cpu().numpy(),
+                                  {n: v.cpu().numpy() for n, v in out.raw_scores.items()})
+        _eq(fl.indices.cpu().numpy(), rf["indices"], "chain flat ids")
+        _eq(fl.scores.cpu().numpy(), rf["scores"], "chain flat scores")
+        _eq(fl.labels.cpu().numpy(), rf["labels"], "chain flat labels")
+        _eq(fl.log_weights.cpu().numpy(), rf["log_weights"], "chain flat log weights")
+        for n in names:
+            _eq(fl.raw_scores[n].cpu().numpy(), rf["raw"][n], f"chain flat raw {n}")
+    return dict(LAST)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=300)
@@ -238,7 +313,7 @@ def main():
     for t in range(a.trials):
         if time.time() - t0 > a.seconds:
             break
-        fn = [fuzz_merge, fuzz_sampling, fuzz_gradients, fuzz_merge_topk, fuzz_flatten][t % 5]
+        fn = [fuzz_merge, fuzz_sampling, fuzz_gradients, fuzz_merge_topk, fuzz_flatten, fuzz_chain][t % 6]
         state = rng.bit_generator.state
         try:
             info = fn(rng)

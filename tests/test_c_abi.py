@@ -45,3 +45,27 @@ def test_c_consumer_gets_the_exact_answer(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=dict(os.environ))
     assert out.returncode == 0, out.stderr + out.stdout
     assert "C ABI smoke ok" in out.stdout
+
+
+def test_collate_args_struct_layout_matches_the_ctypes_mirror(tmp_path):
+    """`vodhip_collate_args_t` crosses the boundary by pointer: the ctypes mirror (`_native.CollateArgs`) must have the C
+    compiler's size and field offsets."""
+    import ctypes
+
+    from vod_amd import _native
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    fields = [name for name, _ in _native.CollateArgs._fields_]
+    prog = tmp_path / "layout.c"
+    prog.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "vodhip.h"\nint main(void) {\n'
+        '  printf("%zu\\n", sizeof(vodhip_collate_args_t));\n'
+        + "".join(f'  printf("%zu\\n", offsetof(vodhip_collate_args_t, {f}));\n' for f in fields)
+        + "  return 0;\n}\n"
+    )
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", str(prog), "-I", str(ROOT / "include"), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got[0] == ctypes.sizeof(_native.CollateArgs)
+    assert got[1:] == [getattr(_native.CollateArgs, f).offset for f in fields]

@@ -40,8 +40,8 @@ def test_search_campaign_slice(seed):
 def test_collate_campaign_slice(seed):
     fz = _load("fuzz_collate")
     rng = np.random.default_rng(seed)
-    fns = [fz.fuzz_merge, fz.fuzz_sampling, fz.fuzz_gradients, fz.fuzz_merge_topk, fz.fuzz_flatten]
-    for t in range(150):
+    fns = [fz.fuzz_merge, fz.fuzz_sampling, fz.fuzz_gradients, fz.fuzz_merge_topk, fz.fuzz_flatten, fz.fuzz_chain]
+    for t in range(180):
         fn = fns[t % len(fns)]
         try:
             fn(rng)
