@@ -496,3 +496,145 @@ def test_master_command_line_for_a_multi_gpu_group(tmp_path):
     m1 = vclient.HipMipsMaster(tmp_path / "v.npy", device=2, port=7001, skip_setup=True)
     cmd1 = m1._make_cmd()
     assert cmd1[cmd1.index("--device") + 1] == "2" and "--devices" not in cmd1
+
+
+# ---- the asyncio HTTP shell (production) speaks the same contract over real sockets ------------------------------------------
+def _serve_in_thread(engine, micro_batch_wait_ms=0.0):
+    import asyncio
+    import threading
+
+    from vod_amd.search import fastserver
+    from vod_amd.search.server import Endpoints
+    from vod_amd.search.socket import find_available_port
+
+    port = find_available_port()
+    state = {}
+
+    def run():
+        async def main():
+            state["loop"], state["stop"] = asyncio.get_running_loop(), asyncio.Event()
+            ready = asyncio.Event()
+            task = asyncio.create_task(fastserver.serve(Endpoints(engine, micro_batch_wait_ms), "127.0.0.1", port, workers=16, ready=ready,
+                                                        stop=state["stop"]))
+            await ready.wait()
+            state["ready"] = True
+            await task
+
+        asyncio.run(main())
+
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    for _ in range(200):
+        if state.get("ready"):
+            break
+        __import__("time").sleep(0.02)
+    assert state.get("ready"), "server did not start"
+
+    def stop():
+        state["loop"].call_soon_threadsafe(state["stop"].set)
+        th.join(timeout=10)
+
+    return port, stop
+
+
+def test_asyncio_server_routes_wire_format_and_errors():
+    import http.client
+
+    import requests
+
+    rng = np.random.default_rng(0)
+    x = rng.integers(-4, 5, size=(50, 8)).astype(np.float32)
+    q = rng.integers(-4, 5, size=(3, 8)).astype(np.float32)
+    port, stop = _serve_in_thread(_OracleEngine(x))
+    try:
+        url = f"http://127.0.0.1:{port}"
+        c = vclient.HipMipsClient("http://127.0.0.1", port)
+        assert c.ping() and requests.get(url + "/").json() == "OK"
+        # the reference's own client code path: requests.post(json=...) with the reference codec strings
+        r = requests.post(url + "/fast-search", json={"vectors": vio.serialize_np_array(q), "top_k": 60})
+        assert r.status_code == 200 and set(r.json()) == {"scores", "indices"}
+        scores, ids = vio.deserialize_np_array(r.json()["scores"]), vio.deserialize_np_array(r.json()["indices"])
+        assert scores.dtype == np.float32 and ids.dtype == np.int64 and scores.shape == (3, 60)
+        assert np.all(ids[:, 50:] == -1) and np.all(np.isneginf(scores[:, 50:]))
+        # our client, both routes, float32 and float16 on the wire, over ONE kept-alive connection each
+        for binary in (False, True):
+            for wire in (None, "float16"):
+                cl = vclient.HipMipsClient("http://127.0.0.1", port, binary=binary, wire_dtype=wire)
+                for _ in range(3):
+                    res = cl.search(vector=q, top_k=7)
+                np.testing.assert_array_equal(res.indices, ids[:, :7])
+                np.testing.assert_array_equal(res.scores, scores[:, :7])
+                clone = pickle.loads(pickle.dumps(cl))  # a DataLoader worker's copy opens its own connection
+                np.testing.assert_array_equal(clone.search(vector=q, top_k=7).indices, ids[:, :7])
+        r2 = requests.post(url + "/search", json={"vectors": q.tolist(), "top_k": 5})
+        assert r2.status_code == 200 and np.array(r2.json()["indices"]).tolist() == ids[:, :5].tolist()
+        # contract errors: same status codes and bodies as the FastAPI shell
+        assert requests.post(url + "/fast-search", json={"vectors": vio.serialize_np_array(q), "top_k": 3, "extra": 1}).status_code == 422
+        assert requests.post(url + "/fast-search", json={"vectors": 3, "top_k": 3}).status_code == 422
+        assert requests.post(url + "/fast-search", data=b"[1, 2]").status_code == 422
+        bad = requests.post(url + "/fast-search", json={"vectors": vio.serialize_np_array(q[0]), "top_k": 3})
+        assert bad.status_code == 500 and "Expected 2D array" in bad.json()["detail"]
+        assert requests.post(url + "/fast-search", json={"vectors": vio.serialize_np_array(q[:, :4]), "top_k": 3}).status_code == 500
+        with pytest.raises(requests.HTTPError):
+            c.search(vector=q[:, :4], top_k=3)
+        assert c.search(vector=q, top_k=2).indices.tolist() == ids[:, :2].tolist()  # the connection survived the 500
+        assert requests.get(url + "/nope").status_code == 404 and requests.get(url + "/fast-search").status_code == 405
+        assert requests.post(url + "/raw-search?top_k=x", data=b"").status_code == 422
+        # protocol corners: Expect: 100-continue, chunked upload refused, two pipelined requests on one connection
+        hc = http.client.HTTPConnection("127.0.0.1", port)
+        body = bytes(vio.json_body_with_arrays({"vectors": q}, {"top_k": 4}))
+        hc.request("POST", "/fast-search", body=body, headers={"Expect": "100-continue", "content-type": "application/json"})
+        resp = hc.getresponse()
+        assert resp.status == 200 and b"scores" in resp.read()
+        hc.putrequest("POST", "/fast-search")
+        hc.putheader("Transfer-Encoding", "chunked")
+        hc.endheaders()
+        assert hc.getresponse().status == 501
+        import socket as _socket
+
+        s = _socket.create_connection(("127.0.0.1", port))
+        one = b"POST /fast-search HTTP/1.1\r\nHost: x\r\nContent-Length: %d\r\n\r\n" % len(body) + body
+        s.sendall(one + one)
+        got = b""
+        while got.count(b'"scores"') < 2:
+            chunk = s.recv(65536)
+            assert chunk, "connection closed before both pipelined replies arrived"
+            got += chunk
+        s.close()
+    finally:
+        stop()
+
+
+def test_asyncio_server_fuses_concurrent_clients():
+    """32 concurrent clients with micro-batching on: every caller gets its own exact rows, and the engine saw fewer, larger batches."""
+    import concurrent.futures
+
+    from oracle.flat_ip import flat_ip_topk
+
+    rng = np.random.default_rng(5)
+    x = rng.integers(-4, 5, size=(400, 8)).astype(np.float32)
+
+    class Counting(_OracleEngine):
+        calls = 0
+
+        def search(self, q, k):
+            Counting.calls += 1
+            return super().search(q, k)
+
+    port, stop = _serve_in_thread(Counting(x), micro_batch_wait_ms=20.0)
+    try:
+        qs = [rng.integers(-4, 5, size=(1 + i % 5, 8)).astype(np.float32) for i in range(32)]
+
+        def one(i):
+            cl = vclient.HipMipsClient("http://127.0.0.1", port, binary=bool(i % 2))
+            return cl.search(vector=qs[i], top_k=3 + i % 4)
+
+        with concurrent.futures.ThreadPoolExecutor(32) as pool:
+            results = list(pool.map(one, range(32)))
+        for i, res in enumerate(results):
+            rs, ri = flat_ip_topk(qs[i], x, 3 + i % 4)
+            np.testing.assert_array_equal(res.indices, ri)
+            np.testing.assert_array_equal(res.scores, rs)
+        assert Counting.calls < 32
+    finally:
+        stop()

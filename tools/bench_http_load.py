@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Throughput THROUGH the drop-in boundary under the load shape the trainer produces: many DataLoader workers, each sending
+its own small batch (/root/reference/src/vod_dataloaders/realm_dataloader.py:92-118, core/search.py:128-146) to ONE server.
+
+P concurrent client PROCESSES (pickled `HipMipsClient`s, like DataLoader workers) x batch size nq, on the reference's wire format
+(`/fast-search`, base64-in-JSON) and on the binary route (`/raw-search`), with the server's micro-batching off and on.
+Per cell: aggregate queries/s, request latency p50 / p99, and the ratio to the device-resident rate of ONE fused batch of
+P * nq queries (what a perfect boundary in front of the same kernels would deliver).
+
+    python tools/bench_http_load.py [--rows 10000000] [--dim 768] [--k 100] [--seconds 2.5] [--out profiles/r03_http_load.json]
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import pathlib
+import statistics
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def _worker(client, nq, dim, k, seconds, barrier, out_q, seed):
+    rng = np.random.default_rng(seed)
+    q = rng.standard_normal((nq, dim), dtype=np.float32)
+    for _ in range(3):
+        client.search(vector=q, top_k=k)
+    barrier.wait()
+    lat = []
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        t0 = time.perf_counter()
+        res = client.search(vector=q, top_k=k)
+        lat.append(time.perf_counter() - t0)
+    assert res.indices.shape == (nq, k)
+    out_q.put(lat)
+
+
+def run_cell(client, P, nq, dim, k, seconds):
+    ctx = mp.get_context("spawn")
+    barrier, out_q = ctx.Barrier(P + 1), ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(client, nq, dim, k, seconds, barrier, out_q, 100 + i)) for i in range(P)]
+    for p in procs:
+        p.start()
+    barrier.wait()
+    t0 = time.perf_counter()
+    lats = [out_q.get(timeout=seconds + 120) for _ in range(P)]
+    wall = time.perf_counter() - t0
+    for p in procs:
+        p.join(timeout=60)
+    flat = sorted(x for lat in lats for x in lat)
+    n_req = len(flat)
+    return {"clients": P, "nq": nq, "requests": n_req, "qps": n_req * nq / wall, "p50_ms": flat[n_req // 2] * 1e3,
+            "p99_ms": flat[min(n_req - 1, int(n_req * 0.99))] * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--seconds", type=float, default=2.5)
+    ap.add_argument("--clients", type=int, nargs="+", default=[1, 8, 32])
+    ap.add_argument("--nq", type=int, nargs="+", default=[32, 64, 256])
+    ap.add_argument("--micro-batch-ms", type=float, nargs="+", default=[0.0, 1.0])
+    ap.add_argument("--http", default="asyncio", choices=["asyncio", "uvicorn"])
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    import torch
+
+    from vod_amd.index import HipFlatIndex
+    from vod_amd.search.client import HipMipsClient, HipMipsMaster
+    from vod_amd.search.server import synthetic_rows
+
+    os.chdir(tempfile.mkdtemp())
+    spec = f"synthetic:{a.rows}x{a.dim}:7"
+    out = {"store": f"{a.rows} x {a.dim} fp16 (synthetic N(0,1), generated on the device)", "k": a.k, "http": a.http, "seconds_per_cell": a.seconds,
+           "host_cpus": len(os.sched_getaffinity(0)), "device_resident": {}, "cells": []}
+    # device-resident reference: the same store in this process, one fused batch of B queries resident in HBM
+    dev = torch.device("cuda", 0)
+    ix = HipFlatIndex(a.dim, a.rows, dtype=torch.float16, device=0)
+    for rows in synthetic_rows(torch, dev, 0, a.rows, a.dim, 7):
+        ix.add(rows.half())
+    for B in sorted({min(2048, P * nq) for P in a.clients for nq in a.nq} | set(a.nq)):
+        q = torch.randn((B, a.dim), device=dev).half()
+        for _ in range(3):
+            ix.search(q, a.k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            ix.search_async(q, a.k)
+            if ix._keep and len(ix._keep) > 1:
+                ix.finish()
+        while ix._keep:
+            ix.finish()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        out["device_resident"][str(B)] = {"ms_per_batch": ms, "qps": B / ms * 1e3}
+    ix.close()
+    del ix
+    torch.cuda.empty_cache()
+    for mb in a.micro_batch_ms:
+        with HipMipsMaster(spec, port=-1, logging_level="warning", micro_batch_wait_ms=mb, http=a.http) as master:
+            for binary in (False, True):
+                client = HipMipsClient(host=master.host, port=master.port, binary=binary)
+                for P in a.clients:
+                    for nq in a.nq:
+                        cell = run_cell(client, P, nq, a.dim, a.k, a.seconds)
+                        fused = str(min(2048, P * nq))
+                        cell.update(route="/raw-search" if binary else "/fast-search", micro_batch_wait_ms=mb,
+                                    device_resident_qps_at_fused_batch=out["device_resident"][fused]["qps"],
+                                    device_resident_qps_at_request_batch=out["device_resident"][str(nq)]["qps"])
+                        cell["fraction_of_device_rate_at_fused_batch"] = cell["qps"] / cell["device_resident_qps_at_fused_batch"]
+                        out["cells"].append(cell)
+                        print(json.dumps(cell), flush=True)
+    text = json.dumps(out, indent=1)
+    if a.out:
+        pathlib.Path(ROOT / a.out).write_text(text)
+    print(json.dumps({"done": True, "cells": len(out["cells"])}))
+
+
+if __name__ == "__main__":
+    main()

@@ -125,3 +125,138 @@ def parse_json_body(body: bytes, payload_keys: tuple[str, ...]) -> dict:
         raise ValueError("expected a JSON object")
     small.update(out)
     return small
+
+
+# ---- buffer-level codec (round 3): the same bytes on the wire without intermediate str / bytes copies ----------------------
+# A 1024 x 768 float32 query batch is 4.2 MB of base64.  `serialize_np_array` -> str -> `json_body` -> bytes copies it three
+# times on the way out, `parse_json_body` -> str -> bytes -> decode three times on the way in; at ~1 GB/s per Python-level copy
+# that is most of the reference format's per-request floor once the search itself takes a millisecond.  These helpers write the
+# base64 text straight into the request / response buffer and decode it straight out of the received body.
+def _addr(buf, offset: int = 0) -> int:
+    """Address of `buf[offset]` for a bytes / bytearray / contiguous memoryview (the object must outlive the call)."""
+    if isinstance(buf, bytes):
+        return ctypes.cast(ctypes.c_char_p(buf), ctypes.c_void_p).value + offset
+    mv = memoryview(buf)
+    if mv.readonly:
+        return ctypes.cast(ctypes.c_char_p(mv.obj if isinstance(mv.obj, bytes) else bytes(mv)), ctypes.c_void_p).value + offset
+    return ctypes.addressof((ctypes.c_char * mv.nbytes).from_buffer(mv)) + offset
+
+
+def npy_header(arr: np.ndarray) -> bytes:
+    head = io.BytesIO()
+    np.lib.format.write_array_header_1_0(head, np.lib.format.header_data_from_array_1_0(arr))
+    return head.getvalue()
+
+
+def b64_len(n_bytes: int) -> int:
+    return 4 * ((n_bytes + 2) // 3)
+
+
+def json_body_with_arrays(arrays: dict[str, np.ndarray], extra: dict | None = None) -> bytearray:
+    """`{"name": "<urlsafe-b64(np.save(array))>", ..., **extra}` - byte for byte what `json_body` of `serialize_np_array` strings
+    gives - assembled in ONE buffer: the encoder writes each array's base64 text in place."""
+    lib = _codec_lib()
+    items = []
+    for name, a in arrays.items():
+        arr = np.asarray(a)
+        if lib is None or arr.dtype.hasobject or not arr.flags.c_contiguous or arr.ndim == 0:
+            return bytearray(json_body({k: serialize_np_array(v) for k, v in arrays.items()}, extra))
+        items.append((json.dumps(name).encode("ascii") + b': "', npy_header(arr), arr))
+    tail = "".join(", " + json.dumps(k) + ": " + json.dumps(v) for k, v in (extra or {}).items()).encode("ascii") + b"}"
+    total = 1 + sum(len(p) + b64_len(len(h) + arr.nbytes) + 1 for p, h, arr in items) + 2 * (len(items) - 1) + len(tail)
+    out = bytearray(total)
+    base = ctypes.addressof((ctypes.c_char * total).from_buffer(out))
+    pos = 0
+    out[pos : pos + 1] = b"{"
+    pos += 1
+    for i, (prefix, head, arr) in enumerate(items):
+        if i:
+            out[pos : pos + 2] = b", "
+            pos += 2
+        out[pos : pos + len(prefix)] = prefix
+        pos += len(prefix)
+        n = lib.vodhip_b64url_encode(head, len(head), arr.ctypes.data if arr.nbytes else None, arr.nbytes, base + pos)
+        if n != b64_len(len(head) + arr.nbytes):
+            raise RuntimeError("base64 encoder returned an unexpected length")
+        pos += n
+        out[pos : pos + 1] = b'"'
+        pos += 1
+    out[pos : pos + len(tail)] = tail
+    assert pos + len(tail) == total
+    return out
+
+
+def find_payload_spans(body, payload_keys: tuple[str, ...]) -> tuple[dict, dict[str, tuple[int, int]]]:
+    """Split a JSON object body into (the small fields, parsed) and the [start, end) byte spans of the big escape-free string
+    fields named in `payload_keys` - nothing is copied.  Falls back to a full `json.loads` when a payload is not a plain string."""
+    mv = body if isinstance(body, (bytes, bytearray)) else bytes(body)
+    spans: dict[str, tuple[int, int]] = {}
+    pieces = []
+    cursor = 0
+    order = []
+    for key in payload_keys:
+        tag = b'"' + key.encode("ascii") + b'"'
+        i = mv.find(tag)
+        if i < 0:
+            continue
+        colon = mv.find(b":", i + len(tag))
+        j = mv.find(b'"', colon + 1)
+        k = mv.find(b'"', j + 1)
+        if colon < 0 or j < 0 or k < 0 or mv[colon + 1 : j].strip() or mv.find(b"\\", j + 1, k) >= 0:
+            full = json.loads(bytes(mv))
+            if not isinstance(full, dict):
+                raise ValueError("expected a JSON object")
+            return full, {}
+        order.append((j + 1, k, key))
+    order.sort()
+    for start, end, key in order:  # the small remainder: everything but the payload characters
+        pieces.append(bytes(mv[cursor:start]))
+        cursor = end
+        spans[key] = (start, end)
+    pieces.append(bytes(mv[cursor:]))
+    small = json.loads(b"".join(pieces))
+    if not isinstance(small, dict):
+        raise ValueError("expected a JSON object")
+    return small, spans
+
+
+def deserialize_np_array_span(body, start: int, end: int) -> np.ndarray:
+    """`deserialize_np_array(body[start:end])` without materialising the slice: base64 text -> owned, writable array."""
+    lib = _codec_lib()
+    if lib is None:
+        return deserialize_np_array(bytes(body[start:end]))
+    n_in = end - start
+    raw = np.empty(3 * n_in // 4 + 3, dtype=np.uint8)
+    keep = body if isinstance(body, (bytes, bytearray)) else bytes(body)
+    n = lib.vodhip_b64url_decode(_addr(keep, start), n_in, raw.ctypes.data)
+    if n < 0:
+        return deserialize_np_array(bytes(body[start:end]))  # lenient decoder (embedded newlines, ...)
+    raw = raw[:n]
+    if raw[:8].tobytes() == b"\x93NUMPY\x01\x00":
+        head = io.BytesIO(raw[:65546].tobytes())
+        head.seek(8)
+        shape, fortran, dt = np.lib.format.read_array_header_1_0(head)
+        if not dt.hasobject and not fortran:
+            count = int(np.prod(shape, dtype=np.int64))
+            off = head.tell()
+            if off + count * dt.itemsize > raw.size:
+                raise ValueError("truncated .npy payload")
+            if off % dt.itemsize == 0 or dt.itemsize == 1:
+                return raw[off : off + count * dt.itemsize].view(dt).reshape(shape)
+            return np.frombuffer(raw[off : off + count * dt.itemsize].tobytes(), dtype=dt).reshape(shape).copy()
+    return np.load(io.BytesIO(raw.tobytes()), allow_pickle=False)
+
+
+def load_npy_view(body) -> np.ndarray:
+    """`np.load` of raw `.npy` bytes as a VIEW into `body` where the layout allows it (C order, no objects, aligned data):
+    a 3 MB query batch is not copied once more on its way to the device.  Anything else goes through `np.load`."""
+    mv = memoryview(body)
+    if bytes(mv[:8]) == b"\x93NUMPY\x01\x00":
+        head = io.BytesIO(bytes(mv[:65546]))
+        head.seek(8)
+        shape, fortran, dt = np.lib.format.read_array_header_1_0(head)
+        off = head.tell()
+        count = int(np.prod(shape, dtype=np.int64))
+        if not dt.hasobject and not fortran and off + count * dt.itemsize <= mv.nbytes and off % dt.itemsize == 0:
+            return np.frombuffer(mv, dtype=dt, count=count, offset=off).reshape(shape)
+    return np.load(io.BytesIO(bytes(mv)), allow_pickle=False)

@@ -28,13 +28,102 @@ class HipMipsClient(base.SearchClient):
 
     requires_vectors = True
 
-    def __init__(self, host: str = "http://localhost", port: int = 7678, binary: bool = False, forward_subset_ids: bool = False):
+    def __init__(self, host: str = "http://localhost", port: int = 7678, binary: bool = False, forward_subset_ids: bool = False,
+                 wire_dtype: str | None = None):
         self.host = host
         self.port = port
         self.binary = binary  # use the raw-bytes route (`/raw-search`) instead of base64-in-JSON (`/fast-search`)
         # The reference's faiss client drops `subset_ids`; set this to let the GPU index honour them (the server must
         # have been started with `--subset-ids-path`).
         self.forward_subset_ids = forward_subset_ids
+        # "float16": send the queries as float16 (half the bytes on the wire).  Exact for a float16 store - the library rounds
+        # float32 queries to the store dtype anyway (round to nearest even, like NumPy) - so only set it for such a store.
+        self.wire_dtype = wire_dtype
+        self._session = None  # per process: a `requests.Session` keeps ONE connection open instead of a TCP handshake per batch
+        self._session_pid = -1
+        self._conn, self._conn_pid = None, -1  # the hot routes' persistent `http.client` connection
+
+    def __getstate__(self) -> dict:
+        state = dict(self.__dict__)
+        state["_session"] = None  # sockets do not pickle: a DataLoader worker opens its own on first use
+        state["_session_pid"] = -1
+        state["_conn"], state["_conn_pid"] = None, -1
+        return state
+
+    def __setstate__(self, state: dict) -> None:
+        self.__dict__.update(state)
+        self.__dict__.setdefault("wire_dtype", None)
+        self._session = None
+        self._session_pid = -1
+        self._conn, self._conn_pid = None, -1
+
+    @property
+    def session(self) -> requests.Session:
+        if self._session is None or self._session_pid != os.getpid():  # a forked worker must not share its parent's socket
+            self._session = requests.Session()
+            self._session_pid = os.getpid()
+        return self._session
+
+    def _post(self, path: str, body, content_type: str, timeout: float) -> tuple[int, "http.client.HTTPMessage", bytes]:
+        """POST on this process's persistent connection (`http.client`: ~half the per-request cost of `requests` for multi-MB
+        bodies - no chunked iteration over the upload, the reply is read in one piece).  A connection the server closed while it
+        was idle is re-opened once; failures surface as the `requests` exceptions callers of the reference client expect."""
+        import http.client
+        import socket
+
+        for attempt in (0, 1):
+            conn = self._connection(timeout)
+            try:
+                conn.request("POST", path, body=body, headers={"content-type": content_type})
+                resp = conn.getresponse()
+                return resp.status, resp.headers, resp.read()
+            except socket.timeout as exc:
+                self._drop_connection()
+                raise requests.exceptions.ReadTimeout(f"POST {self.url}{path} timed out after {timeout} s") from exc
+            except (http.client.HTTPException, OSError) as exc:
+                self._drop_connection()
+                if attempt == 1 or isinstance(exc, ConnectionRefusedError):
+                    raise requests.exceptions.ConnectionError(f"POST {self.url}{path}: {exc}") from exc
+        raise AssertionError("unreachable")
+
+    def _connection(self, timeout: float):
+        import http.client
+        import urllib.parse
+
+        if self._conn is None or self._conn_pid != os.getpid():  # a forked / unpickled worker opens its own socket
+            u = urllib.parse.urlsplit(self.host if "://" in self.host else "http://" + self.host)
+            cls = http.client.HTTPSConnection if u.scheme == "https" else http.client.HTTPConnection
+            self._conn = cls(u.hostname, self.port, timeout=timeout)
+            self._conn_pid = os.getpid()
+        elif self._conn.sock is not None:
+            self._conn.sock.settimeout(timeout)
+        return self._conn
+
+    def _drop_connection(self) -> None:
+        if self._conn is not None:
+            try:
+                self._conn.close()
+            finally:
+                self._conn = None
+
+    @staticmethod
+    def _raise_for_status(status: int, data: bytes, url: str) -> None:
+        if status < 400:
+            return
+        try:  # the reference client prints the server's trace before raising (client.py:81-88)
+            import json
+
+            print(json.loads(data)["detail"], file=sys.stderr)
+        except Exception:
+            print(data[:2000].decode("utf-8", "replace"), file=sys.stderr)
+        kind = "Client Error" if status < 500 else "Server Error"
+        raise requests.exceptions.HTTPError(f"{status} {kind} for url: {url}")
+
+    def _wire(self, vector: np.ndarray) -> np.ndarray:
+        v = np.asarray(vector)
+        if self.wire_dtype is not None and v.dtype != np.dtype(self.wire_dtype):
+            v = v.astype(self.wire_dtype)
+        return np.ascontiguousarray(v)
 
     def __repr__(self) -> str:
         return f"{type(self).__name__}[{self.url}](requires_vectors={self.requires_vectors})"
@@ -45,8 +134,9 @@ class HipMipsClient(base.SearchClient):
 
     def ping(self, timeout: float = 120) -> bool:
         try:
-            response = requests.get(f"{self.url}/", timeout=timeout)
+            response = self.session.get(f"{self.url}/", timeout=timeout)
         except requests.exceptions.ConnectionError:
+            self._session = None
             return False
         response.raise_for_status()
         return "OK" in response.text
@@ -75,36 +165,25 @@ class HipMipsClient(base.SearchClient):
         extra: dict = {"top_k": top_k}
         if self.forward_subset_ids and subset_ids is not None:
             extra["subset_ids"] = [list(map(str, s)) for s in subset_ids]
-        # the same JSON document `requests.post(json=...)` would send, assembled without encoding the 4 MB field
-        body = io.json_body({"vectors": io.serialize_np_array(np.asarray(vector))}, extra)
-        response = requests.post(f"{self.url}/fast-search", data=body, headers={"content-type": "application/json"}, timeout=timeout)
-        try:
-            response.raise_for_status()
-        except requests.exceptions.HTTPError:
-            try:
-                print(response.json()["detail"], file=sys.stderr)
-            except Exception:
-                print(response.text, file=sys.stderr)
-            raise
-        data = io.parse_json_body(response.content, ("scores", "indices"))
-        return vt.RetrievalBatch.cast(
-            indices=io.deserialize_np_array(data["indices"]),
-            scores=io.deserialize_np_array(data["scores"]),
-            labels=None,
-            meta={"time": time.time() - start},
-        )
+        # the same JSON document `requests.post(json=...)` would send: the base64 text is written straight into the body buffer
+        body = io.json_body_with_arrays({"vectors": self._wire(vector)}, extra)
+        status, _, content = self._post("/fast-search", body, "application/json", timeout)
+        self._raise_for_status(status, content, f"{self.url}/fast-search")
+        small, spans = io.find_payload_spans(content, ("scores", "indices"))
+        take = lambda key: io.deserialize_np_array_span(content, *spans[key]) if key in spans else io.deserialize_np_array(small[key])  # noqa: E731
+        return vt.RetrievalBatch.cast(indices=take("indices"), scores=take("scores"), labels=None, meta={"time": time.time() - start})
 
 
     def _search_binary(self, vector: np.ndarray, top_k: int, timeout: float, start: float) -> vt.RetrievalBatch:
-        import io as _io
-
-        buf = _io.BytesIO()
-        np.save(buf, vector, allow_pickle=False)
-        response = requests.post(f"{self.url}/raw-search", params={"top_k": top_k}, data=buf.getvalue(),
-                                 headers={"content-type": "application/octet-stream"}, timeout=timeout)
-        response.raise_for_status()
-        nq, k = int(response.headers["x-nq"]), int(response.headers["x-k"])
-        raw = response.content
+        v = self._wire(vector)
+        head = io.npy_header(v)
+        body = bytearray(len(head) + v.nbytes)  # the `.npy` bytes np.save would write, assembled with one copy of the data
+        body[: len(head)] = head
+        if v.nbytes:
+            np.frombuffer(body, dtype=np.uint8, offset=len(head))[:] = v.reshape(-1).view(np.uint8)
+        status, headers, raw = self._post(f"/raw-search?top_k={int(top_k)}", body, "application/octet-stream", timeout)
+        self._raise_for_status(status, raw, f"{self.url}/raw-search")
+        nq, k = int(headers["x-nq"]), int(headers["x-k"])
         scores = np.frombuffer(raw, dtype=np.float32, count=nq * k).reshape(nq, k).copy()
         indices = np.frombuffer(raw, dtype=np.int64, count=nq * k, offset=nq * k * 4).reshape(nq, k).copy()
         return vt.RetrievalBatch(scores=scores, indices=indices, labels=None, meta={"time": time.time() - start})
@@ -143,9 +222,11 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         devices: None | list[int] = None,
         serve_on_gpu: bool = True,  # noqa: ARG002 - accepted for call-site compatibility: this engine only exists on the GPU
         group_backend: str = "nccl",  # with `devices`: "nccl" (RCCL, one GPU per worker) or "gloo" (host-staged; workers may share a GPU)
+        micro_batch_wait_ms: float = 0.0,  # > 0: the server fuses requests that arrive within this window into one corpus scan
+        http: str = "asyncio",  # the server's HTTP shell: "asyncio" (in-tree, default) or "uvicorn" (FastAPI)
     ):
         super().__init__(skip_setup=skip_setup, free_resources=free_resources)
-        self.vectors_path = pathlib.Path(vectors_path)
+        self.vectors_path = vectors_path if str(vectors_path).startswith("synthetic:") else pathlib.Path(vectors_path)
         self.logging_level = logging_level
         self.host = host
         self.port = find_available_port() if port < 0 else port
@@ -156,6 +237,8 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         # /root/reference/src/vod_search/faiss_search/client.py:118-137, server.py:51-54)
         self.devices = None if devices is None else [int(d) for d in devices]
         self.group_backend = group_backend
+        self.micro_batch_wait_ms = float(micro_batch_wait_ms)
+        self.http = http
 
     def _make_env(self) -> dict[str, str]:
         env = copy(dict(os.environ))
@@ -166,11 +249,13 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
     def _make_cmd(self) -> list[str]:
         return [
             sys.executable, "-m", "vod_amd.search.server",
-            "--vectors-path", str(self.vectors_path.absolute()),
+            "--vectors-path", str(self.vectors_path) if str(self.vectors_path).startswith("synthetic:") else str(self.vectors_path.absolute()),
             "--host", str(self.host),
             "--port", str(self.port),
             "--logging-level", str(self.logging_level),
             "--dtype", self.dtype,
+            "--http", self.http,
+            *(["--micro-batch-wait-ms", str(self.micro_batch_wait_ms)] if self.micro_batch_wait_ms > 0 else []),
             *(["--devices", ",".join(map(str, self.devices)), "--group-backend", self.group_backend]
               if self.devices is not None else ["--device", str(self.device)]),
         ]

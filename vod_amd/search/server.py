@@ -21,7 +21,7 @@ import traceback
 
 import numpy as np
 import pydantic
-from fastapi import FastAPI, HTTPException, Request, Response
+from fastapi import FastAPI, Request, Response
 from fastapi.concurrency import run_in_threadpool
 
 from vod_amd import io
@@ -120,83 +120,156 @@ class MicroBatcher:
                         fut.set_exception(exc)
 
 
-def create_app(engine, micro_batch_wait_ms: float = 0.0) -> FastAPI:
-    """Build the FastAPI app around a search engine.  Requests are serialised (one GPU stream, like the
-    reference's single uvicorn worker running faiss synchronously, server.py:69,78,98) or, with
-    `micro_batch_wait_ms > 0`, fused into shared GPU batches by `MicroBatcher`."""
-    app = FastAPI()
-    lock = threading.Lock()
-    batcher = MicroBatcher(engine, max_wait_s=micro_batch_wait_ms / 1e3, lock=lock) if micro_batch_wait_ms > 0 else None
+class Endpoints:
+    """Routes, validation and error mapping of the search service, independent of the HTTP shell around them.
 
-    def _search(query_vec: np.ndarray, top_k: int, subset_ids=None) -> tuple[np.ndarray, np.ndarray]:
+    `handle(method, path, query, body)` -> (status, content type, payload bytes-like, extra headers).  Both shells - the asyncio
+    server of `vod_amd.search.fastserver` (production) and the FastAPI app of `create_app` (ASGI hosting, tests) - answer with
+    exactly what this returns, so the contract is the reference's whatever carries it:
+      422 + `{"detail": [...]}` for a document that fails the pydantic model (`extra="forbid"`, wrong types: models.py:43-79),
+      500 + `{"detail": <trace>}` for a failing search (server.py:89-91), 404 / 405 for unknown routes.
+    Requests are serialised (one GPU stream, like the reference's single uvicorn worker running faiss synchronously,
+    server.py:69,78,98) or, with `micro_batch_wait_ms > 0`, fused into shared GPU batches by `MicroBatcher`."""
+
+    def __init__(self, engine, micro_batch_wait_ms: float = 0.0):
+        self.engine = engine
+        self.lock = threading.Lock()
+        self.batcher = MicroBatcher(engine, max_wait_s=micro_batch_wait_ms / 1e3, lock=self.lock) if micro_batch_wait_ms > 0 else None
+
+    # -- the search itself --------------------------------------------------------------------------------------------
+    def search(self, query_vec: np.ndarray, top_k: int, subset_ids=None) -> tuple[np.ndarray, np.ndarray]:
         if query_vec.ndim != 2:
             raise ValueError(f"Expected 2D array, got {query_vec.ndim}D array")
         if subset_ids is not None and any(len(s) for s in subset_ids):
             if len(subset_ids) != len(query_vec):
                 raise ValueError("`subset_ids` must have one list per query")
-            with lock:
-                scores, indices = engine.search(query_vec, top_k, subset_ids=subset_ids)
-        elif batcher is not None:
-            scores, indices = batcher.search(query_vec, top_k)
+            with self.lock:
+                scores, indices = self.engine.search(query_vec, top_k, subset_ids=subset_ids)
+        elif self.batcher is not None:
+            scores, indices = self.batcher.search(query_vec, top_k)
         else:
-            with lock:
-                scores, indices = engine.search(query_vec, top_k)
+            with self.lock:
+                scores, indices = self.engine.search(query_vec, top_k)
         return np.asarray(scores, dtype=np.float32), np.asarray(indices, dtype=np.int64)
+
+    # -- routes -------------------------------------------------------------------------------------------------------
+    def health(self) -> str:
+        return "ERROR: Index is empty" if self.engine.ntotal == 0 else "OK"
+
+    def legacy_search(self, document: dict) -> dict:
+        """POST /search (server.py:68-73): JSON lists in, JSON lists out."""
+        query = SearchQuery(**document)
+        scores, indices = self.search(np.asarray(query.vectors, dtype=np.float32), query.top_k)
+        rows = [[(None if np.isneginf(v) else float(v)) for v in r] for r in scores]
+        return SearchResponse(scores=rows, indices=indices.tolist()).model_dump()
+
+    def fast_search(self, body) -> bytearray:
+        """POST /fast-search (server.py:76-91).  The multi-megabyte base64 field is located in the body, validated as the
+        `str` the model asks for, and decoded where it lies; the reply's base64 text is written straight into its buffer."""
+        small, spans = io.find_payload_spans(body, ("vectors",))
+        query = FastSearchQuery(**small)  # raises pydantic.ValidationError -> 422
+        try:
+            vectors = io.deserialize_np_array_span(body, *spans["vectors"]) if "vectors" in spans else io.deserialize_np_array(query.vectors)
+            scores, indices = self.search(vectors, query.top_k, query.subset_ids)
+            return io.json_body_with_arrays({"scores": scores, "indices": indices})
+        except Exception as exc:
+            raise _SearchFailed(traceback.format_exc()) from exc
+
+    def raw_search(self, body, top_k: int) -> tuple[bytes, dict]:
+        """POST /raw-search?top_k=K (not in the reference): body = raw `.npy` bytes of the [nq, d] queries (float32
+        or float16), reply = raw bytes `scores float32 [nq, k]` followed by `indices int64 [nq, k]`; shapes in the headers."""
+        try:
+            scores, indices = self.search(io.load_npy_view(body), top_k)
+            scores, indices = np.ascontiguousarray(scores), np.ascontiguousarray(indices)
+            payload = bytearray(scores.nbytes + indices.nbytes)
+            if scores.nbytes:
+                np.frombuffer(payload, dtype=np.uint8, count=scores.nbytes)[:] = scores.reshape(-1).view(np.uint8)
+                np.frombuffer(payload, dtype=np.uint8, offset=scores.nbytes)[:] = indices.reshape(-1).view(np.uint8)
+            return payload, {"x-nq": str(scores.shape[0]), "x-k": str(scores.shape[1])}
+        except Exception as exc:
+            raise _SearchFailed(traceback.format_exc()) from exc
+
+    def handle(self, method: str, path: str, query: dict, body) -> tuple[int, str, "bytes | bytearray", dict]:
+        import json
+
+        js = "application/json"
+        try:
+            if path == "/":
+                if method != "GET":
+                    return 405, js, b'{"detail":"Method Not Allowed"}', {}
+                return 200, js, json.dumps(self.health()).encode(), {}
+            if path not in ("/search", "/fast-search", "/raw-search"):
+                return 404, js, b'{"detail":"Not Found"}', {}
+            if method != "POST":
+                return 405, js, b'{"detail":"Method Not Allowed"}', {}
+            if path == "/fast-search":
+                return 200, js, self.fast_search(body), {}
+            if path == "/raw-search":
+                try:
+                    top_k = int(query.get("top_k", 3))
+                except ValueError:
+                    return 422, js, b'{"detail":"top_k must be an integer"}', {}
+                payload, headers = self.raw_search(body, top_k)
+                return 200, "application/octet-stream", payload, headers
+            try:
+                document = json.loads(bytes(body))
+                if not isinstance(document, dict):
+                    raise ValueError("expected a JSON object")
+            except ValueError as exc:
+                return 422, js, json.dumps({"detail": f"invalid request body: {exc}"}).encode(), {}
+            try:
+                return 200, js, json.dumps(self.legacy_search(document)).encode(), {}
+            except pydantic.ValidationError:
+                raise
+            except Exception:
+                return 500, js, json.dumps({"detail": traceback.format_exc()}).encode(), {}
+        except pydantic.ValidationError as exc:
+            return 422, js, json.dumps({"detail": exc.errors(include_url=False, include_input=False)}, default=str).encode(), {}
+        except _SearchFailed as exc:
+            return 500, js, json.dumps({"detail": str(exc)}).encode(), {}
+        except ValueError as exc:  # a body that is not a JSON object
+            return 422, js, json.dumps({"detail": f"invalid request body: {exc}"}).encode(), {}
+
+
+class _SearchFailed(RuntimeError):
+    """A request that parsed but whose search (or payload decoding) raised: HTTP 500 with the formatted trace."""
+
+
+def create_app(engine, micro_batch_wait_ms: float = 0.0) -> FastAPI:
+    """The same service as an ASGI app (FastAPI): `Endpoints` behind starlette's request / response objects."""
+    app = FastAPI()
+    endpoints = Endpoints(engine, micro_batch_wait_ms)
+    app.state.endpoints = endpoints
+
+    def _respond(result) -> Response:
+        status, ctype, payload, headers = result
+        return Response(content=bytes(payload) if isinstance(payload, bytearray) else payload, status_code=status, media_type=ctype, headers=headers)
 
     @app.get("/")
     def health_check() -> str:
-        if engine.ntotal == 0:
-            return "ERROR: Index is empty"
-        return "OK"
+        return endpoints.health()
 
     @app.post("/search")
-    def search(query: SearchQuery) -> SearchResponse:
-        try:
-            scores, indices = _search(np.asarray(query.vectors, dtype=np.float32), query.top_k)
-            rows = [[(None if np.isneginf(v) else float(v)) for v in r] for r in scores]
-            return SearchResponse(scores=rows, indices=indices.tolist())
-        except Exception as exc:
-            raise HTTPException(status_code=500, detail=traceback.format_exc()) from exc
+    async def search(request: Request) -> Response:
+        return _respond(await run_in_threadpool(endpoints.handle, "POST", "/search", {}, await request.body()))
 
     @app.post("/fast-search", response_model=FastSearchResponse)
     async def fast_search(request: Request) -> Response:
-        """Same contract as the reference's route (JSON in, JSON out, `FastSearchQuery` / `FastSearchResponse`
-        validation incl. `extra="forbid"` -> 422), but the multi-megabyte base64 fields are sliced out of / pasted
-        into the JSON text instead of going through a JSON parser, pydantic and `jsonable_encoder`."""
-        try:
-            query = FastSearchQuery(**io.parse_json_body(await request.body(), ("vectors",)))
-        except pydantic.ValidationError as exc:
-            raise HTTPException(status_code=422, detail=exc.errors(include_url=False, include_input=False)) from exc
-        except Exception as exc:
-            raise HTTPException(status_code=422, detail=f"invalid request body: {exc}") from exc
-        try:
-            scores, indices = await run_in_threadpool(_search, io.deserialize_np_array(query.vectors), query.top_k, query.subset_ids)
-            body = io.json_body({"scores": io.serialize_np_array(scores), "indices": io.serialize_np_array(indices)})
-            return Response(content=body, media_type="application/json")
-        except Exception as exc:
-            raise HTTPException(status_code=500, detail=traceback.format_exc()) from exc
+        return _respond(await run_in_threadpool(endpoints.handle, "POST", "/fast-search", {}, await request.body()))
 
     @app.post("/raw-search")
-    async def raw_search(request: Request, top_k: int = 3) -> Response:
-        """Binary transport (not in the reference): body = raw `.npy` bytes of the [nq, d] queries,
-        reply = raw bytes `scores float32 [nq, k]` followed by `indices int64 [nq, k]`; shapes in the headers.
-        Skips base64 + JSON, which is ~6 ms of the reference's per-batch floor."""
-        try:
-            import io as _io
-
-            body = await request.body()
-
-            def _decode_and_search():  # off the event loop: other requests are accepted (and fused) meanwhile
-                return _search(np.load(_io.BytesIO(body), allow_pickle=False), top_k)
-
-            scores, indices = await run_in_threadpool(_decode_and_search)
-            payload = np.ascontiguousarray(scores).tobytes() + np.ascontiguousarray(indices).tobytes()
-            return Response(content=payload, media_type="application/octet-stream",
-                            headers={"x-nq": str(scores.shape[0]), "x-k": str(scores.shape[1])})
-        except Exception as exc:
-            raise HTTPException(status_code=500, detail=traceback.format_exc()) from exc
+    async def raw_search(request: Request) -> Response:
+        return _respond(await run_in_threadpool(endpoints.handle, "POST", "/raw-search", dict(request.query_params), await request.body()))
 
     return app
+
+
+def synthetic_rows(torch, dev, lo: int, hi: int, dim: int, seed: int, chunk: int = 250_000):
+    """Rows [lo, hi) of the `synthetic:` store, chunk by chunk (chunk c is seeded seed + c: any row range of any process agrees)."""
+    for c in range(lo // chunk, (hi + chunk - 1) // chunk):
+        g = torch.Generator(device=dev).manual_seed(seed + c)
+        rows = torch.randn((chunk, dim), generator=g, device=dev, dtype=torch.float32)
+        yield rows[max(lo - c * chunk, 0) : min(hi - c * chunk, chunk)]
 
 
 class HipEngine:
@@ -212,6 +285,10 @@ class HipEngine:
         from vod_amd.index import HipFlatIndex
 
         self._torch = torch
+        if str(vectors_path).startswith("synthetic:"):
+            # measurement aid (tools/bench_http_load.py): `synthetic:ROWSxDIM[:SEED]` = N(0, 1) rows generated on the device, chunk
+            # by chunk - the boundary can be measured in front of a 10 M-row store without writing 15 GB to disk first
+            return self._init_synthetic(str(vectors_path), dtype, device, row_range)
         vectors = store.open_vectors(vectors_path)
         n, d = vectors.shape
         lo, hi = (0, n) if row_range is None else (int(row_range[0]), int(row_range[1]))
@@ -233,6 +310,20 @@ class HipEngine:
             uniq, codes = np.unique(ids.astype(str), return_inverse=True)  # the vocabulary is global: same codes on every shard
             self.vocab = {str(u): i for i, u in enumerate(uniq)}
             self.index.set_row_labels(codes[lo:hi].astype(np.int32))
+
+    def _init_synthetic(self, spec: str, dtype: str, device: int, row_range) -> None:
+        import torch
+
+        from vod_amd.index import HipFlatIndex
+
+        shape, _, seed = spec[len("synthetic:"):].partition(":")
+        n, d = (int(v) for v in shape.lower().split("x"))
+        lo, hi = (0, n) if row_range is None else (int(row_range[0]), int(row_range[1]))
+        self.n_store, self.row_lo, self.row_hi = n, lo, hi
+        self.index = HipFlatIndex(d, max(hi - lo, 1), dtype=getattr(torch, dtype), device=device)
+        self.vocab = {}
+        for rows in synthetic_rows(torch, torch.device("cuda", device), lo, hi, d, int(seed or 0)):
+            self.index.add(rows.to(getattr(torch, dtype)))
 
     @property
     def ntotal(self) -> int:
@@ -286,6 +377,9 @@ def parse_args(argv=None) -> argparse.Namespace:
                    help="comma-separated GPU ids: the store is row-sharded over them, one worker process per GPU on an RCCL "
                         "group, rank 0 answers HTTP (the reference's `--serve-on-gpu` = faiss index_cpu_to_all_gpus, server.py:51-54)")
     p.add_argument("--subset-ids-path", type=str, default=None, help=".npy with one subset id (string) per vector")
+    p.add_argument("--http", type=str, default="asyncio", choices=["asyncio", "uvicorn"],
+                   help="HTTP shell: the in-tree asyncio server (socket reads land in the request buffer, codec in place) or uvicorn + FastAPI")
+    p.add_argument("--http-workers", type=int, default=64, help="handler threads = requests that may be in flight at once")
     p.add_argument("--micro-batch-wait-ms", type=float, default=0.0,
                    help="> 0: fuse requests that arrive within this window into one GPU batch (default: serialise, as the reference)")
     # set by the owner process for its workers
@@ -358,7 +452,6 @@ def run_owner(args: argparse.Namespace, argv: list[str]) -> int:
 def run_worker(args: argparse.Namespace) -> None:
     import torch
     import torch.distributed as dist
-    import uvicorn
 
     from vod_amd import store
     from vod_amd.distributed import ShardedFlatIndex, shard_bounds
@@ -372,7 +465,10 @@ def run_worker(args: argparse.Namespace) -> None:
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{args.master_port}", rank=rank, world_size=world, device_id=dev)
     else:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{args.master_port}", rank=rank, world_size=world)
-    n = store.open_vectors(args.vectors_path).shape[0]
+    if str(args.vectors_path).startswith("synthetic:"):
+        n = int(str(args.vectors_path)[len("synthetic:"):].partition(":")[0].lower().split("x")[0])
+    else:
+        n = store.open_vectors(args.vectors_path).shape[0]
     bounds = shard_bounds(n, world, align=256)
     local = HipEngine(args.vectors_path, dtype=args.dtype, device=devices[rank], subset_ids_path=args.subset_ids_path,
                       row_range=(bounds[rank], bounds[rank + 1]))
@@ -385,8 +481,7 @@ def run_worker(args: argparse.Namespace) -> None:
     else:
         host = re.sub(r"^(http|https)://", "", args.host)
         try:
-            uvicorn.run(create_app(GroupHipEngine(local, dispatcher), micro_batch_wait_ms=args.micro_batch_wait_ms), host=host,
-                        port=args.port, workers=1, log_level=args.logging_level.lower())
+            _serve(GroupHipEngine(local, dispatcher), args, host)
         finally:
             _bounded(dispatcher.stop, 5.0)  # peers that already died (owner gone: PDEATHSIG reaches every rank) cannot hang the exit
     _bounded(dist.destroy_process_group, 5.0)
@@ -403,10 +498,21 @@ def _bounded(fn, seconds: float) -> None:
         os._exit(0)
 
 
+def _serve(engine, args: argparse.Namespace, host: str) -> None:
+    """Run the HTTP shell around `engine` until SIGTERM: the asyncio server (default) or uvicorn + FastAPI (`--http uvicorn`)."""
+    if args.http == "uvicorn":
+        import uvicorn
+
+        uvicorn.run(create_app(engine, micro_batch_wait_ms=args.micro_batch_wait_ms), host=host, port=args.port, workers=1,
+                    log_level=args.logging_level.lower())
+    else:
+        from vod_amd.search import fastserver
+
+        fastserver.run(Endpoints(engine, micro_batch_wait_ms=args.micro_batch_wait_ms), host, args.port, workers=args.http_workers)
+
+
 def main(argv=None) -> None:
     import sys
-
-    import uvicorn
 
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
@@ -416,8 +522,7 @@ def main(argv=None) -> None:
         return run_worker(args)
     engine = HipEngine(args.vectors_path, dtype=args.dtype, device=args.device, subset_ids_path=args.subset_ids_path)
     host = re.sub(r"^(http|https)://", "", args.host)
-    uvicorn.run(create_app(engine, micro_batch_wait_ms=args.micro_batch_wait_ms), host=host, port=args.port, workers=1,
-                log_level=args.logging_level.lower())
+    _serve(engine, args, host)
 
 
 if __name__ == "__main__":
