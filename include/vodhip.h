@@ -53,7 +53,10 @@ int vodhip_index_destroy(vodhip_index_t* index);
 
 /* Append `n_rows` row-major [n_rows, dim] vectors of `src_dtype` living in host or device memory.
  * Values are rounded to the store dtype (round-to-nearest-even).  Synchronous for host sources
- * (the call returns when the rows are resident); async on `stream` for device sources. */
+ * (the call returns when the rows are resident); async on `stream` for device sources.
+ * Host sources are pipelined in 64 MB slices: a pinned / registered source is read in place by the DMA engine; a pageable one
+ * (NumPy array, .npy memory map) is copied into two pinned staging slots by CPU threads (param "ingest_threads", 0 = auto)
+ * while the previous slice is in flight.  Pass the WHOLE array in one call: slicing it on the caller's side serialises the stages. */
 int vodhip_index_add(vodhip_index_t* index, const void* rows, int64_t n_rows, int src_dtype,
                      int src_location, void* stream);
 int vodhip_index_reset(vodhip_index_t* index);               /* ntotal := 0 (capacity kept) */
@@ -111,7 +114,8 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
  *   "growth" (x100: a filter stage covers growth x the rows its threshold was calibrated on, default 800),
  *   "force_safe" (1 = exhaustive schedule: dense chunks of <= cand_cap rows), "tile" (0 = auto; 1 = 128x128, 42 / 46 = small-batch
  *   rings, 8 / 9 = persistent 256x256 without / with the wave stagger), "small_chunk_tiles", "profile" (1 = HIP events around
- *   every filter launch), "kflags" (timing knobs of diagnostic builds).
+ *   every filter launch), "ingest_threads" (CPU threads staging pageable host rows, 0 = auto), "kflags" (timing knobs of
+ *   diagnostic builds).
  * stats (of the search completed by the last vodhip_index_search_finish): "last_overflow" (a candidate list overflowed),
  *   "last_safe_reruns" (recovery passes run), "last_recovered_queries" (queries the first recovery pass re-searched),
  *   "last_chunks" (stages), "last_filter_launches", "last_filter_ns" (with "profile"), "last_recovery_launches",

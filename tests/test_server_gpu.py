@@ -278,3 +278,32 @@ def test_micro_batcher_on_the_gpu_engine_mixes_plain_and_subset_requests(tmp_pat
         rs, ri = topk_desc_tiebreak(full, k)
         np.testing.assert_array_equal(i, ri)
         np.testing.assert_array_equal(s, rs)
+
+
+def test_multi_gpu_group_server_eight_workers_sharing_the_gpu(tmp_path):
+    """The node's full width behind one address: `devices=[0] * 8` on gloo = 8 worker processes (one row shard of a 2 M-row store
+    each, 8 HIP contexts on the box's one GPU), rank 0 answering HTTP.  Request broadcast -> 8 fused local top-k with their row
+    offsets -> ONE packed all-gather -> 8-way HIP merge; ids and scores must equal the oracle over the WHOLE store (integer-valued
+    rows: ties across all seven shard boundaries)."""
+    from oracle.flat_ip import flat_ip_topk
+    from vod_amd import store
+    from vod_amd.search.client import HipMipsClient, HipMipsMaster
+
+    rng = np.random.default_rng(88)
+    n, d, nq, k = 2_000_000, 64, 96, 100
+    x = np.empty((n, d), dtype=np.float16)
+    for lo in range(0, n, 250_000):
+        x[lo : lo + 250_000] = rng.integers(-6, 7, size=(250_000, d), dtype=np.int8)
+    q = rng.integers(-6, 7, size=(nq, d)).astype(np.float32)
+    store.save_vectors(tmp_path / "v.npy", x, dtype=np.float16)
+    rs, ri = flat_ip_topk(q, x, k)
+    with HipMipsMaster(tmp_path / "v.npy", port=-1, logging_level="warning", devices=[0] * 8, group_backend="gloo") as m:
+        c = HipMipsClient(host=m.host, port=m.port)
+        assert c.ping()
+        res = c.search(vector=q, top_k=k)
+        np.testing.assert_array_equal(res.indices, ri)
+        np.testing.assert_array_equal(res.scores, rs)
+        assert len({int(i) * 8 // n for i in ri.ravel()}) == 8, "the answer must draw on every shard"
+        raw = HipMipsClient(host=m.host, port=m.port, binary=True, wire_dtype="float16").search(vector=q[:7], top_k=13)
+        np.testing.assert_array_equal(raw.indices, ri[:7, :13])
+    assert not m.get_client().ping()

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <deque>
+#include <thread>
 #include <vector>
 
 #include "vodhip_internal.h"
@@ -72,7 +73,12 @@ struct vodhip_index {
     int* row_label = nullptr;        // [capacity_pad] subset label per row (optional)
     const int* q_label = nullptr;    // caller-owned device [nq, n_qlab] for the next searches (optional)
     int n_qlab = 0;
-    void* stage_dev = nullptr;  // raw-dtype staging for host ingest
+    // host ingest pipeline: two slots of (pinned host staging, device staging of the raw dtype, completion event), one stream
+    void* stage_dev[2] = {nullptr, nullptr};
+    void* stage_pin[2] = {nullptr, nullptr};
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    int64_t ingest_threads = 0;  // CPU threads that fill the pinned staging slots (0 = auto: min(8, hardware threads))
+    int64_t last_ingest_pinned_src = 0;
     SearchWorkspace ws;
     unsigned int* overflow_host = nullptr;  // pinned, one word per in-flight slot
     unsigned int* ovf_q = nullptr;          // device [MAX_IN_FLIGHT][OVF_ROWS]: which queries of a slot's search overflowed
@@ -383,7 +389,11 @@ int vodhip_index_destroy(vodhip_index_t* ix) {
     for (int i = 0; i < MAX_IN_FLIGHT; ++i)
         if (ix->done[i]) (void)hipEventDestroy(ix->done[i]);
     (void)hipFree(ix->data);
-    (void)hipFree(ix->stage_dev);
+    for (int b = 0; b < 2; ++b) {
+        (void)hipFree(ix->stage_dev[b]);
+        (void)hipHostFree(ix->stage_pin[b]);
+        if (ix->stage_done[b]) (void)hipEventDestroy(ix->stage_done[b]);
+    }
     (void)hipFree(ix->row_label);
     (void)hipFree(ix->ovf_q);
     (void)hipFree(ix->q_map);
@@ -409,16 +419,57 @@ int vodhip_index_add(vodhip_index_t* ix, const void* rows, int64_t n_rows, int s
         return 0;
     }
     if (src_location != VODHIP_HOST) return fail("invalid src_location %d", src_location);
-    if (!ix->stage_dev) HIP_OK(hipMalloc(&ix->stage_dev, STAGE_BYTES));
-    const int64_t rows_per_stage = std::max<int64_t>(1, STAGE_BYTES / (ix->dim * es));
-    for (int64_t r = 0; r < n_rows; r += rows_per_stage) {
-        const int64_t n = std::min(rows_per_stage, n_rows - r);
-        HIP_OK(hipMemcpyAsync(ix->stage_dev, (const char*)rows + (size_t)r * ix->dim * es, (size_t)n * ix->dim * es,
-                              hipMemcpyHostToDevice, stream));
-        HIP_OK(launch_convert_rows(ix->stage_dev, src_dtype, n, ix->dim, ix->data + (size_t)(ix->ntotal + r) * ix->dim_pad,
-                                   ix->dtype, ix->dim_pad, stream));
-        HIP_OK(hipStreamSynchronize(stream));  // the staging buffer is reused by the next slice
+    // Host rows -> HBM, pipelined (round 3; the index is rebuilt every training period, /root/reference/src/vod_exps/recipes/
+    // periodic_training.py:53-96, so ingest time is on the trainer's critical path):
+    //   pageable source (a NumPy array, an .npy memory map, decoded zarr chunks): CPU threads copy slice i + 1 into a pinned staging
+    //   slot while the DMA engine moves slice i and the convert kernel rounds it into the store - two slots, one stream;
+    //   pinned / registered source: the DMA reads it in place, no CPU copy at all.
+    // Round 2 pushed 64 MB slices of pageable memory through hipMemcpyAsync (staged by the runtime, synchronous) and waited after each.
+    hipPointerAttribute_t attr;
+    bool src_pinned = false;
+    if (hipPointerGetAttributes(&attr, rows) == hipSuccess) src_pinned = attr.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();  // an ordinary host pointer is "invalid value" to the runtime: not an error here
+    ix->last_ingest_pinned_src = src_pinned;
+    const int64_t row_bytes = ix->dim * es;
+    const int64_t rows_per_stage = std::max<int64_t>(1, STAGE_BYTES / row_bytes);
+    for (int b = 0; b < 2; ++b) {
+        if (!ix->stage_dev[b]) HIP_OK(hipMalloc(&ix->stage_dev[b], STAGE_BYTES));
+        if (!src_pinned && !ix->stage_pin[b]) HIP_OK(hipHostMalloc(&ix->stage_pin[b], STAGE_BYTES, hipHostMallocDefault));
+        if (!ix->stage_done[b]) HIP_OK(hipEventCreateWithFlags(&ix->stage_done[b], hipEventDisableTiming));
     }
+    int n_thr = (int)ix->ingest_threads;
+    if (n_thr <= 0) n_thr = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    bool used[2] = {false, false};
+    int slot = 0;
+    for (int64_t r = 0; r < n_rows; r += rows_per_stage, slot ^= 1) {
+        const int64_t n = std::min(rows_per_stage, n_rows - r);
+        const size_t bytes = (size_t)n * row_bytes;
+        const char* src = (const char*)rows + (size_t)r * row_bytes;
+        if (used[slot]) HIP_OK(hipEventSynchronize(ix->stage_done[slot]));  // the slot's previous slice has left the staging buffers
+        const void* dma_src = src;
+        if (!src_pinned) {
+            char* dst = (char*)ix->stage_pin[slot];
+            const int t_use = (int)std::min<size_t>((size_t)n_thr, std::max<size_t>(1, bytes >> 20));  // >= 1 MB per thread
+            if (t_use <= 1) {
+                memcpy(dst, src, bytes);
+            } else {
+                std::vector<std::thread> pool;
+                const size_t per = ((bytes + t_use - 1) / t_use + 4095) & ~(size_t)4095;
+                for (int t = 0; t < t_use; ++t) {
+                    const size_t lo = std::min(bytes, (size_t)t * per), hi = std::min(bytes, lo + per);
+                    if (hi > lo) pool.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
+                }
+                for (auto& th : pool) th.join();
+            }
+            dma_src = dst;
+        }
+        HIP_OK(hipMemcpyAsync(ix->stage_dev[slot], dma_src, bytes, hipMemcpyHostToDevice, stream));
+        HIP_OK(launch_convert_rows(ix->stage_dev[slot], src_dtype, n, ix->dim, ix->data + (size_t)(ix->ntotal + r) * ix->dim_pad, ix->dtype,
+                                   ix->dim_pad, stream));
+        HIP_OK(hipEventRecord(ix->stage_done[slot], stream));
+        used[slot] = true;
+    }
+    HIP_OK(hipStreamSynchronize(stream));  // synchronous for host sources: the caller may free `rows` on return
     ix->ntotal += n_rows;
     return 0;
 }
@@ -643,6 +694,9 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
         ix->sample_div = value;
     } else if (!strcmp(key, "profile")) {
         ix->profile = value;
+    } else if (!strcmp(key, "ingest_threads")) {
+        if (value < 0 || value > 256) return fail("ingest_threads must be in [0, 256] (0 = auto)");
+        ix->ingest_threads = value;
     } else if (!strcmp(key, "tile")) {
 #ifdef VODHIP_EXPERIMENTS
         const bool ring_ok = true;  // tiles 10 / 11 / 12: the FILTER kernels of experiment builds
@@ -684,6 +738,8 @@ int vodhip_index_get_stat(const vodhip_index_t* ix, const char* key, int64_t* ou
         *out = ix->sample_div;
     else if (!strcmp(key, "dim_pad"))
         *out = ix->dim_pad;
+    else if (!strcmp(key, "last_ingest_pinned_src"))
+        *out = ix->last_ingest_pinned_src;
     else
         return fail("unknown stat '%s'", key);
     return 0;

@@ -295,11 +295,16 @@ class HipEngine:
         self.n_store, self.row_lo, self.row_hi = n, lo, hi
         self.index = HipFlatIndex(d, max(hi - lo, 1), dtype=getattr(torch, dtype), device=device)
         step = 262144
-        if hasattr(vectors, "iter_row_blocks") and row_range is None:  # zarr store: blocks aligned to its chunk grid, each chunk decoded once
-            for _lo, rows in vectors.iter_row_blocks(step):
+        if hasattr(vectors, "iter_row_blocks") and row_range is None:
+            # zarr store: blocks aligned to its chunk grid, each chunk decoded once, on a thread pool running ahead of the ingest
+            for _lo, rows in vectors.iter_row_blocks():
                 self.index.add(rows if rows.dtype != np.float64 else rows.astype(np.float32))
+        elif isinstance(vectors, np.ndarray) and vectors.dtype != np.float64 and vectors[lo:hi].flags.c_contiguous:
+            # .npy memory map: ONE call - the library overlaps the page-cache reads (CPU threads -> pinned staging), the DMA and
+            # the on-device rounding to fp16 / bf16 over 64 MB slices
+            self.index.add(vectors[lo:hi])
         else:
-            for b0 in range(lo, hi, step):  # H2D in slices; the store converts to fp16/bf16 on the device
+            for b0 in range(lo, hi, step):
                 rows = np.ascontiguousarray(vectors[b0 : min(hi, b0 + step)])
                 self.index.add(rows if rows.dtype != np.float64 else rows.astype(np.float32))
         self.vocab: dict[str, int] = {}

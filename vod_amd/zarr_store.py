@@ -211,12 +211,42 @@ class ZarrVectors:
             raise IndexError(i)
         return self.read_rows(i, i + 1)[0]
 
-    def iter_row_blocks(self, rows_per_block: int = 262144) -> typ.Iterator[tuple[int, np.ndarray]]:
-        """(first row, rows) blocks aligned to the chunk grid: every chunk file is decoded exactly once."""
-        cr = self.chunks[0]
+    def iter_row_blocks(self, rows_per_block: int = 65536, workers: int = 8, prefetch: int = 2) -> typ.Iterator[tuple[int, np.ndarray]]:
+        """(first row, rows) blocks aligned to the chunk grid: every chunk file is decoded exactly once.
+
+        The reference's stores are written with 100-row chunks (ts_factory.py:64-77): 100 k files for a 10 M-row index.  Reading +
+        decompressing them (zlib / zstd / blosc release the GIL) runs on `workers` threads, `prefetch` blocks ahead of the block
+        being consumed, so the consumer - the H2D ingest - never waits for a file."""
+        import collections
+        import concurrent.futures
+
+        n, d = self.shape
+        cr, cc = self.chunks
+        n_cj = (d + cc - 1) // cc
         step = max(cr, rows_per_block // cr * cr)
-        for lo in range(0, self.shape[0], step):
-            yield lo, self.read_rows(lo, lo + step)
+        blocks = [(lo, min(n, lo + step)) for lo in range(0, n, step)]
+        if workers <= 1:
+            for lo, hi in blocks:
+                yield lo, self.read_rows(lo, hi)
+            return
+        with concurrent.futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix="vodhip-zarr") as pool:
+            def submit(block):
+                lo, hi = block
+                return {(ci, cj): pool.submit(self._chunk, ci, cj) for ci in range(lo // cr, (hi - 1) // cr + 1) for cj in range(n_cj)}
+
+            pending: collections.deque = collections.deque()
+            nxt = 0
+            for lo, hi in blocks:
+                while nxt < len(blocks) and len(pending) <= prefetch:
+                    pending.append(submit(blocks[nxt]))
+                    nxt += 1
+                futs = pending.popleft()
+                out = np.empty((hi - lo, d), dtype=self.dtype)
+                for (ci, cj), fut in futs.items():
+                    r0, r1 = max(lo, ci * cr), min(hi, (ci + 1) * cr)
+                    c0, c1 = cj * cc, min(d, (cj + 1) * cc)
+                    out[r0 - lo : r1 - lo, c0:c1] = fut.result()[r0 - ci * cr : r1 - ci * cr, : c1 - c0]
+                yield lo, out
 
 
 def write_zarr_vectors(path: str | pathlib.Path, vectors, dtype=np.float32, chunk_size: int = 100,
