@@ -414,7 +414,8 @@ def roofline_of(m: dict, world: int) -> dict:
 
 def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
     """The regimes next to the headline, timed by the same process in the same run (a few seconds): BASELINE configs[1]
-    (C2), the 1.25 M-row shard each of 8 GPUs holds of C3 with the exchange step on RCCL (one rank gathers from itself),
+    (C2), the 1.25 M-row shard each of 8 GPUs holds of C3 without and with the exchange step on RCCL (one rank gathers from itself:
+    the difference is the per-step cost of the collective call + merge),
     nq = 256 on the headline store (one q-tile) and C3 with rows sorted by topic cluster.  Each entry carries ms/batch,
     q/s and the same roofline record as the headline; a failing side run is reported as {"error": ...} and never touches
     the headline fields."""
@@ -451,6 +452,7 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
     one("C2", rows=1_000_000, nq=256, steps=200, warmup=20)
     one("C3_nq256", rows=args.rows, nq=256, steps=50, warmup=5, index=headline_index, row_lo=headline_row_lo)
     one("C3_clustered", rows=args.rows, nq=args.nq, data="clustered", steps=max(5, args.steps), warmup=3)
+    one("C3_shard_of_8", rows=args.rows // 8, nq=args.nq, steps=100, warmup=10)
     one("C3_shard_of_8_with_exchange", rows=args.rows // 8, nq=args.nq, multi=True, steps=100, warmup=10)
     return out
 

@@ -158,7 +158,7 @@ def test_bench_default_line_carries_the_side_workloads():
     rec = _run_bench("--steps", "3", "--warmup", "1", "--cpu-seconds", "1")
     assert rec["config"]["workload"].startswith("10000000 sections x 768")
     names = [s_["name"] for s_ in rec["side"]]
-    assert names == ["C2", "C3_nq256", "C3_clustered", "C3_shard_of_8_with_exchange"]
+    assert names == ["C2", "C3_nq256", "C3_clustered", "C3_shard_of_8", "C3_shard_of_8_with_exchange"]
     for s_ in rec["side"]:
         assert "error" not in s_, s_
         assert s_["verify"]["recall_at_k_vs_torch_fp32"] == 1.0 and s_["roofline"]["frac"] > 0.05

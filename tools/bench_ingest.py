@@ -101,7 +101,7 @@ def main():
     src = np.random.default_rng(1).standard_normal((zr, a.dim)).astype(np.float32)
     for comp, nrows in ((None, zr), ({"id": "zlib", "level": 1}, zr // 4)):
         path = write_zarr_vectors(tmp / f"z_{'raw' if comp is None else 'zlib'}", src[:nrows], dtype=np.float32, chunk_size=100, compressor=comp)
-        for workers in (1, 8):
+        for workers in (1, 4, 8, 16):
             from vod_amd.zarr_store import ZarrVectors
 
             zv = ZarrVectors(path)

@@ -190,12 +190,8 @@ class ZarrVectors:
         out = np.empty((max(0, hi - lo), d), dtype=self.dtype)
         if hi <= lo:
             return out
-        cr, cc = self.chunks
-        for ci in range(lo // cr, (hi - 1) // cr + 1):
-            r0, r1 = max(lo, ci * cr), min(hi, (ci + 1) * cr)
-            for cj in range((d + cc - 1) // cc):
-                c0, c1 = cj * cc, min(d, (cj + 1) * cc)
-                out[r0 - lo : r1 - lo, c0:c1] = self._chunk(ci, cj)[r0 - ci * cr : r1 - ci * cr, : c1 - c0]
+        cr = self.chunks[0]
+        self._fill_rows(out, lo, lo // cr, (hi - 1) // cr + 1)
         return out
 
     def __getitem__(self, item):
@@ -211,41 +207,65 @@ class ZarrVectors:
             raise IndexError(i)
         return self.read_rows(i, i + 1)[0]
 
-    def iter_row_blocks(self, rows_per_block: int = 65536, workers: int = 8, prefetch: int = 2) -> typ.Iterator[tuple[int, np.ndarray]]:
+    def _fill_rows(self, out: np.ndarray, lo: int, ci_lo: int, ci_hi: int) -> None:
+        """Decode the chunk rows [ci_lo, ci_hi) straight into `out` (whose first row is store row `lo`)."""
+        n, d = self.shape
+        cr, cc = self.chunks
+        hi = lo + out.shape[0]
+        raw_full_width = self.compressor is None and cc >= d and cc == d
+        for ci in range(ci_lo, ci_hi):
+            r0, r1 = max(lo, ci * cr), min(hi, (ci + 1) * cr)
+            if raw_full_width and r0 == ci * cr:
+                # an uncompressed full-width chunk IS a run of output rows: read the file into place (no bytes object, no copy)
+                try:
+                    with open(f"{self.path}/{ci}{self.sep}0", "rb", buffering=0) as f:
+                        got = f.readinto(memoryview(out[r0 - lo : r1 - lo]).cast("B"))
+                    if got != (r1 - r0) * d * self.dtype.itemsize:
+                        raise ValueError(f"chunk {ci}{self.sep}0: short read ({got} bytes)")
+                    continue
+                except FileNotFoundError:
+                    out[r0 - lo : r1 - lo] = self.fill_value
+                    continue
+            for cj in range((d + cc - 1) // cc):
+                c0, c1 = cj * cc, min(d, (cj + 1) * cc)
+                out[r0 - lo : r1 - lo, c0:c1] = self._chunk(ci, cj)[r0 - ci * cr : r1 - ci * cr, : c1 - c0]
+
+    def iter_row_blocks(self, rows_per_block: int = 65536, workers: int = 8, prefetch: int = 2, chunks_per_task: int = 32) -> typ.Iterator[tuple[int, np.ndarray]]:
         """(first row, rows) blocks aligned to the chunk grid: every chunk file is decoded exactly once.
 
         The reference's stores are written with 100-row chunks (ts_factory.py:64-77): 100 k files for a 10 M-row index.  Reading +
-        decompressing them (zlib / zstd / blosc release the GIL) runs on `workers` threads, `prefetch` blocks ahead of the block
-        being consumed, so the consumer - the H2D ingest - never waits for a file."""
+        decompressing them (file reads, zlib / zstd / blosc release the GIL) runs on `workers` threads, `prefetch` blocks ahead of
+        the block being consumed, each task decoding a run of `chunks_per_task` chunks straight into the block's rows - the
+        consumer (the H2D ingest) never waits for a file and nothing is copied twice."""
         import collections
         import concurrent.futures
 
         n, d = self.shape
-        cr, cc = self.chunks
-        n_cj = (d + cc - 1) // cc
+        cr = self.chunks[0]
         step = max(cr, rows_per_block // cr * cr)
         blocks = [(lo, min(n, lo + step)) for lo in range(0, n, step)]
         if workers <= 1:
             for lo, hi in blocks:
-                yield lo, self.read_rows(lo, hi)
+                out = np.empty((hi - lo, d), dtype=self.dtype)
+                self._fill_rows(out, lo, lo // cr, (hi - 1) // cr + 1)
+                yield lo, out
             return
         with concurrent.futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix="vodhip-zarr") as pool:
             def submit(block):
                 lo, hi = block
-                return {(ci, cj): pool.submit(self._chunk, ci, cj) for ci in range(lo // cr, (hi - 1) // cr + 1) for cj in range(n_cj)}
+                out = np.empty((hi - lo, d), dtype=self.dtype)
+                c_lo, c_hi = lo // cr, (hi - 1) // cr + 1
+                return out, [pool.submit(self._fill_rows, out, lo, c, min(c_hi, c + chunks_per_task)) for c in range(c_lo, c_hi, chunks_per_task)]
 
             pending: collections.deque = collections.deque()
             nxt = 0
-            for lo, hi in blocks:
+            for lo, _hi in blocks:
                 while nxt < len(blocks) and len(pending) <= prefetch:
                     pending.append(submit(blocks[nxt]))
                     nxt += 1
-                futs = pending.popleft()
-                out = np.empty((hi - lo, d), dtype=self.dtype)
-                for (ci, cj), fut in futs.items():
-                    r0, r1 = max(lo, ci * cr), min(hi, (ci + 1) * cr)
-                    c0, c1 = cj * cc, min(d, (cj + 1) * cc)
-                    out[r0 - lo : r1 - lo, c0:c1] = fut.result()[r0 - ci * cr : r1 - ci * cr, : c1 - c0]
+                out, futs = pending.popleft()
+                for fut in futs:
+                    fut.result()
                 yield lo, out
 
 
