@@ -41,7 +41,7 @@ def test_single_gpu_without_a_gpu_fails_loudly():
 
 
 def test_kloop_microbenchmark_cross_compiles(tmp_path):
-    """tools/ubench/kloop.hip (the K loop rebuilt from its parts: profiles/README.md) stays buildable for gfx950."""
+    """experiments/ubench/kloop.hip (the K loop rebuilt from its parts: profiles/README.md) stays buildable for gfx950."""
     import pathlib
     import shutil
 
@@ -51,5 +51,5 @@ def test_kloop_microbenchmark_cross_compiles(tmp_path):
     if not pathlib.Path(hipcc).exists():
         pytest.skip("no hipcc")
     out = subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-value", "-c", "-o", str(tmp_path / "kloop.o"),
-                          str(ROOT / "tools" / "ubench" / "kloop.hip")], capture_output=True, text=True, timeout=900)
+                          str(ROOT / "experiments" / "ubench" / "kloop.hip")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
