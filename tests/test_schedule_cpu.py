@@ -30,10 +30,15 @@ def _schedule(n, k, nq, cap=0, dense=0, sdiv=0, growth=0, tile=0, recovery=0, n_
     return np.array(out[: r * 6], dtype=np.int64).reshape(r, 6)
 
 
-def _tile_geometry(nq, tile=0):
+def _tile_geometry(nq, tile=0, n=None, sdiv=0, n_cu=256):
     """(BM rows per tile, rows per lane group, TM rows per wave tile, MI 32-row blocks per wave tile) of the GMAX kernel."""
     if tile == 0:
         tile = 8 if nq > 128 else (46 if nq > 64 else 42)
+        # round 3: with the automatic tile, a bootstrap that samples less than one 256-row tile per CU runs on the 128 x 128 kernel
+        if tile == 8 and n is not None:
+            nq_pad = -(-min(2048, nq) // 256) * 256
+            if (n // max(sdiv or 96, 2) + 255) // 256 * max(1, nq_pad // 256) < n_cu:
+                tile = 1
     if tile in (8, 9):
         return 256, 32, None, None
     if tile == 1:
@@ -41,9 +46,9 @@ def _tile_geometry(nq, tile=0):
     return 256, 16, 64, 2  # 42: 4 x 1 waves, 46: 4 x 2 waves -> 64-row wave tiles either way
 
 
-def _sampled_rows_by_slot(stage, nq, tile=0):
+def _sampled_rows_by_slot(stage, nq, tile=0, n=None):
     """slot -> sorted store rows, by the same tile-row decomposition the kernels use to build their LDS-DMA addresses."""
-    bm, rg, tm, mi = _tile_geometry(nq, tile)
+    bm, rg, tm, mi = _tile_geometry(nq, tile, n)
     n_tiles, rstride, n_groups = int(stage[3]), int(stage[4]), int(stage[5])
     r = np.arange(bm)
     if tm is None:  # persistent 16x16x32 layout: tile row = wm*128 + i*16 + 4*fq + rr
@@ -79,7 +84,7 @@ def _check(n, k, nq, cap=16384, tile=0, **kw):
     if len(boots):
         assert st_[0, 0] == GMAX and np.all(scans[:, 0] == FILTER)
         b = boots[0]
-        bm, rg, _, _ = _tile_geometry(nq, tile)
+        bm, rg, _, _ = _tile_geometry(nq, tile, n, kw.get("sdiv", 0), kw.get("n_cu", 256))
         s_rows = int(b[3]) * bm
         kp = 64
         while kp < k:
@@ -116,7 +121,7 @@ def test_schedule_invariants(n, k, nq, cap, tile):
 def test_bootstrap_sample_is_stratified_distinct_and_in_range(n, k, nq, tile):
     st_ = _schedule(n, k, nq, tile=tile)
     assert st_[0, 0] == GMAX
-    slots, rg = _sampled_rows_by_slot(st_[0], nq, tile)
+    slots, rg = _sampled_rows_by_slot(st_[0], nq, tile, n)
     n_groups, rstride = int(st_[0, 5]), int(st_[0, 4])
     assert sorted(slots) == list(range(n_groups))            # every candidate slot is written by exactly one lane group
     all_rows = np.concatenate([np.array(v) for v in slots.values()])
@@ -126,6 +131,18 @@ def test_bootstrap_sample_is_stratified_distinct_and_in_range(n, k, nq, tile):
         assert len(rows) == rg
         assert [r // stratum for r in rows] == list(range(rg))  # one row of every stratum: tight for sorted / clustered stores too
     assert (n - 1) - all_rows.max() < n_groups * rg  # integer stride: fewer than S rows at the end of the store are beyond the sample
+
+
+def test_small_bootstraps_run_on_the_small_tile_and_the_planner_is_a_pure_function_of_its_arguments():
+    """C2 and a 1.25 M-row shard sample fewer 256-row tiles than the chip has CUs: their bootstrap is planned for the 128 x 128
+    kernel (16-row groups); C3's stays on the persistent kernel (32-row groups).  The CU count is an ARGUMENT of the planner
+    (round-2 advisor: it used to ask the HIP runtime, so the pinned stage lists depended on the host)."""
+    for n, nq, rg in [(1_000_000, 256, 16), (1_250_000, 1024, 16), (10_000_000, 1024, 32), (40_000_000, 512, 32)]:
+        b = _schedule(n, 100 if n < 40_000_000 else 200, nq)[0]
+        assert b[0] == GMAX and b[3] * (128 if rg == 16 else 256) == b[5] * rg, (n, nq, b)
+    a = _schedule(10_000_000, 100, 1024, n_cu=256)
+    assert np.array_equal(a, _schedule(10_000_000, 100, 1024, n_cu=256))
+    assert not np.array_equal(a[0], _schedule(10_000_000, 100, 1024, n_cu=304)[0])  # whole rounds of a 304-CU grid differ
 
 
 def test_recovery_passes_halve_the_stages_and_end_dense():
