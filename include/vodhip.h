@@ -113,8 +113,7 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
  *   scored densely, default 2048), "sample_div" (the threshold bootstrap scores ~ntotal / sample_div sampled rows, default 96),
  *   "growth" (x100: a filter stage covers growth x the rows its threshold was calibrated on, default 800),
  *   "force_safe" (1 = exhaustive schedule: dense chunks of <= cand_cap rows), "tile" (0 = auto; 1 = 128x128, 42 / 46 = small-batch
- *   rings, 8 / 9 = persistent 256x256 without / with the wave stagger), "small_chunk_tiles", "gmax_small" (1 = default: a bootstrap sampling less than one 256-row tile per CU runs on the 128 x 128
- *   kernel; 0 = always on the search's own tile), "profile" (1 = HIP events around
+ *   rings, 8 / 9 = persistent 256x256 without / with the wave stagger), "small_chunk_tiles", "profile" (1 = HIP events around
  *   every filter launch), "ingest_threads" (CPU threads staging pageable host rows, 0 = auto), "kflags" (timing knobs of
  *   diagnostic builds).
  * stats (of the search completed by the last vodhip_index_search_finish): "last_overflow" (a candidate list overflowed),

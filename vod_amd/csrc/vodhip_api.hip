@@ -94,7 +94,6 @@ struct vodhip_index {
     int64_t force_safe = 0;
     int64_t tile = 0;
     int64_t kflags = 0;
-    int64_t gmax_small = 1;      // 1: bootstraps that sample less than one 256-row tile per CU run on the 128 x 128 kernel
     int64_t small_chunk_tiles = 256;  // launches with fewer 256x256 tiles than this (less than one per CU) use the 128x128 kernel
     int n_cu = 256;       // compute units of `device` (read once at create; the planner never touches the runtime)
     int64_t profile = 0;  // 1: bracket every filter launch with HIP events (bench / roofline accounting)
@@ -235,13 +234,6 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad,
     }
 }
 
-// the kernel variant of the GMAX bootstrap (its tile height and group size shape the schedule)
-int choose_gmax_tile(const vodhip_index* ix, int tile, bool auto_tile, int64_t nq_pad) {
-    if (!filter_tile_is_persistent(tile) || !auto_tile || ix->gmax_small == 0) return tile;
-    const int64_t sample_tiles = (ix->ntotal / std::max<int64_t>(ix->sample_div, 2) + 255) / 256 * std::max<int64_t>(1, nq_pad / 256);
-    return sample_tiles < (int64_t)ix->n_cu ? 1 : tile;
-}
-
 int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, int recovery, hipStream_t stream) {
     const int k = ps.k;
     int64_t kp = 64;
@@ -260,9 +252,8 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
     // The bootstrap of a SMALL store (C2, a 1.25 M-row shard) samples fewer 256-row tiles than the chip has CUs: on the persistent
     // kernel ~40-200 workgroups would each run one whole 256 x 256 x dim tile (a ~25 us latency chain) while the other CUs idle.
     // Those bootstraps run on the 128 x 128 kernel instead (4x the workgroups, a quarter of the chain each; 16-row groups).
-    const int gmax_tile = choose_gmax_tile(ix, tile, ix->tile == 0, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), bn));
     std::vector<Stage> stages;
-    make_schedule(ix, k, gmax_tile, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), bn), safe, recovery, stages);
+    make_schedule(ix, k, tile, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), bn), safe, recovery, stages);
     ix->last_chunks = (int64_t)stages.size();
 
     const int q_es = elem_size(ps.q_dtype);
@@ -312,7 +303,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
                 HIP_OK(hipEventRecord(ev0, stream));
             }
             // short FILTER stages do not fill 256 CUs with 256x256 tiles: those launches run on 128x128 tiles, 2 workgroups per CU
-            int tile_c = sg.kind == ST_GMAX ? gmax_tile : tile;
+            int tile_c = tile;
             if (persistent && ix->tile == 0 && sg.kind == ST_FILTER) {  // (nq_pad is a multiple of 256 there, which the 128-wide tile divides)
                 const int64_t tiles256 = ((sg.e - sg.b + 255) / 256) * (nq_pad / 256);
                 if (tiles256 < ix->small_chunk_tiles) tile_c = 1;  // fewer than one 256x256 tile per CU
@@ -669,11 +660,9 @@ int vodhip_debug_schedule(int64_t ntotal, int k, int64_t nq, int64_t cand_cap, i
     if (dense_rows > 0) tmp.dense_rows = round_up(dense_rows, ROW_ALIGN);
     if (sample_div > 0) tmp.sample_div = sample_div;
     tmp.growth_x100 = growth_x100;
-    const bool auto_tile = tile == 0;
     if (tile == 0) tile = nq > 128 ? 8 : (nq > 64 ? 46 : 42);
-    const int64_t nq_pad = round_up(std::min(MAX_NQ_PER_PASS, nq), filter_tile_cols(tile));
     std::vector<Stage> st;
-    make_schedule(&tmp, k, choose_gmax_tile(&tmp, tile, auto_tile, nq_pad), nq_pad, false, recovery_pass, st);
+    make_schedule(&tmp, k, tile, round_up(std::min(MAX_NQ_PER_PASS, nq), filter_tile_cols(tile)), false, recovery_pass, st);
     if ((int)st.size() > max_stages) return fail("%d stages do not fit max_stages=%d", (int)st.size(), max_stages);
     for (size_t i = 0; i < st.size(); ++i) {
         int64_t* o = out + i * 6;
@@ -701,8 +690,6 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
         ix->force_safe = value;
     } else if (!strcmp(key, "small_chunk_tiles")) {
         ix->small_chunk_tiles = value;
-    } else if (!strcmp(key, "gmax_small")) {
-        ix->gmax_small = value;
     } else if (!strcmp(key, "kflags")) {
         ix->kflags = value;
     } else if (!strcmp(key, "sample_div")) {
