@@ -545,7 +545,6 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
         }
     };
     auto tile_row0 = [&](int it) { return row_begin + (xt0 + it * xt_step) * BM; };
-
     int g = 0;  // global slice counter of this workgroup: LDS slot = g & 1
     // waves 0..3 (all waves without STAGGER), per slice:  R(ks0) M(ks0) R(ks1) M(ks1)
     // no zero fill (128 v_mov per tile): the first k32 step of the tile's first slice multiplies into a constant-0 C
@@ -1021,8 +1020,7 @@ hipError_t launch_generic_mode(const FilterLaunch& L, int mode, bool subset) {
 template <int DT, int MODE, bool SUBSET, bool STAGGER>
 hipError_t launch_persistent(const FilterLaunch& L) {
     const int n_qtiles = (int)(L.nq_pad / 256);
-    int dev = 0, n_cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int n_cu = L.ws->n_cu > 0 ? L.ws->n_cu : 256;  // read once at index create: no driver call on the launch path
     const int unit = 8 * n_qtiles;
     const int total = ((L.n_xtiles + 7) / 8) * unit;
     int grid = (n_cu / unit) * unit;

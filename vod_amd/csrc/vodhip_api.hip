@@ -118,7 +118,9 @@ int free_workspace(vodhip_index* ix) {
     (void)hipFree(w.thr_s);
     (void)hipFree(w.thr_key);
     (void)hipFree(w.overflow);
+    const int n_cu = w.n_cu;
     w = SearchWorkspace();
+    w.n_cu = n_cu;
     return 0;
 }
 
@@ -362,6 +364,7 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
     ix->capacity_pad = round_up(capacity_rows, ROW_ALIGN) + 2 * ROW_ALIGN;  // the last tile (up to 384 rows from a 256-aligned start) never reads past the allocation
     ix->dtype = store_dtype;
     if (hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ix->n_cu < 1) ix->n_cu = 256;
+    ix->ws.n_cu = ix->n_cu;
     const size_t bytes = (size_t)ix->capacity_pad * ix->dim_pad * 2;
     hipError_t e = hipMalloc((void**)&ix->data, bytes);
     if (e != hipSuccess) {

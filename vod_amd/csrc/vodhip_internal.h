@@ -67,6 +67,7 @@ struct SearchWorkspace {
     key_t64* thr_key = nullptr;      // [nq_pad] key of the current k-th best (0 until k hits exist)
     unsigned int* overflow = nullptr;  // [1] set when a candidate buffer overflowed
     unsigned int* ovf_q = nullptr;     // [nq] per query: its candidate list overflowed in some stage (set by the select kernel), or NULL
+    int n_cu = 256;                    // compute units of the device (read once at index create)
     int64_t nq_cap = 0;
     int64_t cap = 0;
     int64_t kp = 0;
