@@ -293,32 +293,39 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
         ix->ws.extra.q_map = q_map;
         for (size_t c = 0; c < stages.size(); ++c) {
             const Stage& sg = stages[c];
-            hipEvent_t ev0 = nullptr, ev1 = nullptr;
-            if (ix->profile) {
-                while (ix->ev_pool.size() < ix->ev_used + 2) {
-                    hipEvent_t e;
-                    HIP_OK(hipEventCreate(&e));
-                    ix->ev_pool.push_back(e);
+            // one filter launch, bracketed by profile events (bench / roofline accounting)
+            auto launch_one = [&](int tile_c, int64_t b, int64_t e) -> int {
+                hipEvent_t ev1 = nullptr;
+                if (ix->profile) {
+                    while (ix->ev_pool.size() < ix->ev_used + 2) {
+                        hipEvent_t ev;
+                        HIP_OK(hipEventCreate(&ev));
+                        ix->ev_pool.push_back(ev);
+                    }
+                    hipEvent_t ev0 = ix->ev_pool[ix->ev_used++];
+                    ev1 = ix->ev_pool[ix->ev_used++];
+                    HIP_OK(hipEventRecord(ev0, stream));
                 }
-                ev0 = ix->ev_pool[ix->ev_used++];
-                ev1 = ix->ev_pool[ix->ev_used++];
-                HIP_OK(hipEventRecord(ev0, stream));
-            }
-            // short FILTER stages do not fill 256 CUs with 256x256 tiles: those launches run on 128x128 tiles, 2 workgroups per CU
+                ix->ws.extra.sample_rstride = (int)sg.rstride;
+                // S sampled rows at offset + i * rstride, i < S: the (ntotal - 1) % rstride-ish rows the integer stride leaves out
+                // are split between the head and the tail of the store
+                ix->ws.extra.sample_offset = sg.kind == ST_GMAX ? (int)(((ix->ntotal - 1) - (sg.n_tiles * filter_tile_rows(tile_c) - 1) * sg.rstride) / 2) : 0;
+                ix->ws.extra.sample_groups = (int)sg.n_groups;
+                HIP_OK(launch_filter(ix->dtype, tile_c, sg.kind, ix->data, ws.q_pad, ix->dim_pad, b, e, sg.n_tiles, nq, nq_pad, ws, stream));
+                if (ix->profile) HIP_OK(hipEventRecord(ev1, stream));
+                return 0;
+            };
+            const bool last = c + 1 == stages.size();
             int tile_c = tile;
             if (persistent && ix->tile == 0 && sg.kind == ST_FILTER) {  // (nq_pad is a multiple of 256 there, which the 128-wide tile divides)
-                const int64_t tiles256 = ((sg.e - sg.b + 255) / 256) * (nq_pad / 256);
-                if (tiles256 < ix->small_chunk_tiles) tile_c = 1;  // fewer than one 256x256 tile per CU
+                const int64_t q_tiles = nq_pad / 256;
+                const int64_t x_tiles = (sg.e - sg.b + 255) / 256;
+                // short FILTER stages do not fill the CUs with 256x256 tiles: those launches run on 128x128 tiles, 2 workgroups per CU
+                if (x_tiles * q_tiles < ix->small_chunk_tiles) {
+                    tile_c = 1;
+                }
             }
-            ix->ws.extra.sample_rstride = (int)sg.rstride;
-            // S sampled rows at offset + i * rstride, i < S: the (ntotal - 1) % rstride-ish rows the integer stride leaves out
-            // are split between the head and the tail of the store
-            ix->ws.extra.sample_offset = sg.kind == ST_GMAX ? (int)(((ix->ntotal - 1) - (sg.n_tiles * filter_tile_rows(tile_c) - 1) * sg.rstride) / 2) : 0;
-            ix->ws.extra.sample_groups = (int)sg.n_groups;
-            const bool last = c + 1 == stages.size();
-            HIP_OK(launch_filter(ix->dtype, tile_c, sg.kind, ix->data, ws.q_pad, ix->dim_pad, sg.b, sg.e, sg.n_tiles, nq, nq_pad,
-                                 ws, stream));
-            if (ix->profile) HIP_OK(hipEventRecord(ev1, stream));
+            if (launch_one(tile_c, sg.b, sg.e)) return -1;
             int64_t dense_n = -1;
             int flags = last ? 1 : 0;
             if (sg.kind == ST_DENSE) dense_n = sg.e - sg.b;
