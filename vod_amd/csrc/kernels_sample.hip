@@ -401,6 +401,8 @@ __global__ __launch_bounds__(SM_THREADS) void priority_sample_kernel(SampleArgs 
 }
 
 static hipError_t launch_sample_args(SampleArgs& a, int64_t nq, int max_width, hipStream_t stream) {
+    // more positives than samples cannot be drawn (the reference's numba loop would write past its [k_total] output row there)
+    if (a.k_positive > a.k_total) a.k_positive = a.k_total;
     int P = 256;
     while (P < max_width) P <<= 1;
     a.P_cap = P;
