@@ -117,7 +117,7 @@ def fuzz_sampling(rng):
         assert len(set(v.tolist())) == len(v), "duplicate sample"
     both = np.isfinite(r_lse)
     assert np.array_equal(np.isfinite(lse), both), "finite lse"
-    np.testing.assert_allclose(lse[both], r_lse[both], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(lse[both], r_lse[both], rtol=5e-5, atol=5e-5)  # tree vs sequential float32 sums of up to 4096 terms
     return dict(kind="sampling", nq=nq, n=n, k_pos=k_pos, k_tot=k_tot, temp=temp, support=support)
 
 
@@ -280,17 +280,31 @@ def fuzz_chain(rng):
     # are interchangeable - NumPy's order among equal keys is unspecified, this kernel takes the smaller column - so there the
     # selected SCORES are compared, not the ids behind them
     ids_comparable = temp > 0
-    if ids_comparable:
-        _eq(out.indices.cpu().numpy()[fin], ref["indices"][fin], "chain ids")
+    got_ids, got_s = out.indices.cpu().numpy(), out.scores.cpu().numpy()
     _eq(out.labels.cpu().numpy(), ref["labels"], "chain labels")
+    lab = ref["labels"]
     if ids_comparable:
-        _eq(out.scores.cpu().numpy()[fin], ref["scores"][fin], "chain scores")
-    else:  # scores a few ulp apart can round to the SAME log-probability: equal keys again, so the score multiset per row and class is compared
-        got_s, ref_s = np.where(fin, out.scores.cpu().numpy(), -np.inf), np.where(fin, ref["scores"], -np.inf)
-        lab = ref["labels"]
-        for cls in (True, False):
-            _eq(np.sort(np.where(lab == cls, got_s, -np.inf), axis=1), np.sort(np.where(lab == cls, ref_s, -np.inf), axis=1), f"chain scores (class {cls})")
-    np.testing.assert_allclose(got_w[fin], ref["log_weights"][fin], rtol=2e-4, atol=2e-4)
+        # the same SET of sections per row and class; their order may differ where two priority keys agree to the last ulp
+        # (`log_p - log(noise)` is evaluated with this device's logf, the reference's with NumPy's)
+        for r in range(nq):
+            for cls in (True, False):
+                m_ = fin[r] & (lab[r] == cls)
+                if sorted(got_ids[r][m_].tolist()) != sorted(ref["indices"][r][m_].tolist()):
+                    raise AssertionError(f"chain ids row {r} class {cls}:\n  got {got_ids[r][m_].tolist()}\n  ref {ref['indices'][r][m_].tolist()}")
+    # scores: the multiset per row and class (temperature 0: scores a few ulp apart can round to the SAME log-probability - equal keys)
+    gs, rs = np.where(fin, got_s, -np.inf), np.where(fin, ref["scores"], -np.inf)
+    for cls in (True, False):
+        _eq(np.sort(np.where(lab == cls, gs, -np.inf), axis=1), np.sort(np.where(lab == cls, rs, -np.inf), axis=1), f"chain scores (class {cls})")
+    # log-weights: `log_p - log1p(-exp(-exp(log_p - log_tau)))` is ill-conditioned for inclusion probabilities << 1; the reference's
+    # own float32 and float64 evaluations differ there, and that difference sets the tolerance (as in fuzz_sampling)
+    with np.errstate(all="ignore"):
+        ref64 = osmp.sample_search_results(m_idx, m_scr.astype(np.float64), m_lbl, {}, noise[:, :w].astype(np.float64), total, kpos, temp, support)
+    same = ids_comparable and np.array_equal(np.where(fin, ref64["local"], -1), np.where(fin, ref["local"], -1)) and np.array_equal(got_ids[fin], ref["indices"][fin])
+    if same:
+        cond = np.abs(np.where(fin, ref["log_weights"].astype(np.float64) - ref64["log_weights"], 0.0)).max(axis=1, keepdims=True)
+        tol = 2e-4 + 2e-4 * np.abs(np.where(fin, ref["log_weights"], 0.0)) + 4.0 * cond
+        bad = fin & (np.abs(np.where(fin, got_w.astype(np.float64) - ref["log_weights"], 0.0)) > tol)
+        assert not bad.any(), f"chain log weights: got {got_w[bad][:4]} ref {ref['log_weights'][bad][:4]} fp64 {ref64['log_weights'][bad][:4]}"
     for key in ("lse_pos", "lse_neg"):
         both = np.isfinite(ref[key])
         got = getattr(out, key).cpu().numpy()
@@ -299,7 +313,7 @@ def fuzz_chain(rng):
     settled = (fin | (ref["local"] < 0)).all(axis=1)
     _eq(out.max_sampling_id.cpu().numpy()[settled], ref["max_sampling_id"][settled], "chain rank diagnostic")
     for n in names:
-        if ids_comparable:
+        if same:
             _eq(out.raw_scores[n].cpu().numpy()[fin], ref["raw"][n][fin], f"chain raw {n}")
     if flat:
         fl = collate_on_device(t(l_idx), t(l_lbl), engines, weights, t(noise), total=total, max_pos_sections=kpos, temperature=temp,
