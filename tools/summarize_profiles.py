@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise gpurun_out/<round>/<workload>_* (tools/profile_r2.sh) into profiles/<round>_<workload>_*.
+"""Summarise gpurun_out/<round>/<workload>_* (tools/profile_r3.sh) into profiles/<round>_<workload>_*.
 
 For every workload: the bench line, the rocprofv3 kernel stats CSV, a per-step kernel timeline (from the kernel trace)
 and one JSON with the PMC sums over the filter launches of ONE batch: HBM traffic = FETCH_SIZE * 1024 * 2 (gfx950 reports
