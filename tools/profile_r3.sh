@@ -20,9 +20,9 @@ for w in $LIST; do
   extra="--no-cpu-baseline --no-side"; [ "$w" = "c3" ] && extra=""   # c3 = the default command: headline + side workloads + CPU baseline
   timeout 900 python3 $ROOTD/bench.py $a $extra > $OUT/${w}_bench.json 2> $OUT/${w}_bench.err
   tail -1 $OUT/${w}_bench.json | cut -c1-400
-  [ "$w" = "shardfc" ] && continue
   P="--steps 5 --warmup 2 --no-cpu-baseline --no-verify --no-side"
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${w}_prof -- python3 $ROOTD/bench.py $a $P > $OUT/${w}_prof.log 2>&1
+  [ "$w" = "shardfc" ] && continue   # (the exchange step: kernel trace only - what the RCCL all-gather and the merge cost per step)
   for pass in "sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "tcc1 FETCH_SIZE GRBM_GUI_ACTIVE" "tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
     set -- $pass; name=$1; shift
     timeout 900 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/${w}_pmc_$name -- python3 $ROOTD/bench.py $a --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-side > $OUT/${w}_pmc_$name.log 2>&1
