@@ -1,12 +1,14 @@
 /* A plain C99 consumer of include/vodhip.h: no Python, no torch, no C++.
  * Builds an index from host float32 rows, searches it with device buffers from the HIP runtime's C API, and checks the
- * result against a brute-force loop (integer-valued data: every dot product is exact in fp32; ties -> smaller id).
+ * result against a brute-force loop (integer-valued data: every dot product is exact in fp32; ties -> smaller id); then runs
+ * the collate-side chain (merge -> sampling) through `vodhip_collate` on the SURVEY's hand-written three-engine case.
  * Built and run by tests/test_c_abi.py:  gcc -std=c99 abi_smoke.c -I include -I /opt/rocm/include -lvodhip -lamdhip64 */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "vodhip.h"
 
@@ -25,6 +27,72 @@
             return 1;                                                                \
         }                                                                            \
     } while (0)
+
+/* The collate-side chain through `vodhip_collate`: one struct of device pointers, no Python.  The SURVEY's hand-written case
+ * (section 9, Q3): lookup [4, -1] (labels 1, 0), dense ids [2, 4] scores [.8, .4], sparse ids [8, 2] scores [3, 1], weights 1 / 1
+ *   -> merged ids [4, 2, 8, -1], scores [0, .4, 2, -inf], labels [1, -1, -1, 0]  (min-subtracted, first-seen order, one pad column);
+ * deterministic sampling (temperature 0), 1 positive of 3: the positive 4, then the negatives by score: 8, 2. */
+static int collate_case(void) {
+    const int64_t h_lidx[2] = {4, -1}, h_llbl[2] = {1, 0}, h_didx[2] = {2, 4}, h_sidx[2] = {8, 2};
+    const float h_dscr[2] = {0.8f, 0.4f}, h_sscr[2] = {3.0f, 1.0f}, h_noise[5] = {1.f, 1.f, 1.f, 1.f, 1.f};
+    enum { STRIDE = 5, KT = 3 };
+    char* base = NULL;
+    HIPCHECK(hipMalloc((void**)&base, 16384));
+    HIPCHECK(hipMemset(base, 0, 16384));
+    size_t off = 0;
+#define CARVE(type, count) (type*)(base + (off += 256) - 256 + 0 * (count))
+    int64_t *lidx = CARVE(int64_t, 2), *llbl = CARVE(int64_t, 2), *didx = CARVE(int64_t, 2), *sidx = CARVE(int64_t, 2);
+    float *dscr = CARVE(float, 2), *sscr = CARVE(float, 2), *noise = CARVE(float, 5);
+    int64_t *m_idx = CARVE(int64_t, STRIDE), *m_lbl = CARVE(int64_t, STRIDE);
+    float *m_scr = CARVE(float, STRIDE), *m_rd = CARVE(float, STRIDE), *m_rs = CARVE(float, STRIDE);
+    int32_t* cursor = CARVE(int32_t, 4);
+    int64_t *o_local = CARVE(int64_t, KT), *o_ids = CARVE(int64_t, KT);
+    float *o_scr = CARVE(float, KT), *o_logw = CARVE(float, KT), *o_rd = CARVE(float, KT), *o_rs = CARVE(float, KT), *o_row = CARVE(float, 3);
+    uint8_t* o_lab = CARVE(uint8_t, KT);
+    HIPCHECK(hipMemcpy(lidx, h_lidx, sizeof h_lidx, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(llbl, h_llbl, sizeof h_llbl, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(didx, h_didx, sizeof h_didx, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(sidx, h_sidx, sizeof h_sidx, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dscr, h_dscr, sizeof h_dscr, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(sscr, h_sscr, sizeof h_sscr, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(noise, h_noise, sizeof h_noise, hipMemcpyHostToDevice));
+    vodhip_collate_args_t a;
+    memset(&a, 0, sizeof a);
+    a.lookup_idx = lidx; a.lookup_lbl = llbl; a.k_lookup = 2; a.n_engines = 2; a.nq = 1;
+    a.engine_idx[0] = didx; a.engine_scr[0] = dscr; a.engine_k[0] = 2; a.engine_weight[0] = 1.0f;
+    a.engine_idx[1] = sidx; a.engine_scr[1] = sscr; a.engine_k[1] = 2; a.engine_weight[1] = 1.0f;
+    a.noise = noise; a.noise_stride = STRIDE;
+    a.k_positive = 1; a.k_total = KT; a.max_support_size = -1; a.temperature = 0.0f;
+    a.merged_idx = m_idx; a.merged_lbl = m_lbl; a.merged_scr = m_scr; a.merged_raw[0] = m_rd; a.merged_raw[1] = m_rs; a.row_cursor = cursor;
+    a.out_local = o_local; a.out_ids = o_ids; a.out_scores = o_scr; a.out_log_weights = o_logw; a.out_labels = o_lab;
+    a.out_raw[0] = o_rd; a.out_raw[1] = o_rs; a.out_lse_pos = o_row; a.out_lse_neg = o_row + 1; a.out_max_sampling_id = o_row + 2;
+    CHECK(vodhip_collate(&a, NULL));
+    HIPCHECK(hipDeviceSynchronize());
+    int64_t g_m[STRIDE], g_ids[KT];
+    float g_ms[STRIDE], g_s[KT];
+    uint8_t g_l[KT];
+    HIPCHECK(hipMemcpy(g_m, m_idx, sizeof g_m, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(g_ms, m_scr, sizeof g_ms, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(g_ids, o_ids, sizeof g_ids, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(g_s, o_scr, sizeof g_s, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(g_l, o_lab, sizeof g_l, hipMemcpyDeviceToHost));
+    const int64_t want_m[STRIDE] = {4, 2, 8, -1, -1}, want_ids[KT] = {4, 8, 2};
+    const float want_ms[3] = {0.0f, 0.8f - 0.4f, 3.0f - 1.0f}, want_s[KT] = {0.0f, 3.0f - 1.0f, 0.8f - 0.4f};
+    for (int c = 0; c < STRIDE; ++c)
+        if (g_m[c] != want_m[c] || (c < 3 && g_ms[c] != want_ms[c]) || (c >= 3 && !(isinf(g_ms[c]) && g_ms[c] < 0))) {
+            fprintf(stderr, "collate: merged column %d: (%lld, %g)\n", c, (long long)g_m[c], g_ms[c]);
+            return 1;
+        }
+    for (int j = 0; j < KT; ++j)
+        if (g_ids[j] != want_ids[j] || g_s[j] != want_s[j] || g_l[j] != (j == 0)) {
+            fprintf(stderr, "collate: sample %d: (%lld, %g, %d)\n", j, (long long)g_ids[j], g_s[j], (int)g_l[j]);
+            return 1;
+        }
+    a.n_engines = 9;  /* errors come back through the ABI */
+    if (vodhip_collate(&a, NULL) == 0) { fprintf(stderr, "n_engines = 9 was not rejected\n"); return 1; }
+    (void)hipFree(base);
+    return 0;
+}
 
 int main(void) {
     const int64_t n = 30000, d = 96, nq = 37;
@@ -81,6 +149,7 @@ int main(void) {
         return 1;
     }
     CHECK(vodhip_index_destroy(ix));
+    if (collate_case() != 0) return 1;
     (void)hipFree(dq); (void)hipFree(ds); (void)hipFree(di);
     free(x); free(q); free(hs); free(hi); free(sc);
     printf("C ABI smoke ok\n");
