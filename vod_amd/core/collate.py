@@ -209,8 +209,8 @@ def collate_on_device(
     total = int(total)
     U = nq * total
     flat = bool(in_batch_negatives)
-    if flat and U > 8192:
-        raise ValueError(f"{U} sampled ids in the batch: the one-launch flattening holds at most 8192")
+    if flat and (U > 8192 or total > 1024):
+        raise ValueError(f"{U} sampled ids in the batch ({total} per row): the one-launch flattening holds at most 8192 (1024 per row)")
     if noise is None:
         noise = torch.empty((nq, stride), dtype=torch.float32, device=dev).exponential_(generator=generator)
     elif noise.dtype is not torch.float32 or noise.stride(-1) != 1:

@@ -52,7 +52,8 @@ def flatten_samples(samples: PrioritySampledSections, padding: bool = True, devi
     if samples.batch.labels is None:
         raise ValueError("The `search_results` must have labels.")
     dev = torch.device("cuda", device)
-    if 0 < samples.batch.indices.size <= 8192 and len(samples.raw_scores) <= 5 and samples.batch.indices.ndim == 2:
+    if (0 < samples.batch.indices.size <= 8192 and len(samples.raw_scores) <= 5 and samples.batch.indices.ndim == 2
+            and samples.batch.indices.shape[1] <= 1024):
         return _flatten_one_launch(samples, padding, dev)
     indices = torch.from_numpy(np.ascontiguousarray(samples.batch.indices)).to(dev)
     unique = torch.unique(indices)  # sorted, like np.unique

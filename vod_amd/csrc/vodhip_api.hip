@@ -980,6 +980,7 @@ int vodhip_flatten_inbatch(const int64_t* ids, int64_t n_rows, int n_keys, int n
     if (n_rows < 0 || n_keys < 0 || n_values < 0 || n_values > 8) return fail("invalid sizes (n_values <= 8)");
     if ((labels == nullptr) != (out_labels == nullptr)) return fail("labels and out_labels go together");
     if (n_rows * (int64_t)n_keys > 8192) return fail("%lld ids in the batch: the one-launch flattening holds at most 8192", (long long)(n_rows * n_keys));
+    if (n_keys > 1024) return fail("%d ids per row: the one-launch flattening stages at most 1024 per row in LDS (use vodhip_gather_by_id)", n_keys);
     if (n_rows == 0 || n_keys == 0) return 0;
     if (!ids || !out_unique || (n_values && (!values || !fill || !outs))) return fail("NULL argument");
     for (int v = 0; v < n_values; ++v)
@@ -1063,6 +1064,7 @@ int vodhip_collate(const vodhip_collate_args_t* c, void* stream_) {
     HIP_OK(launch_priority_sample_merged(m, stream));
     if (!c->in_batch_negatives) return 0;
     if (c->nq * (int64_t)c->k_total > 8192) return fail("%lld ids in the batch: the one-launch flattening holds at most 8192", (long long)(c->nq * c->k_total));
+    if (c->k_total > 1024) return fail("k_total=%d: the one-launch flattening stages at most 1024 ids per row", c->k_total);
     if (!c->flat_ids || !c->flat_scores || !c->flat_log_weights || !c->flat_labels) return fail("NULL flattened output");
     const float* values[8];
     float* outs[8];

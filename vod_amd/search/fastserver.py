@@ -23,12 +23,12 @@ _REASONS = {200: "OK", 100: "Continue", 400: "Bad Request", 404: "Not Found", 40
             413: "Content Too Large", 422: "Unprocessable Entity", 431: "Request Header Fields Too Large", 500: "Internal Server Error",
             501: "Not Implemented"}
 MAX_HEAD = 64 * 1024
-MAX_BODY = 1 << 31
+MAX_BODY = 512 << 20  # default cap on Content-Length (a 2048 x 4096 float32 batch is 45 MB of base64): the body buffer is allocated up front
 
 
 class _Connection(asyncio.BufferedProtocol):
-    def __init__(self, endpoints, pool: concurrent.futures.Executor):
-        self.endpoints, self.pool = endpoints, pool
+    def __init__(self, endpoints, pool: concurrent.futures.Executor, max_body: int = MAX_BODY):
+        self.endpoints, self.pool, self.max_body = endpoints, pool, max_body
         self.transport = None
         self.head = bytearray(MAX_HEAD)   # request line + headers (and whatever of the body arrived with them)
         self.head_len = 0
@@ -90,7 +90,7 @@ class _Connection(asyncio.BufferedProtocol):
             n = int(headers.get("content-length", "0"))
         except ValueError:
             return self._fail(400, "malformed Content-Length")
-        if n < 0 or n > MAX_BODY:
+        if n < 0 or n > self.max_body:
             return self._fail(413, "request body too large")
         if method in ("POST", "PUT") and "content-length" not in headers:
             return self._fail(411, "Content-Length required")
@@ -118,6 +118,7 @@ class _Connection(asyncio.BufferedProtocol):
         method, path, query, keep = self.request
         body, self.body, self.body_len, self.filled = self.body, None, 0, 0
         self.busy = True
+        self.transport.pause_reading()  # a pipelined request stays in the socket (and in what `head` already holds) until this one is answered
         loop = asyncio.get_running_loop()
         fut = loop.run_in_executor(self.pool, self.endpoints.handle, method, path, query, body)
         fut.add_done_callback(lambda f: self._reply(f, keep))
@@ -133,7 +134,9 @@ class _Connection(asyncio.BufferedProtocol):
         self.busy = False
         if not keep:
             self.transport.close()
-        elif self.head_len:
+            return
+        self.transport.resume_reading()
+        if self.head_len:
             self._parse_head()  # a pipelined request was already waiting
 
     def _write(self, status: int, ctype: str, payload, extra: dict, keep: bool) -> None:
@@ -154,12 +157,13 @@ class _Connection(asyncio.BufferedProtocol):
         self.transport = None
 
 
-async def serve(endpoints, host: str, port: int, workers: int = 64, ready: "asyncio.Event | None" = None, stop: "asyncio.Event | None" = None) -> None:
+async def serve(endpoints, host: str, port: int, workers: int = 64, ready: "asyncio.Event | None" = None, stop: "asyncio.Event | None" = None,
+                max_body: int = MAX_BODY) -> None:
     """Serve until `stop` is set (or forever).  `workers`: handler threads = requests that may be in flight at once (each DataLoader
     worker of each trainer rank holds one connection: src/vod_dataloaders/realm_dataloader.py:92-118)."""
     loop = asyncio.get_running_loop()
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix="vodhip-http")
-    server = await loop.create_server(lambda: _Connection(endpoints, pool), host=host, port=port, reuse_address=True, backlog=256)
+    server = await loop.create_server(lambda: _Connection(endpoints, pool, max_body), host=host, port=port, reuse_address=True, backlog=256)
     if ready is not None:
         ready.set()
     try:
@@ -173,7 +177,7 @@ async def serve(endpoints, host: str, port: int, workers: int = 64, ready: "asyn
         pool.shutdown(wait=False, cancel_futures=True)
 
 
-def run(endpoints, host: str, port: int, workers: int = 64) -> None:
+def run(endpoints, host: str, port: int, workers: int = 64, max_body: int = MAX_BODY) -> None:
     """Blocking entry point (the server process's main thread): SIGTERM / SIGINT stop it cleanly."""
     import signal
 
@@ -185,6 +189,6 @@ def run(endpoints, host: str, port: int, workers: int = 64) -> None:
                 loop.add_signal_handler(sig, stop.set)
             except (NotImplementedError, RuntimeError):  # pragma: no cover - not the main thread
                 pass
-        await serve(endpoints, host, port, workers=workers, stop=stop)
+        await serve(endpoints, host, port, workers=workers, stop=stop, max_body=max_body)
 
     asyncio.run(main())
