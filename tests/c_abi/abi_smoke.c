@@ -34,15 +34,15 @@
  * deterministic sampling (temperature 0), 1 positive of 3: the positive 4, then the negatives by score: 8, 2. */
 static int collate_case(void) {
     const int64_t h_lidx[2] = {4, -1}, h_llbl[2] = {1, 0}, h_didx[2] = {2, 4}, h_sidx[2] = {8, 2};
-    const float h_dscr[2] = {0.8f, 0.4f}, h_sscr[2] = {3.0f, 1.0f}, h_noise[5] = {1.f, 1.f, 1.f, 1.f, 1.f};
-    enum { STRIDE = 5, KT = 3 };
+    const float h_dscr[2] = {0.8f, 0.4f}, h_sscr[2] = {3.0f, 1.0f}, h_noise[7] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    enum { STRIDE = 7, KT = 3 };  /* stride = k_lookup + sum(engine_k) + 1 */
     char* base = NULL;
     HIPCHECK(hipMalloc((void**)&base, 16384));
     HIPCHECK(hipMemset(base, 0, 16384));
     size_t off = 0;
 #define CARVE(type, count) (type*)(base + (off += 256) - 256 + 0 * (count))
     int64_t *lidx = CARVE(int64_t, 2), *llbl = CARVE(int64_t, 2), *didx = CARVE(int64_t, 2), *sidx = CARVE(int64_t, 2);
-    float *dscr = CARVE(float, 2), *sscr = CARVE(float, 2), *noise = CARVE(float, 5);
+    float *dscr = CARVE(float, 2), *sscr = CARVE(float, 2), *noise = CARVE(float, 7);
     int64_t *m_idx = CARVE(int64_t, STRIDE), *m_lbl = CARVE(int64_t, STRIDE);
     float *m_scr = CARVE(float, STRIDE), *m_rd = CARVE(float, STRIDE), *m_rs = CARVE(float, STRIDE);
     int32_t* cursor = CARVE(int32_t, 4);
@@ -76,7 +76,7 @@ static int collate_case(void) {
     HIPCHECK(hipMemcpy(g_ids, o_ids, sizeof g_ids, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(g_s, o_scr, sizeof g_s, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(g_l, o_lab, sizeof g_l, hipMemcpyDeviceToHost));
-    const int64_t want_m[STRIDE] = {4, 2, 8, -1, -1}, want_ids[KT] = {4, 8, 2};
+    const int64_t want_m[STRIDE] = {4, 2, 8, -1, -1, -1, -1}, want_ids[KT] = {4, 8, 2};
     const float want_ms[3] = {0.0f, 0.8f - 0.4f, 3.0f - 1.0f}, want_s[KT] = {0.0f, 3.0f - 1.0f, 0.8f - 0.4f};
     for (int c = 0; c < STRIDE; ++c)
         if (g_m[c] != want_m[c] || (c < 3 && g_ms[c] != want_ms[c]) || (c >= 3 && !(isinf(g_ms[c]) && g_ms[c] < 0))) {
