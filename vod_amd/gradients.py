@@ -35,28 +35,28 @@ class _RetrievalLoss(torch.autograd.Function):
         if not q.is_cuda:
             raise _native.NativeLibraryError("RetrievalGradients needs device tensors (there is no CPU path)")
         enc = q.dtype if q.dtype in (torch.float16, torch.bfloat16, torch.float32) else torch.float32
-        qc = q.detach().to(enc).contiguous()
-        sc = s.detach().to(enc).contiguous()
+        as_ = lambda t, dt: t.detach() if (t.dtype is dt and t.is_contiguous()) else t.detach().to(dt).contiguous()  # noqa: E731
+        qc = as_(q, enc)
+        sc = as_(s, enc)
         three_d = sc.dim() == 3
         if sc.dim() not in (2, 3):
             raise ValueError(f"Invalid dimension for `section_encoding`: {tuple(sc.shape)}")
         B, H = qc.shape
         D = sc.shape[1] if three_d else sc.shape[0]
-        score_c = score.detach().float().contiguous()
-        rel_c = relevance.detach().long().contiguous()
+        score_c = as_(score, torch.float32)
+        rel_c = as_(relevance, torch.int64)
         if score_c.shape != (B, D) or rel_c.shape != (B, D):
             raise ValueError(f"section__score / section__relevance must be [{B}, {D}]")
-        sparse_c = None if sparse is None else sparse.detach().float().contiguous()
-        dense_c = None if dense is None else dense.detach().float().contiguous()
+        sparse_c = None if sparse is None else as_(sparse, torch.float32)
+        dense_c = None if dense is None else as_(dense, torch.float32)
         dev = q.device
-        scores = torch.empty((B, D), dtype=torch.float32, device=dev)
-        d_scores = torch.empty((B, D), dtype=torch.float32, device=dev)
-        loss = torch.empty((1,), dtype=torch.float32, device=dev)
-        kl = torch.empty((3,), dtype=torch.float32, device=dev)
+        both = torch.empty((2, B, D), dtype=torch.float32, device=dev)  # retriever scores | dLoss/dScores
+        scores, d_scores = both.unbind(0)
+        # loss [1] | kl [3] | auxiliary terms [3] (the library writes all three: NaN where the weight is 0) | pad | row workspace [16 B]
+        small = torch.empty((8 + 16 * B,), dtype=torch.float32, device=dev)
+        loss, kl, aux, work = small[0], small[1:4], small[4:7], small[8:]
         g_type, w_g, w_ss, w_sd = aux_cfg
         any_aux = w_g > 0 or w_ss > 0 or w_sd > 0
-        work = torch.empty((16 * B,), dtype=torch.float32, device=dev)
-        aux = torch.full((3,), float("nan"), dtype=torch.float32, device=dev)
         aux_grad = torch.empty((3, B, D), dtype=torch.float32, device=dev) if any_aux else None
         with torch.cuda.device(dev):
             _native.check(
@@ -72,7 +72,7 @@ class _RetrievalLoss(torch.autograd.Function):
         ctx.save_for_backward(qc, sc, d_scores)
         ctx.meta = (enc, three_d, B, D, H, q.dtype, s.dtype)
         ctx.mark_non_differentiable(scores, kl, aux)
-        return loss.reshape(()), scores, kl, aux
+        return loss, scores, kl, aux
 
     @staticmethod
     def backward(ctx, g_loss, _g_scores, _g_kl, _g_aux):  # noqa: ANN001
@@ -80,7 +80,9 @@ class _RetrievalLoss(torch.autograd.Function):
         qc, sc, d_scores = ctx.saved_tensors
         enc, three_d, B, D, H, q_dt, s_dt = ctx.meta
         dev = qc.device
-        go = g_loss.detach().float().reshape(1).contiguous()
+        go = g_loss.detach()
+        if go.dtype is not torch.float32 or not go.is_contiguous():
+            go = go.float().contiguous()
         dq = torch.empty((B, H), dtype=torch.float32, device=dev)
         ds = torch.empty(tuple(sc.shape), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
@@ -90,7 +92,7 @@ class _RetrievalLoss(torch.autograd.Function):
                     d_scores.data_ptr(), go.data_ptr(), dq.data_ptr(), ds.data_ptr(), _native.current_stream_ptr(dev),
                 )
             )
-        return dq.to(q_dt), ds.to(s_dt), None, None, None, None, None
+        return (dq if q_dt is torch.float32 else dq.to(q_dt)), (ds if s_dt is torch.float32 else ds.to(s_dt)), None, None, None, None, None
 
 
 class RetrievalGradients:
