@@ -625,9 +625,12 @@ def test_asyncio_server_fuses_concurrent_clients():
     try:
         qs = [rng.integers(-4, 5, size=(1 + i % 5, 8)).astype(np.float32) for i in range(32)]
 
+        # ONE client object per route, shared by all threads - as the reference shares its client between executor threads
+        # (sharded_search.py:159-167): each thread gets its own kept-alive connection
+        shared = {b: vclient.HipMipsClient("http://127.0.0.1", port, binary=b) for b in (False, True)}
+
         def one(i):
-            cl = vclient.HipMipsClient("http://127.0.0.1", port, binary=bool(i % 2))
-            return cl.search(vector=qs[i], top_k=3 + i % 4)
+            return shared[bool(i % 2)].search(vector=qs[i], top_k=3 + i % 4)
 
         with concurrent.futures.ThreadPoolExecutor(32) as pool:
             results = list(pool.map(one, range(32)))

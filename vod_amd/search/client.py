@@ -11,6 +11,7 @@ from __future__ import annotations
 import os
 import pathlib
 import sys
+import threading
 import time
 from copy import copy
 
@@ -39,30 +40,28 @@ class HipMipsClient(base.SearchClient):
         # "float16": send the queries as float16 (half the bytes on the wire).  Exact for a float16 store - the library rounds
         # float32 queries to the store dtype anyway (round to nearest even, like NumPy) - so only set it for such a store.
         self.wire_dtype = wire_dtype
-        self._session = None  # per process: a `requests.Session` keeps ONE connection open instead of a TCP handshake per batch
-        self._session_pid = -1
-        self._conn, self._conn_pid = None, -1  # the hot routes' persistent `http.client` connection
+        # Connections are kept open instead of a TCP handshake per batch - ONE PER THREAD and per process: the reference calls a
+        # shared client from several executor threads at once (sharded_search.py:159-167, hybrid_search.py:103-119), and a socket
+        # must not be shared across a fork / an unpickling
+        self._local = threading.local()
 
     def __getstate__(self) -> dict:
         state = dict(self.__dict__)
-        state["_session"] = None  # sockets do not pickle: a DataLoader worker opens its own on first use
-        state["_session_pid"] = -1
-        state["_conn"], state["_conn_pid"] = None, -1
+        state.pop("_local", None)  # sockets do not pickle: a DataLoader worker opens its own on first use
         return state
 
     def __setstate__(self, state: dict) -> None:
         self.__dict__.update(state)
         self.__dict__.setdefault("wire_dtype", None)
-        self._session = None
-        self._session_pid = -1
-        self._conn, self._conn_pid = None, -1
+        self._local = threading.local()
 
     @property
     def session(self) -> requests.Session:
-        if self._session is None or self._session_pid != os.getpid():  # a forked worker must not share its parent's socket
-            self._session = requests.Session()
-            self._session_pid = os.getpid()
-        return self._session
+        loc = self._local
+        if getattr(loc, "session", None) is None or loc.session_pid != os.getpid():  # a forked worker must not share its parent's socket
+            loc.session = requests.Session()
+            loc.session_pid = os.getpid()
+        return loc.session
 
     def _post(self, path: str, body, content_type: str, timeout: float) -> tuple[int, "http.client.HTTPMessage", bytes]:
         """POST on this process's persistent connection (`http.client`: ~half the per-request cost of `requests` for multi-MB
@@ -90,21 +89,23 @@ class HipMipsClient(base.SearchClient):
         import http.client
         import urllib.parse
 
-        if self._conn is None or self._conn_pid != os.getpid():  # a forked / unpickled worker opens its own socket
+        loc = self._local
+        if getattr(loc, "conn", None) is None or loc.conn_pid != os.getpid():  # a forked / unpickled worker opens its own socket
             u = urllib.parse.urlsplit(self.host if "://" in self.host else "http://" + self.host)
             cls = http.client.HTTPSConnection if u.scheme == "https" else http.client.HTTPConnection
-            self._conn = cls(u.hostname, self.port, timeout=timeout)
-            self._conn_pid = os.getpid()
-        elif self._conn.sock is not None:
-            self._conn.sock.settimeout(timeout)
-        return self._conn
+            loc.conn = cls(u.hostname, self.port, timeout=timeout)
+            loc.conn_pid = os.getpid()
+        elif loc.conn.sock is not None:
+            loc.conn.sock.settimeout(timeout)
+        return loc.conn
 
     def _drop_connection(self) -> None:
-        if self._conn is not None:
+        conn = getattr(self._local, "conn", None)
+        if conn is not None:
             try:
-                self._conn.close()
+                conn.close()
             finally:
-                self._conn = None
+                self._local.conn = None
 
     @staticmethod
     def _raise_for_status(status: int, data: bytes, url: str) -> None:
@@ -136,7 +137,7 @@ class HipMipsClient(base.SearchClient):
         try:
             response = self.session.get(f"{self.url}/", timeout=timeout)
         except requests.exceptions.ConnectionError:
-            self._session = None
+            self._local.session = None
             return False
         response.raise_for_status()
         return "OK" in response.text
