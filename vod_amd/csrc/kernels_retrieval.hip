@@ -91,7 +91,8 @@ template <int DT, bool S3D, bool PRE = false>
 __global__ __launch_bounds__(RT_THREADS) void retrieval_forward_kernel(
     const void* __restrict__ q, const void* __restrict__ s, int D, int H, const float* __restrict__ score,
     const int64_t* __restrict__ relevance, const float* __restrict__ sparse, const float* __restrict__ dense,
-    float* __restrict__ retriever_scores, float* __restrict__ d_scores, float* __restrict__ workspace, RetrievalAux aux) {
+    float* __restrict__ retriever_scores, float* __restrict__ d_scores, float* __restrict__ workspace, RetrievalAux aux,
+    const float* __restrict__ pre_slabs = nullptr, int n_slabs = 0, int64_t slab_stride = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qrow = (float*)smem;   // [H]
     float* S = qrow + H;          // [D] scores -> log-probs
@@ -100,8 +101,13 @@ __global__ __launch_bounds__(RT_THREADS) void retrieval_forward_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     if constexpr (PRE) {
-        // 1'. the contraction was done by small_gemm_kernel (MFMA) into `retriever_scores`
-        for (int d = tid; d < D; d += RT_THREADS) S[d] = retriever_scores[b * D + d];
+        // 1'. the contraction was done by small_gemm_kernel (MFMA) in `n_slabs` split-K slabs: summed here in slab order
+        //     (fixed order: bitwise reproducible), no separate reduction launch
+        for (int d = tid; d < D; d += RT_THREADS) {
+            float acc = pre_slabs[b * D + d];
+            for (int z = 1; z < n_slabs; ++z) acc += pre_slabs[(int64_t)z * slab_stride + b * D + d];
+            S[d] = acc;
+        }
         __syncthreads();
     } else {
         for (int h = tid; h < H; h += RT_THREADS) qrow[h] = ld_enc<DT>(q, b * H + h);
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(RT_THREADS) void retrieval_ds_kernel(const void* __
 // Used for the in-batch contraction einsum("bh,dh->bd") and its two gradients when the section encodings are the
 // flattened in-batch set (D = B * n_sections ~ 2048): 0.2 GFLOP, launch-latency bound - the point is one MFMA
 // launch instead of every workgroup re-reading the whole section matrix.
-// Workgroup = 4 waves = 64 x 64 tile of C (wave (wm, wn) owns 32 x 32); K tile 96 staged through LDS as f32.
+// Workgroup = 4 waves = 64 x 64 tile of C (wave (wm, wn) owns 32 x 32); K tile 64 staged through LDS as f32.
 // ------------------------------------------------------------------------------------------------
 typedef float g_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -410,10 +416,9 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const void* __restrict_
                                                          float* __restrict__ C, int64_t ldc, int M, int N, int K,
                                                          const float* __restrict__ alpha_ptr, int k_per_split,
                                                          int64_t c_split_stride) {
-    // K tile 96: the in-batch contraction (K = H = 768) runs 8 staged iterations instead of 24 - each one is a global -> LDS -> MFMA
-    // latency chain with two barriers, and with 32 workgroups for a 64 x 2048 output the chain IS the kernel time (61 -> ~25 us);
-    // the k order of the accumulation is unchanged, so results are bit-identical
-    constexpr int TMN = 64, KT = 96;
+    // K tile 64.  Staging moves 4 consecutive elements of the unit-stride dimension per load (a 16-byte load for f32, 8 bytes for
+    // f16 / bf16) where the tile is interior and the row pitch keeps them aligned; the scalar loop handles edges and odd pitches.
+    constexpr int TMN = 64, KT = 64;
     __shared__ float As[TMN][KT + 1];
     __shared__ float Bs[KT][TMN + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -424,24 +429,61 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(const void* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const bool a_k_fast = sa_k == 1, b_n_fast = sb_n == 1;
-    // split-K: blockIdx.z owns K range [z * k_per_split, ...) and writes its own slab of C (summed by reduce_slabs_kernel
-    // in a fixed order: bitwise reproducible, unlike float atomics)
+    // split-K: blockIdx.z owns K range [z * k_per_split, ...) and writes its own slab of C (summed in a fixed order by the
+    // consumer: bitwise reproducible, unlike float atomics)
     const int k_begin = blockIdx.z * k_per_split;
     const int k_end = min(K, k_begin + k_per_split);
     C += (int64_t)blockIdx.z * c_split_stride;
     K = k_end;
+    // element (r, c) of a [R][Ccols] tile whose unit-stride dimension is `c`: src[(r0 + r) * pitch + c0 + c]
+    auto stage_vec = [&](auto dt_tag, const void* src, int64_t pitch, int r0, int c0, int R_lim, int C_lim, auto store) {
+        constexpr int DT = decltype(dt_tag)::value;
+        const bool vec_ok = (pitch % 4 == 0) && (c0 % 4 == 0) && r0 + TMN <= R_lim && c0 + KT <= C_lim && TMN == KT;
+        if (vec_ok) {
+            for (int e = tid; e < TMN * (KT / 4); e += 256) {
+                const int r = e / (KT / 4), c = (e % (KT / 4)) * 4;
+                const int64_t off = (int64_t)(r0 + r) * pitch + c0 + c;
+                float v[4];
+                if constexpr (DT == 2) {
+                    const float4 t = *(const float4*)((const float*)src + off);
+                    v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+                } else {
+                    const uint2 t = *(const uint2*)((const uint16_t*)src + off);
+                    const unsigned w[2] = {t.x, t.y};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint16_t h = (uint16_t)(w[u >> 1] >> (16 * (u & 1)));
+                        if constexpr (DT == 0) v[u] = (float)__builtin_bit_cast(_Float16, h);
+                        else v[u] = __builtin_bit_cast(float, (unsigned)h << 16);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) store(r, c + u, v[u]);
+            }
+        } else {
+            for (int e = tid; e < TMN * KT; e += 256) {
+                const int r = e / KT, c = e % KT;
+                store(r, c, (r0 + r < R_lim && c0 + c < C_lim) ? ld_enc<DT>(src, (int64_t)(r0 + r) * pitch + c0 + c) : 0.f);
+            }
+        }
+    };
     for (int k0 = k_begin; k0 < k_end; k0 += KT) {
-        // stage A tile [64][32] and B tile [32][64]; consecutive threads follow the unit-stride dimension
-        for (int e = tid; e < TMN * KT; e += 256) {
-            const int m = a_k_fast ? e / KT : e % TMN, k = a_k_fast ? e % KT : e / TMN;
-            const int gm = m0 + m, gk = k0 + k;
-            As[m][k] = (gm < M && gk < K) ? ld_enc<DTA>(A, gm * sa_m + gk * sa_k) : 0.f;
-        }
-        for (int e = tid; e < KT * TMN; e += 256) {
-            const int k = b_n_fast ? e / TMN : e % KT, n = b_n_fast ? e % TMN : e / KT;
-            const int gk = k0 + k, gn = n0 + n;
-            Bs[k][n] = (gk < K && gn < N) ? ld_enc<DTB>(Bm, gk * sb_k + gn * sb_n) : 0.f;
-        }
+        // A tile [64 m][64 k]: rows = m when k is the unit-stride dimension, rows = k when m is
+        if (a_k_fast) stage_vec(std::integral_constant<int, DTA>{}, A, sa_m, m0, k0, M, K, [&](int r, int c, float v) { As[r][c] = v; });
+        else if (sa_m == 1) stage_vec(std::integral_constant<int, DTA>{}, A, sa_k, k0, m0, K, M, [&](int r, int c, float v) { As[c][r] = v; });
+        else
+            for (int e = tid; e < TMN * KT; e += 256) {
+                const int m = e % TMN, k = e / TMN;
+                As[m][k] = (m0 + m < M && k0 + k < K) ? ld_enc<DTA>(A, (m0 + m) * sa_m + (k0 + k) * sa_k) : 0.f;
+            }
+        // B tile [64 k][64 n]
+        if (b_n_fast) stage_vec(std::integral_constant<int, DTB>{}, Bm, sb_k, k0, n0, K, N, [&](int r, int c, float v) { Bs[r][c] = v; });
+        else if (sb_k == 1) stage_vec(std::integral_constant<int, DTB>{}, Bm, sb_n, n0, k0, N, K, [&](int r, int c, float v) { Bs[c][r] = v; });
+        else
+            for (int e = tid; e < KT * TMN; e += 256) {
+                const int k = e % KT, n = e / KT;
+                Bs[k][n] = (k0 + k < K && n0 + n < N) ? ld_enc<DTB>(Bm, (k0 + k) * sb_k + (n0 + n) * sb_n) : 0.f;
+            }
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < KT; kk += 2) {
@@ -472,7 +514,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int n_slabs
 static hipError_t launch_small_gemm(int dta, int dtb, const void* A, int64_t sa_m, int64_t sa_k, const void* B, int64_t sb_k,
                                     int64_t sb_n, float* C, int64_t ldc, int M, int N, int K, const float* alpha,
                                     hipStream_t stream, int n_splits = 1, int64_t c_split_stride = 0) {
-    const int k_per_split = ((K + n_splits - 1) / n_splits + 95) / 96 * 96;
+    const int k_per_split = ((K + n_splits - 1) / n_splits + 63) / 64 * 64;
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64), (unsigned)n_splits);
 #define VOD_SG(X, Y)                                                                                              \
     if (dta == X && dtb == Y) {                                                                                   \
@@ -493,20 +535,34 @@ hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype,
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (!sections_3d) {
         // einsum("bh,dh->bd"): scores[b,d] = sum_h q[b,h] * s[d,h]  ->  A = q [B,H] (k fast), B = s^T (k = h fast)
-        hipError_t e = launch_small_gemm(enc_dtype, enc_dtype, q, H, 1, s, 1, H, retriever_scores, D, (int)B, (int)D, (int)H,
-                                         nullptr, stream);
-        if (e != hipSuccess) return e;
+        // A 64 x 2048 output is 32 workgroups of 64 x 64: each would walk all of K alone (12 global -> LDS -> MFMA rounds, ~60 us,
+        // 7/8 of the chip idle).  K is split over 4 workgroups per tile into slabs of a stream-ordered temporary; the row kernel
+        // sums the slabs in order while it loads its row.
+        const int n_splits = (H >= 512 && B * D <= (int64_t)1 << 22) ? 4 : 1;
+        float* slabs = retriever_scores;
+        if (n_splits > 1) {
+            hipError_t ea = hipMallocAsync((void**)&slabs, (size_t)n_splits * B * D * sizeof(float), stream);
+            if (ea != hipSuccess) return ea;
+        }
+        hipError_t e = launch_small_gemm(enc_dtype, enc_dtype, q, H, 1, s, 1, H, slabs, D, (int)B, (int)D, (int)H, nullptr, stream, n_splits,
+                                         B * D);
+        if (e != hipSuccess) {
+            if (n_splits > 1) (void)hipFreeAsync(slabs, stream);
+            return e;
+        }
 #define VOD_FWDP(DT)                                                                                                  \
     if (enc_dtype == DT) {                                                                                            \
         auto kern = retrieval_forward_kernel<DT, false, true>;                                                        \
         e = allow_dynamic_lds((const void*)kern, 160 * 1024); /* cached: no driver call on the launch path */          \
         if (e != hipSuccess) return e;                                                                                \
         hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(RT_THREADS), lds, stream, q, s, (int)D, (int)H, score,       \
-                           relevance, sparse, dense, retriever_scores, d_scores, workspace, aux);                     \
+                           relevance, sparse, dense, retriever_scores, d_scores, workspace, aux, (const float*)slabs, \
+                           n_splits, (int64_t)(B * D));                                                               \
     }
         VOD_FWDP(0) VOD_FWDP(1) VOD_FWDP(2)
 #undef VOD_FWDP
         e = hipGetLastError();
+        if (n_splits > 1) (void)hipFreeAsync(slabs, stream);  // stream-ordered: released after the row kernel has read it
         if (e != hipSuccess) return e;
         const int64_t n_el = B * D;
         const unsigned blk = (unsigned)std::min<int64_t>(1024, (n_el + RT_THREADS - 1) / RT_THREADS);
@@ -520,7 +576,8 @@ hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype,
         hipError_t e = allow_dynamic_lds((const void*)kern, 160 * 1024);                                               \
         if (e != hipSuccess) return e;                                                                               \
         hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(RT_THREADS), lds, stream, q, s, (int)D, (int)H, score,      \
-                           relevance, sparse, dense, retriever_scores, d_scores, workspace, aux);                    \
+                           relevance, sparse, dense, retriever_scores, d_scores, workspace, aux, (const float*)nullptr, 0, \
+                           (int64_t)0);                                                                              \
     }
     VOD_FWD(0, false) VOD_FWD(0, true) VOD_FWD(1, false) VOD_FWD(1, true) VOD_FWD(2, false) VOD_FWD(2, true)
 #undef VOD_FWD
