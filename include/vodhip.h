@@ -200,13 +200,14 @@ int vodhip_retrieval_forward(const void* q, const void* s, int enc_dtype, int se
  *   score decay       (weight > 0): mean of the squared finite scores                                     (:143-145)
  * loss = KL term + sum(weight * term); d_scores carries every term's gradient.  aux_losses float32 [3] (DEVICE) receives the
  * three terms (NaN where the weight is 0); aux_grad is DEVICE scratch of 3*B*D floats (may be NULL when all weights are 0);
- * workspace >= 16*B floats. */
+ * workspace holds workspace_floats >= 16*B floats; with >= 16*B + 4*B*D (2-D sections) the in-batch contraction is split over K
+ * into slabs behind the row words and uses 4x the workgroups. */
 int vodhip_retrieval_forward_aux(const void* q, const void* s, int enc_dtype, int sections_3d,
                                  int64_t B, int64_t D, int64_t H,
                                  const float* score, const int64_t* relevance, const float* sparse, const float* dense,
                                  int guidance_type, float guidance_weight, float self_supervision_weight, float score_decay,
                                  float* retriever_scores, float* d_scores, float* loss, float* kl, float* aux_losses,
-                                 float* aux_grad, float* workspace /* DEVICE scratch, >= 16*B floats */, void* stream);
+                                 float* aux_grad, float* workspace /* DEVICE scratch */, int64_t workspace_floats, void* stream);
 int vodhip_retrieval_backward(const void* q, const void* s, int enc_dtype, int sections_3d,
                               int64_t B, int64_t D, int64_t H, const float* d_scores, const float* grad_out,
                               float* dq, float* ds, void* stream);

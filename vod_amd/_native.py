@@ -69,7 +69,7 @@ SIGNATURES: dict[str, tuple] = {
     ),
     "vodhip_retrieval_forward_aux": (
         _i32, [_vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _c.c_float, _c.c_float, _c.c_float,
-               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     ),
     "vodhip_priority_sample": (
         _i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _c.c_float, _i32, _i32, _vp, _vp, _vp, _vp, _vp],

@@ -530,7 +530,7 @@ static hipError_t launch_small_gemm(int dta, int dtb, const void* A, int64_t sa_
 hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype, int sections_3d, int64_t B, int64_t D,
                                     int64_t H, const float* score, const int64_t* relevance, const float* sparse,
                                     const float* dense, float* retriever_scores, float* d_scores, float* loss, float* kl,
-                                    float* workspace, const RetrievalAux& aux, hipStream_t stream) {
+                                    float* workspace, const RetrievalAux& aux, hipStream_t stream, int64_t workspace_floats) {
     const size_t lds = (size_t)(H + D + 4) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (!sections_3d) {
@@ -538,18 +538,24 @@ hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype,
         // A 64 x 2048 output is 32 workgroups of 64 x 64: each would walk all of K alone (12 global -> LDS -> MFMA rounds, ~60 us,
         // 7/8 of the chip idle).  K is split over 4 workgroups per tile into slabs of a stream-ordered temporary; the row kernel
         // sums the slabs in order while it loads its row.
-        const int n_splits = (H >= 512 && B * D <= (int64_t)1 << 22) ? 4 : 1;
+        // The slabs live in the caller's workspace behind the 16 B row words when it is large enough (a stream-ordered temporary was
+        // tried: hipMallocAsync + hipFreeAsync cost ~150 us per call); else two slabs: the two [B, D] outputs, which the row kernel
+        // reads (its own row, into LDS) before it writes them.
+        int n_splits = 1;
         float* slabs = retriever_scores;
-        if (n_splits > 1) {
-            hipError_t ea = hipMallocAsync((void**)&slabs, (size_t)n_splits * B * D * sizeof(float), stream);
-            if (ea != hipSuccess) return ea;
+        int64_t slab_stride = B * D;
+        if (H >= 512) {
+            if (workspace_floats >= 16 * B + 4 * B * D) {
+                n_splits = 4;
+                slabs = workspace + 16 * B;
+            } else if (d_scores == retriever_scores + B * D || retriever_scores == d_scores + B * D) {
+                n_splits = 2;  // adjacent outputs: slab z = the z-th of the two buffers
+                slabs = retriever_scores < d_scores ? retriever_scores : d_scores;
+            }
         }
         hipError_t e = launch_small_gemm(enc_dtype, enc_dtype, q, H, 1, s, 1, H, slabs, D, (int)B, (int)D, (int)H, nullptr, stream, n_splits,
-                                         B * D);
-        if (e != hipSuccess) {
-            if (n_splits > 1) (void)hipFreeAsync(slabs, stream);
-            return e;
-        }
+                                         slab_stride);
+        if (e != hipSuccess) return e;
 #define VOD_FWDP(DT)                                                                                                  \
     if (enc_dtype == DT) {                                                                                            \
         auto kern = retrieval_forward_kernel<DT, false, true>;                                                        \
@@ -557,12 +563,11 @@ hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype,
         if (e != hipSuccess) return e;                                                                                \
         hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(RT_THREADS), lds, stream, q, s, (int)D, (int)H, score,       \
                            relevance, sparse, dense, retriever_scores, d_scores, workspace, aux, (const float*)slabs, \
-                           n_splits, (int64_t)(B * D));                                                               \
+                           n_splits, slab_stride);                                                                    \
     }
         VOD_FWDP(0) VOD_FWDP(1) VOD_FWDP(2)
 #undef VOD_FWDP
         e = hipGetLastError();
-        if (n_splits > 1) (void)hipFreeAsync(slabs, stream);  // stream-ordered: released after the row kernel has read it
         if (e != hipSuccess) return e;
         const int64_t n_el = B * D;
         const unsigned blk = (unsigned)std::min<int64_t>(1024, (n_el + RT_THREADS - 1) / RT_THREADS);

@@ -863,7 +863,8 @@ int vodhip_retrieval_forward_aux(const void* q, const void* s, int enc_dtype, in
                                  const float* score, const int64_t* relevance, const float* sparse, const float* dense,
                                  int guidance_type, float guidance_weight, float self_supervision_weight, float score_decay,
                                  float* retriever_scores, float* d_scores, float* loss, float* kl, float* aux_losses,
-                                 float* aux_grad, float* workspace, void* stream) {
+                                 float* aux_grad, float* workspace, int64_t workspace_floats, void* stream) {
+    if (workspace_floats < 16 * B) return fail("workspace_floats=%lld < 16 * B", (long long)workspace_floats);
     if (!q || !s || !score || !relevance || !retriever_scores || !d_scores || !loss || !kl || !workspace || !aux_losses)
         return fail("NULL argument");
     if (B <= 0 || D <= 0 || H <= 0) return fail("invalid sizes");
@@ -883,7 +884,7 @@ int vodhip_retrieval_forward_aux(const void* q, const void* s, int enc_dtype, in
     aux.grad = aux_grad;
     aux.out = aux_losses;
     HIP_OK(launch_retrieval_forward(q, s, enc_dtype, sections_3d, B, D, H, score, relevance, sparse, dense,
-                                    retriever_scores, d_scores, loss, kl, workspace, aux, (hipStream_t)stream));
+                                    retriever_scores, d_scores, loss, kl, workspace, aux, (hipStream_t)stream, workspace_floats));
     return 0;
 }
 

@@ -143,7 +143,8 @@ struct RetrievalAux {
 hipError_t launch_retrieval_forward(const void* q, const void* s, int enc_dtype, int sections_3d, int64_t B, int64_t D,
                                     int64_t H, const float* score, const int64_t* relevance, const float* sparse,
                                     const float* dense, float* retriever_scores, float* d_scores, float* loss,
-                                    float* kl, float* workspace, const RetrievalAux& aux, hipStream_t stream);
+                                    float* kl, float* workspace, const RetrievalAux& aux, hipStream_t stream,
+                                    int64_t workspace_floats = 0);
 hipError_t launch_retrieval_backward(const void* q, const void* s, int enc_dtype, int sections_3d, int64_t B, int64_t D,
                                      int64_t H, const float* d_scores, const float* grad_out, float* dq, float* ds,
                                      hipStream_t stream);

@@ -52,8 +52,9 @@ class _RetrievalLoss(torch.autograd.Function):
         dev = q.device
         both = torch.empty((2, B, D), dtype=torch.float32, device=dev)  # retriever scores | dLoss/dScores
         scores, d_scores = both.unbind(0)
-        # loss [1] | kl [3] | auxiliary terms [3] (the library writes all three: NaN where the weight is 0) | pad | row workspace [16 B]
-        small = torch.empty((8 + 16 * B,), dtype=torch.float32, device=dev)
+        # loss [1] | kl [3] | auxiliary terms [3] (the library writes all three: NaN where the weight is 0) | pad | workspace
+        n_work = 16 * B + (4 * B * D if not three_d else 0)  # + room for the split-K slabs of the in-batch contraction
+        small = torch.empty((8 + n_work,), dtype=torch.float32, device=dev)
         loss, kl, aux, work = small[0], small[1:4], small[4:7], small[8:]
         g_type, w_g, w_ss, w_sd = aux_cfg
         any_aux = w_g > 0 or w_ss > 0 or w_sd > 0
@@ -66,7 +67,7 @@ class _RetrievalLoss(torch.autograd.Function):
                     None if sparse_c is None else sparse_c.data_ptr(), None if dense_c is None else dense_c.data_ptr(),
                     int(g_type), float(w_g), float(w_ss), float(w_sd),
                     scores.data_ptr(), d_scores.data_ptr(), loss.data_ptr(), kl.data_ptr(), aux.data_ptr(),
-                    None if aux_grad is None else aux_grad.data_ptr(), work.data_ptr(), _native.current_stream_ptr(dev),
+                    None if aux_grad is None else aux_grad.data_ptr(), work.data_ptr(), n_work, _native.current_stream_ptr(dev),
                 )
             )
         ctx.save_for_backward(qc, sc, d_scores)
