@@ -157,3 +157,34 @@ def test_invalid_guidance_type_is_rejected():
 
     with pytest.raises(ValueError, match="guidance"):
         RetrievalGradients(guidance="dense", guidance_weight=0.1)
+
+
+@pytest.mark.parametrize("adjacent", [True, False])
+def test_plain_entry_point_matches_the_autograd_wrapper_in_batch(adjacent):
+    """`vodhip_retrieval_forward` (no auxiliary terms, 8 B workspace words) on the flattened in-batch section set: with the two
+    [B, D] outputs adjacent in memory the K-split contraction uses them as its two slabs (each row's workgroup reads its slab rows
+    before it writes), otherwise it runs unsplit - both must give the wrapper's numbers (which splits 4 ways in its workspace)."""
+    from vod_amd import _native
+
+    lib = _native.load_library()
+    rng = np.random.default_rng(11)
+    B, D, H = 64, 2048, 768
+    q = rng.standard_normal((B, H)).astype(np.float32)
+    s = rng.standard_normal((D, H)).astype(np.float32)
+    score = rng.standard_normal((B, D)).astype(np.float32)
+    score[rng.random((B, D)) < 0.1] = -np.inf
+    rel = (rng.random((B, D)) < 0.02).astype(np.int64)
+    out, _, _ = _run(q, s, score, rel, None, None)
+    qt, st = torch.tensor(q, device="cuda"), torch.tensor(s, device="cuda")
+    sc, rl = torch.tensor(score, device="cuda"), torch.tensor(rel, device="cuda")
+    both = torch.zeros((3, B, D), device="cuda")
+    scores, d_scores = (both[0], both[1]) if adjacent else (both[0], both[2])
+    small = torch.zeros(4 + 16 * B, device="cuda")
+    _native.check(lib.vodhip_retrieval_forward(qt.data_ptr(), st.data_ptr(), _native.torch_dtype_code(torch.float32), 0, B, D, H,
+                                               sc.data_ptr(), rl.data_ptr(), None, None, scores.data_ptr(), d_scores.data_ptr(),
+                                               small[0:1].data_ptr(), small[1:4].data_ptr(), small[4:].data_ptr(),
+                                               _native.current_stream_ptr(qt.device)))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(scores.cpu().numpy(), out.retriever_scores.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(small[0].item(), out.loss.item(), rtol=1e-5)
+    np.testing.assert_allclose(small[1].item(), out.diagnostics["kl_score"].item(), rtol=1e-4, atol=1e-6)
