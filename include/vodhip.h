@@ -152,6 +152,34 @@ int vodhip_merge_topk_strided(const float* scores, int64_t shard_stride_scores, 
                               float* out_scores, int64_t* out_ids, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * H1 + H2 + H3 on several devices of one node, from ONE process: for consumers without torch.distributed (C, C++, cgo, JNI).
+ * Replaces: faiss.index_cpu_to_all_gpus(index, co) with co.shard = True, i.e. faiss IndexShards
+ *           (src/vod_search/faiss_search/server.py:51-54, src/vod_configs/search.py:80).
+ * Shard g (on devices[g]; a device may be listed more than once) holds the global rows [g * R, (g + 1) * R), R = ceil(capacity /
+ * n_devices): rows keep their insertion ids, the shards are balanced when the store is full.  A search replicates the query batch,
+ * runs on every device at once, copies the per-shard top-k lists to devices[0] (peer copies) and merges them there with
+ * vodhip_merge_topk: results are identical to one index holding all the rows.  (The Python host uses one process per GPU and one
+ * RCCL all-gather instead - vod_amd/distributed.py - because that is how torch.distributed programs are launched.)
+ *   add     HOST rows only (row-major [n_rows, dim] of src_dtype); the shards a batch straddles ingest concurrently; synchronous.
+ *   search  location = VODHIP_HOST: queries / outputs are host buffers, the call returns with the results in place (`stream` unused);
+ *           location = VODHIP_DEVICE: they live on devices[0]; the queries must be complete on `stream` and the outputs are complete
+ *           on `stream` when the call returns (the exactness check of every shard has already been done on the host).
+ *   shard   the per-device handle (for params, stats, subset labels, persistence), its id offset and its device.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vodhip_node_index vodhip_node_index_t;
+int vodhip_node_index_create(int n_devices, const int* devices, int64_t dim, int store_dtype, int64_t capacity_rows,
+                             vodhip_node_index_t** out);
+int vodhip_node_index_destroy(vodhip_node_index_t* index);
+int vodhip_node_index_add(vodhip_node_index_t* index, const void* rows, int64_t n_rows, int src_dtype);
+int vodhip_node_index_reset(vodhip_node_index_t* index);
+int vodhip_node_index_ntotal(const vodhip_node_index_t* index, int64_t* out);
+int vodhip_node_index_n_shards(const vodhip_node_index_t* index);
+int vodhip_node_index_shard(vodhip_node_index_t* index, int g, vodhip_index_t** shard, int64_t* id_base, int* device);
+int vodhip_node_index_set_param(vodhip_node_index_t* index, const char* key, int64_t value);  /* on every shard */
+int vodhip_node_index_search(vodhip_node_index_t* index, const void* queries, int q_dtype, int64_t nq, int k, int location,
+                             float* out_scores, int64_t* out_ids, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * H4  hybrid score merge (lookup + up to VODHIP_MAX_ENGINES scored engines), one query row per wavefront.
  * Replaces: _merge_search_results (src/vod_dataloaders/core/search.py:79-125) =
  *           normalize_search_scores_ (core/normalize.py:6-20) + merge_search_results

@@ -1,6 +1,7 @@
 /* A plain C99 consumer of include/vodhip.h: no Python, no torch, no C++.
  * Builds an index from host float32 rows, searches it with device buffers from the HIP runtime's C API, and checks the
- * result against a brute-force loop (integer-valued data: every dot product is exact in fp32; ties -> smaller id); then runs
+ * result against a brute-force loop (integer-valued data: every dot product is exact in fp32; ties -> smaller id); repeats the
+ * search through the one-process node index (three shards); then runs
  * the collate-side chain (merge -> sampling) through `vodhip_collate` on the SURVEY's hand-written three-engine case.
  * Built and run by tests/test_c_abi.py:  gcc -std=c99 abi_smoke.c -I include -I /opt/rocm/include -lvodhip -lamdhip64 */
 #define __HIP_PLATFORM_AMD__ 1
@@ -149,6 +150,30 @@ int main(void) {
         return 1;
     }
     CHECK(vodhip_index_destroy(ix));
+    /* the same rows behind the one-process node index, three shards (all on device 0 here), host buffers in and out: must give
+     * the single index's answer (ids without the +1000 offset) */
+    {
+        const int devs[3] = {0, 0, 0};
+        vodhip_node_index_t* nx = NULL;
+        CHECK(vodhip_node_index_create(3, devs, d, VODHIP_F16, n, &nx));
+        CHECK(vodhip_node_index_add(nx, x, 12345, VODHIP_F32));
+        CHECK(vodhip_node_index_add(nx, x + 12345 * d, n - 12345, VODHIP_F32));
+        if (vodhip_node_index_n_shards(nx) != 3) { fprintf(stderr, "n_shards\n"); return 1; }
+        float* ns = (float*)malloc(sizeof(float) * nq * k);
+        int64_t* ni = (int64_t*)malloc(sizeof(int64_t) * nq * k);
+        CHECK(vodhip_node_index_search(nx, q, VODHIP_F32, nq, k, VODHIP_HOST, ns, ni, NULL));
+        for (int64_t e = 0; e < nq * k; ++e)
+            if (ni[e] != hi[e] - 1000 || ns[e] != hs[e]) {
+                fprintf(stderr, "node index entry %lld: got (%g, %lld) want (%g, %lld)\n", (long long)e, ns[e], (long long)ni[e], hs[e],
+                        (long long)(hi[e] - 1000));
+                return 1;
+            }
+        int64_t base1 = -1;
+        CHECK(vodhip_node_index_shard(nx, 1, NULL, &base1, NULL));
+        if (base1 != 10000) { fprintf(stderr, "shard 1 starts at %lld\n", (long long)base1); return 1; }
+        CHECK(vodhip_node_index_destroy(nx));
+        free(ns); free(ni);
+    }
     if (collate_case() != 0) return 1;
     (void)hipFree(dq); (void)hipFree(ds); (void)hipFree(di);
     free(x); free(q); free(hs); free(hi); free(sc);

@@ -30,6 +30,14 @@ int fail(const char* fmt, ...) {
     return -1;
 }
 
+}  // namespace
+
+namespace vodhip {
+void set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
+}  // namespace vodhip
+
+namespace {
+
 #define HIP_OK(expr)                                                                            \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \

@@ -29,6 +29,8 @@
 
 namespace vodhip {
 
+void set_last_error(const char* msg);  // the calling thread's vodhip_last_error() text (vodhip_node.hip composes public entry points)
+
 // which: 0 = merge_hybrid_kernel, 1 = priority_sample_kernel, 2 = flatten_inbatch_kernel; out: 256 words = 64 (cycles, 10 ns ticks) phase pairs + 64 (begin, end) workgroup pairs
 hipError_t read_probe_hybrid(long long* out);
 hipError_t read_probe_sample(int which, long long* out);

@@ -1,0 +1,319 @@
+// vodhip_node_index_*: the row-sharded index of ONE node driven from ONE process, for consumers that have no
+// torch.distributed (C, C++, cgo, JNI): every device holds a contiguous row range, a search runs on all devices at once and the
+// per-shard top-k lists meet on devices[0] (peer copies over xGMI) where vodhip_merge_topk folds them.
+// Counterpart of faiss.index_cpu_to_all_gpus(index, co) with co.shard = True (/root/reference/src/vod_search/faiss_search/
+// server.py:51-54, vod_configs/search.py:80).  A composition of the PUBLIC entry points of include/vodhip.h - nothing here reaches
+// into a shard's internals.  (The Python host shards with one process per GPU and one RCCL all-gather instead: vod_amd/distributed.py.)
+#include "../../include/vodhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "vodhip_internal.h"
+
+namespace {
+
+int nfail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    vodhip::set_last_error(buf);
+    return -1;
+}
+
+#define NODE_HIP_OK(expr)                                                                                               \
+    do {                                                                                                                \
+        hipError_t _e = (expr);                                                                                         \
+        if (_e != hipSuccess) return nfail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+inline size_t elem_bytes(int dtype) { return dtype == VODHIP_F32 ? 4 : 2; }
+
+struct ShardBuffers {
+    void* q = nullptr;          // the query batch on this shard's device
+    float* scores = nullptr;    // this shard's top-k [nq, k]
+    int64_t* ids = nullptr;
+    size_t q_bytes = 0, res_elems = 0;
+};
+
+}  // namespace
+
+struct vodhip_node_index {
+    int n = 0;
+    int64_t dim = 0, capacity = 0, rows_per_shard = 0, ntotal = 0;
+    int dtype = 0;
+    std::vector<int> device;
+    std::vector<vodhip_index_t*> shard;
+    std::vector<hipStream_t> stream;   // one per shard, on its device
+    std::vector<hipEvent_t> arrived;   // shard g's result is on devices[0]
+    std::vector<ShardBuffers> buf;
+    hipEvent_t ready = nullptr;        // on devices[0]: the caller's queries are readable / the previous merge has read `gathered`
+    float* gathered_scores = nullptr;  // devices[0]: [n, nq, k]
+    int64_t* gathered_ids = nullptr;
+    float* merged_scores = nullptr;    // devices[0]: [nq, k] (host-located outputs)
+    int64_t* merged_ids = nullptr;
+    size_t gathered_elems = 0, merged_elems = 0;
+};
+
+namespace {
+
+int ensure(void** p, size_t* have, size_t want, size_t elem) {
+    if (*have >= want && *p) return 0;
+    if (*p) NODE_HIP_OK(hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+    const size_t n = want + want / 4 + 64;  // a little headroom: batch sizes wobble
+    NODE_HIP_OK(hipMalloc(p, n * elem));
+    *have = n;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vodhip_node_index_create(int n_devices, const int* devices, int64_t dim, int store_dtype, int64_t capacity_rows,
+                             vodhip_node_index_t** out) {
+    if (!out) return nfail("out is NULL");
+    if (n_devices < 1 || n_devices > 64 || !devices) return nfail("n_devices=%d out of range [1, 64]", n_devices);
+    if (capacity_rows < 0) return nfail("invalid capacity=%lld", (long long)capacity_rows);
+    vodhip_node_index* nx = new vodhip_node_index();
+    nx->n = n_devices;
+    nx->dim = dim;
+    nx->dtype = store_dtype;
+    nx->capacity = capacity_rows;
+    nx->rows_per_shard = (capacity_rows + n_devices - 1) / n_devices;
+    nx->device.assign(devices, devices + n_devices);
+    nx->shard.assign(n_devices, nullptr);
+    nx->stream.assign(n_devices, nullptr);
+    nx->arrived.assign(n_devices, nullptr);
+    nx->buf.resize(n_devices);
+    auto bail = [&](int rc) {
+        const std::string keep = vodhip_last_error();
+        vodhip_node_index_destroy(nx);
+        vodhip::set_last_error(keep.c_str());
+        return rc;
+    };
+    for (int g = 0; g < n_devices; ++g) {
+        const int64_t lo = std::min(capacity_rows, g * nx->rows_per_shard), hi = std::min(capacity_rows, lo + nx->rows_per_shard);
+        if (vodhip_index_create(devices[g], dim, store_dtype, hi - lo, &nx->shard[g])) return bail(-1);
+        hipError_t e = hipSetDevice(devices[g]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&nx->stream[g], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&nx->arrived[g], hipEventDisableTiming);
+        if (e != hipSuccess) return bail(nfail("stream / event creation on device %d failed: %s", devices[g], hipGetErrorString(e)));
+    }
+    hipError_t e = hipSetDevice(devices[0]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&nx->ready, hipEventDisableTiming);
+    if (e != hipSuccess) return bail(nfail("event creation failed: %s", hipGetErrorString(e)));
+    *out = nx;
+    return 0;
+}
+
+int vodhip_node_index_destroy(vodhip_node_index_t* nx) {
+    if (!nx) return 0;
+    for (int g = 0; g < nx->n; ++g) {
+        (void)hipSetDevice(nx->device[g]);
+        if (nx->stream[g]) (void)hipStreamSynchronize(nx->stream[g]);
+        if (nx->shard[g]) (void)vodhip_index_destroy(nx->shard[g]);
+        (void)hipFree(nx->buf[g].q);
+        (void)hipFree(nx->buf[g].scores);
+        (void)hipFree(nx->buf[g].ids);
+        if (nx->arrived[g]) (void)hipEventDestroy(nx->arrived[g]);
+        if (nx->stream[g]) (void)hipStreamDestroy(nx->stream[g]);
+    }
+    if (nx->n) (void)hipSetDevice(nx->device[0]);
+    (void)hipFree(nx->gathered_scores);
+    (void)hipFree(nx->gathered_ids);
+    (void)hipFree(nx->merged_scores);
+    (void)hipFree(nx->merged_ids);
+    if (nx->ready) (void)hipEventDestroy(nx->ready);
+    delete nx;
+    return 0;
+}
+
+int vodhip_node_index_add(vodhip_node_index_t* nx, const void* rows, int64_t n_rows, int src_dtype) {
+    if (!nx) return nfail("index is NULL");
+    if (n_rows < 0 || (n_rows > 0 && !rows)) return nfail("invalid rows");
+    if (src_dtype < 0 || src_dtype > 2) return nfail("invalid src_dtype %d", src_dtype);
+    if (nx->ntotal + n_rows > nx->capacity)
+        return nfail("index full: ntotal=%lld + %lld > capacity=%lld", (long long)nx->ntotal, (long long)n_rows, (long long)nx->capacity);
+    // global rows [ntotal, ntotal + n_rows): the part inside shard g's range goes to shard g; the shards ingest concurrently
+    // (one host thread each: every device has its own DMA engines and PCIe link)
+    struct Part { int g; int64_t first, count; };
+    std::vector<Part> parts;
+    for (int g = 0; g < nx->n; ++g) {
+        const int64_t lo = g * nx->rows_per_shard, hi = lo + nx->rows_per_shard;
+        const int64_t a = std::max(lo, nx->ntotal), b = std::min(hi, nx->ntotal + n_rows);
+        if (b > a) parts.push_back({g, a - nx->ntotal, b - a});
+    }
+    std::vector<std::string> errors(parts.size());
+    std::vector<int> rcs(parts.size(), 0);
+    auto work = [&](size_t i) {
+        const Part& p = parts[i];
+        const char* src = (const char*)rows + (size_t)p.first * (size_t)nx->dim * elem_bytes(src_dtype);
+        rcs[i] = vodhip_index_add(nx->shard[p.g], src, p.count, src_dtype, VODHIP_HOST, nx->stream[p.g]);
+        if (rcs[i]) errors[i] = vodhip_last_error();  // thread-local text: carried back to the caller's thread
+    };
+    if (parts.size() == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (size_t i = 0; i < parts.size(); ++i) pool.emplace_back(work, i);
+        for (auto& t : pool) t.join();
+    }
+    for (size_t i = 0; i < parts.size(); ++i)
+        if (rcs[i]) return nfail("shard %d: %s", parts[i].g, errors[i].c_str());
+    nx->ntotal += n_rows;
+    return 0;
+}
+
+int vodhip_node_index_reset(vodhip_node_index_t* nx) {
+    if (!nx) return nfail("index is NULL");
+    for (int g = 0; g < nx->n; ++g)
+        if (vodhip_index_reset(nx->shard[g])) return -1;
+    nx->ntotal = 0;
+    return 0;
+}
+
+int vodhip_node_index_ntotal(const vodhip_node_index_t* nx, int64_t* out) {
+    if (!nx || !out) return nfail("NULL argument");
+    *out = nx->ntotal;
+    return 0;
+}
+
+int vodhip_node_index_n_shards(const vodhip_node_index_t* nx) { return nx ? nx->n : nfail("index is NULL"); }
+
+int vodhip_node_index_shard(vodhip_node_index_t* nx, int g, vodhip_index_t** shard, int64_t* id_base, int* device) {
+    if (!nx) return nfail("index is NULL");
+    if (g < 0 || g >= nx->n) return nfail("shard %d out of range [0, %d)", g, nx->n);
+    if (shard) *shard = nx->shard[g];
+    if (id_base) *id_base = g * nx->rows_per_shard;
+    if (device) *device = nx->device[g];
+    return 0;
+}
+
+int vodhip_node_index_set_param(vodhip_node_index_t* nx, const char* key, int64_t value) {
+    if (!nx) return nfail("index is NULL");
+    for (int g = 0; g < nx->n; ++g)
+        if (vodhip_index_set_param(nx->shard[g], key, value)) return -1;
+    return 0;
+}
+
+int vodhip_node_index_search(vodhip_node_index_t* nx, const void* queries, int q_dtype, int64_t nq, int k, int location,
+                             float* out_scores, int64_t* out_ids, void* stream_) {
+    if (!nx) return nfail("index is NULL");
+    if (k < 1 || k > VODHIP_MAX_K) return nfail("k=%d out of range [1, %d]", k, VODHIP_MAX_K);
+    if (nq < 0 || (nq > 0 && (!queries || !out_scores || !out_ids))) return nfail("invalid query / output pointers");
+    if (q_dtype < 0 || q_dtype > 2) return nfail("invalid q_dtype %d", q_dtype);
+    if (location != VODHIP_HOST && location != VODHIP_DEVICE) return nfail("invalid location %d", location);
+    if (nq == 0) return 0;
+    const int G = nx->n, dev0 = nx->device[0];
+    hipStream_t user = location == VODHIP_DEVICE ? (hipStream_t)stream_ : nx->stream[0];
+    const size_t q_bytes = (size_t)nq * (size_t)nx->dim * elem_bytes(q_dtype), res = (size_t)nq * (size_t)k;
+
+    // buffers (grown on demand, kept)
+    for (int g = 0; g < G; ++g) {
+        NODE_HIP_OK(hipSetDevice(nx->device[g]));
+        ShardBuffers& b = nx->buf[g];
+        size_t rs = b.res_elems, ri = b.res_elems;
+        if (ensure(&b.q, &b.q_bytes, q_bytes, 1)) return -1;
+        if (ensure((void**)&b.scores, &rs, res, sizeof(float))) return -1;
+        if (ensure((void**)&b.ids, &ri, res, sizeof(int64_t))) return -1;
+        b.res_elems = std::min(rs, ri);
+    }
+    NODE_HIP_OK(hipSetDevice(dev0));
+    if (G > 1) {
+        size_t gs = nx->gathered_elems, gi = nx->gathered_elems;
+        if (ensure((void**)&nx->gathered_scores, &gs, res * G, sizeof(float))) return -1;
+        if (ensure((void**)&nx->gathered_ids, &gi, res * G, sizeof(int64_t))) return -1;
+        nx->gathered_elems = std::min(gs, gi);
+    }
+    if (location == VODHIP_HOST) {
+        size_t ms = nx->merged_elems, mi = nx->merged_elems;
+        if (ensure((void**)&nx->merged_scores, &ms, res, sizeof(float))) return -1;
+        if (ensure((void**)&nx->merged_ids, &mi, res, sizeof(int64_t))) return -1;
+        nx->merged_elems = std::min(ms, mi);
+    }
+    float* final_scores = location == VODHIP_HOST ? nx->merged_scores : out_scores;
+    int64_t* final_ids = location == VODHIP_HOST ? nx->merged_ids : out_ids;
+
+    // 1. the query batch reaches every device (replicated: nq * dim * 2-4 bytes), then every shard searches - all enqueued before
+    //    anything is waited for, so the devices run side by side
+    if (location == VODHIP_DEVICE) NODE_HIP_OK(hipEventRecord(nx->ready, user));  // the caller's stream has produced the queries
+    for (int g = 0; g < G; ++g) {
+        NODE_HIP_OK(hipSetDevice(nx->device[g]));
+        if (location == VODHIP_HOST) {
+            NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q, queries, q_bytes, hipMemcpyHostToDevice, nx->stream[g]));
+        } else {
+            NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], nx->ready, 0));
+            if (nx->device[g] == dev0) NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q, queries, q_bytes, hipMemcpyDeviceToDevice, nx->stream[g]));
+            else NODE_HIP_OK(hipMemcpyPeerAsync(nx->buf[g].q, nx->device[g], queries, dev0, q_bytes, nx->stream[g]));
+        }
+        // a G = 1 index writes the caller's / the merged buffers directly
+        float* s_out = G == 1 ? final_scores : nx->buf[g].scores;
+        int64_t* i_out = G == 1 ? final_ids : nx->buf[g].ids;
+        if (vodhip_index_search_async(nx->shard[g], nx->buf[g].q, q_dtype, nq, k, g * nx->rows_per_shard, s_out, i_out, nx->stream[g])) {
+            const std::string keep = vodhip_last_error();
+            for (int h = 0; h < g; ++h) (void)vodhip_index_search_finish(nx->shard[h], nx->stream[h]);  // nothing stays in flight
+            return nfail("shard %d: %s", g, keep.c_str());
+        }
+    }
+    // 2. exactness check of every shard (host side; a shard that needs a recovery pass runs it on its own stream), then its list
+    //    travels to devices[0]
+    int rc = 0;
+    std::string first_error;
+    for (int g = 0; g < G; ++g) {
+        if (vodhip_index_search_finish(nx->shard[g], nx->stream[g])) {
+            if (!rc) first_error = std::string("shard ") + std::to_string(g) + ": " + vodhip_last_error();
+            rc = -1;
+            continue;
+        }
+        if (G == 1 || rc) continue;
+        NODE_HIP_OK(hipSetDevice(nx->device[g]));
+        float* ds = nx->gathered_scores + (size_t)g * res;
+        int64_t* di = nx->gathered_ids + (size_t)g * res;
+        if (nx->device[g] == dev0) {
+            NODE_HIP_OK(hipMemcpyAsync(ds, nx->buf[g].scores, res * sizeof(float), hipMemcpyDeviceToDevice, nx->stream[g]));
+            NODE_HIP_OK(hipMemcpyAsync(di, nx->buf[g].ids, res * sizeof(int64_t), hipMemcpyDeviceToDevice, nx->stream[g]));
+        } else {
+            NODE_HIP_OK(hipMemcpyPeerAsync(ds, dev0, nx->buf[g].scores, nx->device[g], res * sizeof(float), nx->stream[g]));
+            NODE_HIP_OK(hipMemcpyPeerAsync(di, dev0, nx->buf[g].ids, nx->device[g], res * sizeof(int64_t), nx->stream[g]));
+        }
+        NODE_HIP_OK(hipEventRecord(nx->arrived[g], nx->stream[g]));
+    }
+    if (rc) return nfail("%s", first_error.c_str());
+    // 3. merge on devices[0], on the caller's stream (DEVICE) or shard 0's (HOST)
+    NODE_HIP_OK(hipSetDevice(dev0));
+    if (G > 1) {
+        for (int g = 0; g < G; ++g) NODE_HIP_OK(hipStreamWaitEvent(user, nx->arrived[g], 0));
+        if (vodhip_merge_topk(nx->gathered_scores, nx->gathered_ids, G, nq, k, k, final_scores, final_ids, user)) return -1;
+    } else if (location == VODHIP_DEVICE) {
+        NODE_HIP_OK(hipEventRecord(nx->arrived[0], nx->stream[0]));
+        NODE_HIP_OK(hipStreamWaitEvent(user, nx->arrived[0], 0));
+    }
+    if (location == VODHIP_HOST) {
+        NODE_HIP_OK(hipMemcpyAsync(out_scores, final_scores, res * sizeof(float), hipMemcpyDeviceToHost, user));
+        NODE_HIP_OK(hipMemcpyAsync(out_ids, final_ids, res * sizeof(int64_t), hipMemcpyDeviceToHost, user));
+        NODE_HIP_OK(hipStreamSynchronize(user));
+    } else {
+        // the next search must not overwrite `gathered` / the shard buffers before this merge has read them: the shard streams
+        // wait for `ready`, recorded again here on the caller's stream at the start of the next call - and for this call:
+        NODE_HIP_OK(hipEventRecord(nx->ready, user));
+        for (int g = 0; g < G; ++g) {
+            NODE_HIP_OK(hipSetDevice(nx->device[g]));
+            NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], nx->ready, 0));
+        }
+        NODE_HIP_OK(hipSetDevice(dev0));
+    }
+    return 0;
+}
+
+}  // extern "C"

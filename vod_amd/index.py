@@ -275,3 +275,101 @@ class PackedTopk:
                                               self.k, k_out, out_s.data_ptr(), out_i.data_ptr(), _native.current_stream_ptr(dev))
             )
         return out_s, out_i
+
+
+class HipNodeIndex:
+    """The row-sharded index of one node in ONE process (`vodhip_node_index_*`): shard g on `devices[g]` holds a contiguous row
+    range, a search runs on every device at once and the per-shard top-k lists are merged on `devices[0]`.
+
+    Counterpart of faiss `index_cpu_to_all_gpus(..., shard=True)` (/root/reference/src/vod_search/faiss_search/server.py:51-54).
+    The collective variant (one process per GPU, one RCCL all-gather) is `vod_amd.distributed.ShardedFlatIndex`; this one is what a
+    C / C++ consumer of the library gets, and what a single-process Python host can use without `torch.distributed`.
+    """
+
+    def __init__(self, dim: int, capacity: int, devices: list[int], dtype: torch.dtype = torch.float16):
+        self._lib = _native.load_library()
+        if not torch.cuda.is_available():
+            raise _native.NativeLibraryError("HipNodeIndex needs a ROCm device (torch.cuda.is_available() is False)")
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise TypeError("store dtype must be torch.float16 or torch.bfloat16")
+        if not devices:
+            raise ValueError("devices must list at least one device ordinal")
+        self.dim, self.capacity, self.dtype, self.devices = int(dim), int(capacity), dtype, [int(d) for d in devices]
+        self.device = torch.device("cuda", self.devices[0])
+        handle = ctypes.c_void_p()
+        arr = (ctypes.c_int32 * len(self.devices))(*self.devices)
+        _native.check(self._lib.vodhip_node_index_create(len(self.devices), arr, self.dim, _native.torch_dtype_code(dtype), self.capacity,
+                                                         ctypes.byref(handle)))
+        self._h = handle
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.vodhip_node_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self) -> "HipNodeIndex":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
+    @property
+    def ntotal(self) -> int:
+        out = ctypes.c_int64()
+        _native.check(self._lib.vodhip_node_index_ntotal(self._h, ctypes.byref(out)))
+        return out.value
+
+    def reset(self) -> None:
+        _native.check(self._lib.vodhip_node_index_reset(self._h))
+
+    def set_param(self, key: str, value: int) -> None:
+        _native.check(self._lib.vodhip_node_index_set_param(self._h, key.encode(), int(value)))
+
+    def shard(self, g: int) -> tuple[int, int, int]:
+        """(raw `vodhip_index_t*` of shard g, its id offset, its device) - for stats / params of one shard."""
+        h, base, dev = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int32()
+        _native.check(self._lib.vodhip_node_index_shard(self._h, int(g), ctypes.byref(h), ctypes.byref(base), ctypes.byref(dev)))
+        return h.value, base.value, dev.value
+
+    def add(self, vectors: np.ndarray) -> None:
+        """Append host rows (float32 / float16 NumPy, [n, dim]); the shards the batch straddles ingest concurrently."""
+        v = np.ascontiguousarray(vectors)
+        if v.ndim != 2 or v.shape[1] != self.dim:
+            raise ValueError(f"expected [n, {self.dim}] vectors, got {tuple(v.shape)}")
+        if v.dtype not in (np.float32, np.float16):
+            v = v.astype(np.float32)
+        code = 2 if v.dtype == np.float32 else 0
+        _native.check(self._lib.vodhip_node_index_add(self._h, v.ctypes.data, v.shape[0], code))
+
+    def search(self, queries: np.ndarray | torch.Tensor, k: int):
+        """NumPy in -> NumPy out (host buffers, synchronous); a tensor on `devices[0]` in -> tensors there, complete on the current stream."""
+        if isinstance(queries, torch.Tensor):
+            if queries.device != self.device:
+                raise ValueError(f"queries live on {queries.device}, the merge device is {self.device}")
+            q = queries.contiguous()
+            if q.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+                q = q.float()
+            if q.ndim != 2 or q.shape[1] != self.dim:
+                raise ValueError(f"expected [nq, {self.dim}] queries, got {tuple(q.shape)}")
+            out_s = torch.empty((q.shape[0], k), dtype=torch.float32, device=self.device)
+            out_i = torch.empty((q.shape[0], k), dtype=torch.int64, device=self.device)
+            with torch.cuda.device(self.device):
+                _native.check(self._lib.vodhip_node_index_search(self._h, q.data_ptr(), _native.torch_dtype_code(q.dtype), q.shape[0], int(k), 1,
+                                                                 out_s.data_ptr(), out_i.data_ptr(), _native.current_stream_ptr(self.device)))
+            return out_s, out_i
+        q = np.ascontiguousarray(queries)
+        if q.dtype not in (np.float32, np.float16):
+            q = q.astype(np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError(f"expected [nq, {self.dim}] queries, got {tuple(q.shape)}")
+        out_s = np.empty((q.shape[0], k), dtype=np.float32)
+        out_i = np.empty((q.shape[0], k), dtype=np.int64)
+        _native.check(self._lib.vodhip_node_index_search(self._h, q.ctypes.data, 2 if q.dtype == np.float32 else 0, q.shape[0], int(k), 0,
+                                                         out_s.ctypes.data, out_i.ctypes.data, None))
+        return out_s, out_i
