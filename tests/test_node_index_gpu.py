@@ -103,3 +103,10 @@ def test_errors_are_reported_not_thrown_across_the_boundary():
             nx.shard(7)
     with pytest.raises(_native.NativeLibraryError):
         HipNodeIndex(32, 100, [99])  # no such device
+    # a reported failure must not linger in the HIP runtime's sticky error and fail the NEXT launch check
+    from vod_amd.gradients import RetrievalGradients
+
+    q = torch.randn(4, 16, device="cuda", requires_grad=True)
+    s = torch.randn(4, 3, 16, device="cuda")
+    batch = {"section__score": torch.zeros(4, 3, device="cuda"), "section__relevance": torch.ones(4, 3, dtype=torch.int64, device="cuda")}
+    assert torch.isfinite(RetrievalGradients()(batch=batch, query_encoding=q, section_encoding=s).loss)

@@ -41,7 +41,10 @@ namespace {
 #define HIP_OK(expr)                                                                            \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \
-        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        if (_e != hipSuccess) {                                                                 \
+            (void)hipGetLastError(); /* reported here: must not resurface in a later launch check */ \
+            return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                       \
     } while (0)
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }

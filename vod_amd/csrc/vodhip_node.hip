@@ -32,7 +32,10 @@ int nfail(const char* fmt, ...) {
 #define NODE_HIP_OK(expr)                                                                                               \
     do {                                                                                                                \
         hipError_t _e = (expr);                                                                                         \
-        if (_e != hipSuccess) return nfail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        if (_e != hipSuccess) {                                                                                         \
+            (void)hipGetLastError();                                                                                    \
+            return nfail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);                   \
+        }                                                                                                               \
     } while (0)
 
 inline size_t elem_bytes(int dtype) { return dtype == VODHIP_F32 ? 4 : 2; }
