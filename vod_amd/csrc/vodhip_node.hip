@@ -123,6 +123,7 @@ int vodhip_node_index_create(int n_devices, const int* devices, int64_t dim, int
 int vodhip_node_index_destroy(vodhip_node_index_t* nx) {
     if (!nx) return 0;
     for (int g = 0; g < nx->n; ++g) {
+        if (!nx->shard[g]) continue;  // create() failed before this shard existed: its device may not exist either
         (void)hipSetDevice(nx->device[g]);
         if (nx->stream[g]) (void)hipStreamSynchronize(nx->stream[g]);
         if (nx->shard[g]) (void)vodhip_index_destroy(nx->shard[g]);
@@ -132,13 +133,14 @@ int vodhip_node_index_destroy(vodhip_node_index_t* nx) {
         if (nx->arrived[g]) (void)hipEventDestroy(nx->arrived[g]);
         if (nx->stream[g]) (void)hipStreamDestroy(nx->stream[g]);
     }
-    if (nx->n) (void)hipSetDevice(nx->device[0]);
+    if (nx->n && nx->shard[0]) (void)hipSetDevice(nx->device[0]);
     (void)hipFree(nx->gathered_scores);
     (void)hipFree(nx->gathered_ids);
     (void)hipFree(nx->merged_scores);
     (void)hipFree(nx->merged_ids);
     if (nx->ready) (void)hipEventDestroy(nx->ready);
     delete nx;
+    (void)hipGetLastError();  // best-effort teardown: nothing of it may resurface in the caller's next launch check
     return 0;
 }
 
