@@ -185,6 +185,6 @@ def test_plain_entry_point_matches_the_autograd_wrapper_in_batch(adjacent):
                                                small[0:1].data_ptr(), small[1:4].data_ptr(), small[4:].data_ptr(),
                                                _native.current_stream_ptr(qt.device)))
     torch.cuda.synchronize()
-    np.testing.assert_allclose(scores.cpu().numpy(), out.retriever_scores.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(scores.cpu().numpy(), out.retriever_scores.cpu().numpy(), rtol=2e-4, atol=2e-4)  # fp32 sums of 768 products in 1 / 2 / 4 slabs
     np.testing.assert_allclose(small[0].item(), out.loss.item(), rtol=1e-5)
     np.testing.assert_allclose(small[1].item(), out.diagnostics["kl_score"].item(), rtol=1e-4, atol=1e-6)
