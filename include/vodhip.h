@@ -130,7 +130,7 @@ int vodhip_debug_schedule(int64_t ntotal, int k, int64_t nq, int64_t cand_cap, i
                           int64_t growth_x100, int tile, int recovery_pass, int n_cu, int64_t* out, int max_stages);
 int vodhip_index_get_stat(const vodhip_index_t* index, const char* key, int64_t* out);
 /* Diagnostic builds only (make ABLATION=1; production returns -1): phase stamps of workgroup 0 of the last launch of a
- * collate-side kernel (which: 0 = hybrid merge, 1 = priority sampling, 2 = in-batch flattening) as 64 pairs
+ * kernel (which: 0 = hybrid merge, 1 = priority sampling, 2 = in-batch flattening, 3 = the search's select kernel) as 64 pairs
  * (shader-clock cycles, 10 ns ticks of the constant 100 MHz counter), then the (begin, end) ticks of workgroups 0..63;
  * out holds n >= 256 values. */
 int vodhip_debug_read_probe(int which, int64_t* out, int n);

@@ -21,6 +21,7 @@
 //
 // Roofline: 2*nq*N*D flop per batch on MFMA vs N*D*2 bytes of HBM; arithmetic intensity = nq flop/B.
 #include "mips_common.h"
+#include "wg_sort.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -672,74 +673,159 @@ __device__ __forceinline__ void bitonic_sort_desc_lds(key_t64* keys, int P, int 
     __syncthreads();
 }
 
-// k-th largest of `total` 64-bit keys in LDS (zeros = padding, `total` >= k): MSB-first radix select, 8 passes of one
-// byte with a 256-bin LDS histogram.  Returns the key on every thread.  `hist` = 256 ints + scratch.
-__device__ key_t64 radix_select_kth_lds(const key_t64* keys, int total, int k, int* hist, int tid) {
-    // hist: [0..255] bins | 256 digit / key low | 257 rank / key high | 258 (caller's compaction counter) | 259 bin count
-    //       | 260..263 per-wave totals.  MSB-first byte passes; as soon as the bin that holds the k-th key holds ONE key
-    //       (typically after 3-4 of the 8 bytes: distinct float scores) that key is looked up directly.
-    key_t64 prefix = 0, mask = 0;
-    int rank = k;  // 1-based rank from the top among the keys that match the prefix
+// k-th largest of the workgroup's 64-bit keys, KPT per thread in REGISTERS (zeros = padding): MSB-first radix select, up to 8 bits
+// per pass with a 256-bin LDS histogram.  Returns the key on every thread (0 when fewer than k keys are real).
+//   * The keys never sit in LDS: every pass (and the caller's compaction) runs over statically indexed registers, so its LDS
+//     atomics issue back to back.  (Round 2 re-read the keys from LDS in a rolled loop each pass: ~70 ns of read latency per key.)
+//   * The score bits every real key shares are skipped up front (AND / OR of the high words: one wave reduction): they are the
+//     expensive passes - the sign / exponent byte of a batch of candidate scores is ONE bin, i.e. serialised LDS atomics - and the
+//     first digit starts AT the highest differing bit, so it spreads the keys over its bins.
+//   * Two barriers per pass: the bins alternate between two buffers (the idle one is cleared while the other is filled), and the
+//     suffix scan over the 256 bins is done by ONE wavefront (4 bins per lane, shuffle scan) which publishes digit / rank / bin size.
+//   * As soon as the bin that holds the k-th key holds ONE key (typically after 2 passes: distinct float scores) its holder
+//     publishes it.
+// hist (SEL_HIST_INTS ints): [0..255] | [256..511] bins | 512 digit | 513 rank | 514 bin size | 515 / 516 key low / high |
+//                            517 compaction counter (the caller's) | 520..531 per-wave reduction words.
+constexpr int SEL_HIST_INTS = 544;
+#ifdef VODHIP_ABLATION
+// phase stamps of workgroup 0: [0..7] the final select, [8..15] the threshold-only one, [16..23] a middle one; [24 + 10 * kind ..]
+// inside the radix select of that launch: after the AND / OR reduction, then (bins filled, digit published) per pass
+__device__ long long g_probe_select[256];
+#endif
+#define RSEL_PROBE(i) VODHIP_PROBE(g_probe_select, ppb + (i))
+template <int KPT>
+__device__ __forceinline__ key_t64 radix_select_kth_regs(const key_t64 (&mine)[KPT], int k, int* hist, int tid, [[maybe_unused]] int ppb) {
     const int lane = tid & 63, wave = tid >> 6;
-    for (int byte = 7; byte >= 0; --byte) {
-        hist[tid] = 0;
-        __syncthreads();
-        const int sh = byte * 8;
-        for (int i = tid; i < total; i += 256) {
-            const key_t64 e = keys[i];
-            if ((e & mask) == prefix) atomicAdd(&hist[(int)((e >> sh) & 255ull)], 1);
-        }
-        __syncthreads();
-        // suffix sums over the 256 bins: thread t learns above(t) = #keys in bins > t; exactly one t has
-        // above(t) < rank <= above(t) + hist[t].  Wave-level shuffle scan + 4 wave totals through LDS.
-        const int mine = hist[tid];
-        int v = mine;
+    unsigned a_hi = ~0u, o_hi = 0u;
+    int nz = 0;  // real keys of this WAVE (ballots: wave-uniform, no shuffle)
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int u = __shfl_down(v, off);
-            if (lane + off < 64) v += u;
+    for (int u = 0; u < KPT; ++u) {
+        const key_t64 e = mine[u];
+        const bool real = e != 0ull;
+        if (real) {
+            a_hi &= (unsigned)(e >> 32);
+            o_hi |= (unsigned)(e >> 32);
         }
-        if (lane == 0) hist[260 + wave] = v;
+        nz += __builtin_popcountll(__ballot(real));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a_hi &= (unsigned)__shfl_xor((int)a_hi, off);
+        o_hi |= (unsigned)__shfl_xor((int)o_hi, off);
+    }
+    hist[tid] = 0;  // the bins of the first pass
+    if (lane == 0) {
+        int* w = hist + 520 + wave * 3;
+        w[0] = (int)a_hi;
+        w[1] = (int)o_hi;
+        w[2] = nz;
+    }
+    __syncthreads();
+    a_hi = ~0u, o_hi = 0u, nz = 0;
+#pragma unroll
+    for (int w_ = 0; w_ < 4; ++w_) {
+        const int* w = hist + 520 + w_ * 3;
+        a_hi &= (unsigned)w[0];
+        o_hi |= (unsigned)w[1];
+        nz += w[2];
+    }
+    RSEL_PROBE(0);
+    if (nz < k) return 0ull;  // the k-th best is padding
+    // digits of up to 8 bits from the highest score bit in which two real keys differ; equal scores everywhere: the ids decide
+    const unsigned diff_hi = a_hi ^ o_hi;
+    int hi_bit = diff_hi ? 63 - __builtin_clz(diff_hi) : 31;
+    key_t64 mask = hi_bit == 63 ? 0ull : ~0ull << (hi_bit + 1);
+    key_t64 prefix = ((key_t64)a_hi << 32) & mask;
+    int rank = k;  // 1-based rank from the top among the real keys that match the prefix
+    for (int pass = 0; hi_bit >= 0; ++pass) {
+        int* bins = hist + (pass & 1) * 256;
+        const int w = min(8, hi_bit + 1), sh = hi_bit + 1 - w;
+        const key_t64 dmask = (1ull << w) - 1ull;
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) {
+            const key_t64 e = mine[u];
+            if (e != 0ull && (e & mask) == prefix) atomicAdd(&bins[(int)((e >> sh) & dmask)], 1);
+        }
+        hist[(((pass + 1) & 1) << 8) + tid] = 0;  // the other buffer: its last reader finished before the previous pass's second barrier
         __syncthreads();
-        int above = v - mine;
-        for (int w = wave + 1; w < 4; ++w) above += hist[260 + w];
-        if (above < rank && rank <= above + mine) {
-            hist[256] = tid;
-            hist[257] = rank - above;
-            hist[259] = mine;
+        if (pass < 4) RSEL_PROBE(1 + 2 * pass);
+        if (wave == 0) {
+            // lane l owns bins 4l .. 4l+3; suffix sums: inside the lane, then over the lanes above it
+            const int4 h = *reinterpret_cast<const int4*>(bins + 4 * lane);
+            const int s3 = h.w, s2 = s3 + h.z, s1 = s2 + h.y, s0 = s1 + h.x;
+            int v = s0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int u = __shfl_down(v, off);
+                if (lane + off < 64) v += u;
+            }
+            const int above_lane = v - s0;  // keys in the bins of higher lanes
+            const int ab[4] = {above_lane + s1, above_lane + s2, above_lane + s3, above_lane};
+            const int hh[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ab[j] < rank && rank <= ab[j] + hh[j]) {  // exactly one (lane, j) satisfies this
+                    hist[512] = 4 * lane + j;
+                    hist[513] = rank - ab[j];
+                    hist[514] = hh[j];
+                }
         }
         __syncthreads();
-        const int digit = hist[256];
-        rank = hist[257];
-        const int in_bin = hist[259];
+        if (pass < 4) RSEL_PROBE(2 + 2 * pass);
+        const int digit = hist[512];
+        rank = hist[513];
+        const int in_bin = hist[514];
         prefix |= (key_t64)digit << sh;
-        mask |= 255ull << sh;
-        __syncthreads();
-        if (in_bin == 1 && byte > 0) {  // workgroup-uniform: the k-th key is the only one with this prefix
-            for (int i = tid; i < total; i += 256) {
-                const key_t64 e = keys[i];
-                if ((e & mask) == prefix) {
-                    hist[256] = (int)(unsigned)(e & 0xFFFFFFFFull);
-                    hist[257] = (int)(unsigned)(e >> 32);
+        mask |= dmask << sh;
+        hi_bit = sh - 1;
+        if (in_bin == 1 && hi_bit >= 0) {  // workgroup-uniform: the k-th key is the only real key with this prefix
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) {
+                const key_t64 e = mine[u];
+                if (e != 0ull && (e & mask) == prefix) {
+                    hist[515] = (int)(unsigned)(e & 0xFFFFFFFFull);
+                    hist[516] = (int)(unsigned)(e >> 32);
                 }
             }
             __syncthreads();
-            const key_t64 kth = ((key_t64)(unsigned)hist[257] << 32) | (key_t64)(unsigned)hist[256];
-            __syncthreads();
-            return kth;
+            return ((key_t64)(unsigned)hist[516] << 32) | (key_t64)(unsigned)hist[515];
         }
     }
     return prefix;
 }
 
-// One workgroup per query.  The LDS buffer holds SB keys (SB >= 2*kp, power of two): the running top-k sits in
-// front, candidates are folded in rounds of SB - kp.  Between stages only the k-th best key (the threshold) and the
-// SET of the k best are needed, so intermediate launches use a radix select + compaction (unsorted top-k);
-// the last launch of a search (SELECT_FINAL) then sorts those k and writes the result rows.
+// The kp keys of `keys` (the k best, unordered, zeros behind) sorted descending.  Up to 512 keys ONE wavefront sorts them in its
+// registers (1-8 keys per lane, shuffles only: the 28 barrier-separated LDS stages this replaces were more than half of the last
+// select of a search; ranking by counting - kp * kp / 256 broadcast LDS reads per thread, no dependent chain - measured 3.0 us
+// against 1.8); above that the 256-thread register network of wg_sort.h.
+__device__ __forceinline__ void sort_front_desc(key_t64* keys, int kp, int tid) {
+    __syncthreads();
+    if (kp <= 512) {
+        if (tid < 64) {
+            switch (kp) {
+                case 64: wave_sort_regs<1, true>(keys, tid); break;
+                case 128: wave_sort_regs<2, true>(keys, tid); break;
+                case 256: wave_sort_regs<4, true>(keys, tid); break;
+                default: wave_sort_regs<8, true>(keys, tid); break;
+            }
+        }
+        __syncthreads();
+    } else if (!wg_sort_lds_256<true>(keys, kp, tid)) {
+        bitonic_sort_desc_lds(keys, kp, tid);
+    }
+}
+
+// One workgroup per query; every thread holds KPT keys in registers (256 * KPT >= 2 * kp): the running top-k (kp keys) plus up to
+// 256 * KPT - kp candidates per round.  Between stages only the k-th best key (the threshold) and the SET of the k best are needed, so
+// intermediate launches use a radix select + compaction (unsorted top-k); the last launch of a search (SELECT_FINAL) then sorts
+// those k and writes the result rows.
 // SELECT_THRESHOLD_ONLY (after a GMAX stage): the candidates are group maxima, not rows - only the threshold leaves.
 // The threshold never decreases: a stage whose candidates do not fill the top-k keeps the bound it was given.
+// LDS: the histogram words + `front`, kp keys: where a round's survivors are gathered (and sorted, and read by the next round).
 enum : int { SELECT_FINAL = 1, SELECT_THRESHOLD_ONLY = 2 };
-__global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ topk, int kp, int k, int sb,
+#define SEL_PROBE(i) VODHIP_PROBE(g_probe_select, pb + (i))
+template <int KPT>
+__global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ topk, int kp, int k,
                                                           const key_t64* __restrict__ cand,
                                                           unsigned int* __restrict__ cnt, int cap, int dense_n,
                                                           float* __restrict__ thr_s, key_t64* __restrict__ thr_key,
@@ -747,12 +833,24 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
                                                           int64_t id_base, float* __restrict__ out_scores,
                                                           int64_t* __restrict__ out_ids, const int* __restrict__ q_map) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    key_t64* keys = (key_t64*)smem;
-    int* hist = (int*)(keys + sb);  // 264 ints: bins, scratch words, compaction counter at [258] (see radix_select_kth_lds)
+    int* hist = (int*)smem;  // SEL_HIST_INTS ints: two sets of bins, scratch words, compaction counter at [517] (see radix_select_kth_regs)
+    key_t64* front = (key_t64*)(hist + SEL_HIST_INTS);
     const int q = blockIdx.x;
     const int tid = threadIdx.x;
     const bool final_sort = (flags & SELECT_FINAL) != 0;
     const bool thr_only = (flags & SELECT_THRESHOLD_ONLY) != 0;
+    [[maybe_unused]] const int pb = final_sort ? 0 : thr_only ? 8 : 16;
+    SEL_PROBE(0);
+    // The first round's keys are requested BEFORE the candidate count is known (the candidate buffer holds `cap` slots per query
+    // whatever the count): one global-memory latency instead of two in a kernel that lasts a few microseconds.
+    key_t64 mine[KPT];
+    const key_t64* cq = cand + (size_t)q * cap;
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const int i = tid + u * 256;
+        if (i < kp) mine[u] = thr_only ? 0ull : topk[(size_t)q * kp + i];
+        else mine[u] = (i - kp) < cap ? cq[i - kp] : 0ull;
+    }
     unsigned n = dense_n >= 0 ? (unsigned)dense_n : cnt[(size_t)q * CNT_STRIDE];
     if (n > (unsigned)cap) {  // this query lost candidates in this stage: the host recovers it (and only it)
         if (tid == 0) {
@@ -761,47 +859,68 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
         }
         n = cap;
     }
-    for (int i = tid; i < kp; i += 256) keys[i] = thr_only ? 0ull : topk[(size_t)q * kp + i];
-    const int room = sb - kp;
+    const int room = KPT * 256 - kp;
     int done = 0;
     key_t64 kth = 0;
     do {
         const int take = min((int)n - done, room);
         const int total = kp + take;
-        {
-            for (int i = kp + tid; i < total; i += 256) keys[i] = cand[(size_t)q * cap + done + (i - kp)];
-            __syncthreads();
-            kth = radix_select_kth_lds(keys, total, k, hist, tid);  // total >= kp >= k (zeros pad the running top-k)
-            // compaction: the keys >= kth (exactly k of them unless kth == 0) move to the front, zeros behind
-            key_t64 mine[32];  // SB <= 8192 keys / 256 threads
-            int n_mine = 0;
-            for (int i = tid; i < total; i += 256) {
-                const key_t64 e = keys[i];
-                if (e >= kth && e != 0ull && n_mine < 32) mine[n_mine++] = e;
-            }
-            if (tid == 0) hist[258] = 0;
-            __syncthreads();
-            int base = n_mine ? atomicAdd(&hist[258], n_mine) : 0;
-            __syncthreads();  // every thread has read its keys before anyone overwrites the front
-            for (int i = tid; i < kp; i += 256) keys[i] = 0ull;
-            __syncthreads();
+        if (done > 0) {  // a further round (rare): the survivors so far + the next candidates
 #pragma unroll
-            for (int u = 0; u < 32; ++u)
-                if (u < n_mine) keys[base + u] = mine[u];
+            for (int u = 0; u < KPT; ++u) {
+                const int i = tid + u * 256;
+                mine[u] = i < kp ? front[i] : (i < total ? cq[done + (i - kp)] : 0ull);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < KPT; ++u)
+                if (tid + u * 256 >= total) mine[u] = 0ull;  // slots behind the count hold stale keys of an earlier stage
+        }
+        if (tid == 0) hist[517] = 0;  // compaction counter (ordered by the barriers inside the select)
+        SEL_PROBE(1);
+        kth = radix_select_kth_regs<KPT>(mine, k, hist, tid, 24 + 10 * (pb >> 3));
+        SEL_PROBE(2);
+        done += take;
+        // compaction: the keys >= kth (exactly k of them unless kth == 0) are gathered in `front`, zeros behind.  Not needed when
+        // only the threshold leaves and no further round follows.
+        if (!thr_only || done < (int)n) {
+            // slots by ballot: a key's position = the wave's base + the survivors of this wave before it (earlier register slots,
+            // then lower lanes); ONE LDS atomic per wave (256 same-address atomics with return cost ~1 us)
+            unsigned long long keep[KPT];
+            int n_wave = 0;
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) {
+                keep[u] = __ballot(mine[u] >= kth && mine[u] != 0ull);
+                n_wave += __builtin_popcountll(keep[u]);
+            }
+            int base = 0;
+            if ((tid & 63) == 0 && n_wave) base = atomicAdd(&hist[517], n_wave);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) {
+                const int at = base + __builtin_popcountll(keep[u] & below);
+                if (((keep[u] >> (tid & 63)) & 1ull) && at < kp) front[at] = mine[u];
+                base += __builtin_popcountll(keep[u]);
+            }
+            __syncthreads();
+            const int n_kept = min(hist[517], kp);
+            for (int i = n_kept + tid; i < kp; i += 256) front[i] = 0ull;
             __syncthreads();
         }
-        done += take;
     } while (done < (int)n);
-    if (final_sort) {  // the k best are in front, unordered: only they are sorted
-        bitonic_sort_desc_lds(keys, kp, tid);
-        kth = keys[k - 1];
+    SEL_PROBE(3);
+    if (final_sort) {  // the k best are in `front`, unordered
+        sort_front_desc(front, kp, tid);
+        kth = front[k - 1];
     }
+    SEL_PROBE(4);
     if (!thr_only)
-        for (int i = tid; i < kp; i += 256) topk[(size_t)q * kp + i] = keys[i];
+        for (int i = tid; i < kp; i += 256) topk[(size_t)q * kp + i] = front[i];
     if (out_scores != nullptr) {  // last select of a search: the sorted keys leave as (float32 score, int64 id) rows
         const size_t qo = q_map ? (size_t)q_map[q] : (size_t)q;
         for (int c = tid; c < k; c += 256) {
-            const key_t64 key = keys[c];
+            const key_t64 key = front[c];
             out_scores[qo * k + c] = key ? unflip_f32((unsigned)(key >> 32)) : -__builtin_inff();
             out_ids[qo * k + c] = key ? id_base + (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)) : -1;
         }
@@ -815,6 +934,14 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
             thr_s[q] = unflip_f32((unsigned)(kth >> 32));
         }
         cnt[(size_t)q * CNT_STRIDE] = 0;
+    }
+    SEL_PROBE(5);
+    if (tid == 0 && q == 0) {
+        [[maybe_unused]] const long long nn = (long long)n;
+#ifdef VODHIP_ABLATION
+        g_probe_select[2 * (pb + 6)] = nn;  // candidates this launch folded for query 0
+        g_probe_select[2 * (pb + 6) + 1] = 1;
+#endif
     }
 }
 
@@ -1078,20 +1205,29 @@ hipError_t launch_filter(int store_dtype, int tile, int mode, const void* store,
     return store_dtype == 0 ? launch_filter_dt<0>(tile, mode, subset, L) : launch_filter_dt<1>(tile, mode, subset, L);
 }
 
-hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, int flags, hipStream_t stream,
-                         int64_t id_base, float* out_scores, int64_t* out_ids, const int* q_map) {
-    // keys per workgroup buffer: 16 KB -> 8 workgroups per CU; a stage with a KNOWN large candidate count per query (the
-    // bootstrap's group maxima) gets a buffer that takes them in one round
-    int sb = 2048;
-    while (sb < 2 * ws.kp) sb <<= 1;
-    while (dense_n > sb - ws.kp && sb < 8192) sb <<= 1;
-    const size_t lds = (size_t)sb * sizeof(key_t64) + 264 * sizeof(int);
-    if (hipError_t e = allow_dynamic_lds((const void*)mips_select_kernel, 8192 * (int)sizeof(key_t64) + 264 * (int)sizeof(int)); e != hipSuccess) return e;
+template <int KPT>
+static hipError_t launch_select_kpt(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, int flags, hipStream_t stream,
+                                    int64_t id_base, float* out_scores, int64_t* out_ids, const int* q_map) {
+    const size_t lds = SEL_HIST_INTS * sizeof(int) + (size_t)ws.kp * sizeof(key_t64);
     const bool final_sort = (flags & SELECT_FINAL) != 0;
-    hipLaunchKernelGGL(mips_select_kernel, dim3((unsigned)nq), dim3(256), lds, stream, ws.topk, (int)ws.kp, k, sb, ws.cand,
+    hipLaunchKernelGGL(mips_select_kernel<KPT>, dim3((unsigned)nq), dim3(256), lds, stream, ws.topk, (int)ws.kp, k, ws.cand,
                        ws.cnt, (int)ws.cap, (int)dense_n, ws.thr_s, ws.thr_key, ws.overflow, ws.ovf_q, flags, id_base,
                        final_sort ? out_scores : nullptr, final_sort ? out_ids : nullptr, q_map);
     return hipGetLastError();
+}
+
+hipError_t launch_select(const SearchWorkspace& ws, int64_t nq, int k, int64_t dense_n, int flags, hipStream_t stream,
+                         int64_t id_base, float* out_scores, int64_t* out_ids, const int* q_map) {
+    // keys per round: 2048 (8 per thread) unless the running top-k alone needs more; a stage with a KNOWN large candidate count per
+    // query (the bootstrap's group maxima) gets a round that takes them at once
+    int sb = 2048;
+    while (sb < 2 * ws.kp) sb <<= 1;
+    while (dense_n > sb - ws.kp && sb < 8192) sb <<= 1;
+    switch (sb) {
+        case 2048: return launch_select_kpt<8>(ws, nq, k, dense_n, flags, stream, id_base, out_scores, out_ids, q_map);
+        case 4096: return launch_select_kpt<16>(ws, nq, k, dense_n, flags, stream, id_base, out_scores, out_ids, q_map);
+        default: return launch_select_kpt<32>(ws, nq, k, dense_n, flags, stream, id_base, out_scores, out_ids, q_map);
+    }
 }
 
 hipError_t launch_output(const SearchWorkspace& ws, int64_t nq, int k, int64_t id_base, float* out_scores,
@@ -1235,6 +1371,15 @@ hipError_t launch_merge_topk(const float* scores, const int64_t* ids, int64_t st
     hipLaunchKernelGGL(merge_topk_kernel, dim3((unsigned)nq), dim3(256), lds, stream, scores, ids, stride_s, stride_i, n_shards, nq, k,
                        k_out, L, S2, flat, out_scores, out_ids);
     return hipGetLastError();
+}
+
+hipError_t read_probe_select(long long* out) {
+#ifdef VODHIP_ABLATION
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe_select), sizeof(long long) * 256);
+#else
+    (void)out;
+    return hipErrorNotSupported;
+#endif
 }
 
 }  // namespace vodhip

@@ -1109,7 +1109,7 @@ int vodhip_gather_by_id(const int64_t* queries, int64_t n_queries, const int64_t
 int vodhip_debug_read_probe(int which, int64_t* out, int n) {
     if (!out || n < 256) return fail("out must hold 256 values");
     static_assert(sizeof(long long) == sizeof(int64_t), "probe words are 64-bit");
-    const hipError_t e = which == 0 ? read_probe_hybrid((long long*)out) : read_probe_sample(which, (long long*)out);
+    const hipError_t e = which == 0 ? read_probe_hybrid((long long*)out) : which == 3 ? read_probe_select((long long*)out) : read_probe_sample(which, (long long*)out);
     if (e == hipErrorNotSupported) return fail("phase stamps exist in diagnostic builds only (make ABLATION=1)");
     if (e != hipSuccess) return fail("HIP error: %s", hipGetErrorString(e));
     return 0;

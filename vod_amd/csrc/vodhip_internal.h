@@ -34,6 +34,7 @@ void set_last_error(const char* msg);  // the calling thread's vodhip_last_error
 // which: 0 = merge_hybrid_kernel, 1 = priority_sample_kernel, 2 = flatten_inbatch_kernel; out: 256 words = 64 (cycles, 10 ns ticks) phase pairs + 64 (begin, end) workgroup pairs
 hipError_t read_probe_hybrid(long long* out);
 hipError_t read_probe_sample(int which, long long* out);
+hipError_t read_probe_select(long long* out);  // which = 3: mips_select_kernel (final | threshold-only | middle launch at [0], [8], [16])
 
 // 64-bit order-preserving result key: high 32 bits = monotone image of the fp32 score, low 32 bits =
 // 0xFFFFFFFF - local row id.  Larger key == better hit (higher score; on equal score the smaller id).

@@ -75,6 +75,46 @@ __device__ void wg_sort_regs(K* buf, int tid) {
     __syncthreads();
 }
 
+// ONE wavefront sorts the 64 * E keys of `buf` (LDS) in its registers: no barrier inside - the caller orders the LDS accesses of
+// the other wavefronts around it.  Only lanes of one wavefront call it (`lane` = 0..63).
+template <int E, bool DESC, typename K>
+__device__ void wave_sort_regs(K* buf, int lane) {
+    constexpr int P = 64 * E;
+    K v[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) v[j] = buf[lane * E + j];
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride >= E; stride >>= 1) {  // partner in another lane
+            const int lane_mask = stride / E;
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const int i = lane * E + j;
+                const K o = wg_shfl_xor64(v[j], lane_mask);
+                const bool keep_min = ((i & stride) == 0) == (((i & size) == 0) != DESC);
+                v[j] = ((o < v[j]) == keep_min) ? o : v[j];
+            }
+        }
+#pragma unroll
+        for (int st = E / 2; st > 0; st >>= 1) {  // partner in another register of this lane
+            if (st < size) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    if ((j & st) == 0) {
+                        const int i = lane * E + j;
+                        const bool up = ((i & size) == 0) != DESC;
+                        const K x = v[j], y = v[j + st];
+                        const bool sw = (y < x) == up;
+                        v[j] = sw ? y : x;
+                        v[j + st] = sw ? x : y;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) buf[lane * E + j] = v[j];
+}
+
 // Sort `P` keys in LDS with a 256-thread workgroup (P = 256, 512, ..., 4096; a power of two).  Returns false otherwise.
 // One out-of-line copy per size: the sampling kernel sorts at two sites.
 template <int E, bool DESC, typename K>
