@@ -687,6 +687,20 @@ __device__ __forceinline__ void bitonic_sort_desc_lds(key_t64* keys, int P, int 
 // hist (SEL_HIST_INTS ints): [0..255] | [256..511] bins | 512 digit | 513 rank | 514 bin size | 515 / 516 key low / high |
 //                            517 compaction counter (the caller's) | 520..531 per-wave reduction words.
 constexpr int SEL_HIST_INTS = 544;
+
+// Wave-wide inclusive scan / reduction with DPP row shifts and row broadcasts (GFX9 encodings: row_shr:n = 0x110 + n, row_bcast:15 =
+// 0x142, row_bcast:31 = 0x143): six VALU instructions instead of six ds_bpermute round trips (~100 cycles each) - the select kernel
+// is a chain of such steps.  After the sequence lane l holds op(values of lanes 0..l); lane 63 the reduction.
+template <typename Op>
+__device__ __forceinline__ int wave_scan_dpp(int v, int identity, Op op) {
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xf, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xf, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xf, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xf, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xa, 0xf, false));  // lane 15 / 47 -> rows 1 / 3
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xc, 0xf, false));  // lane 31 -> rows 2 and 3
+    return v;
+}
 #ifdef VODHIP_ABLATION
 // phase stamps of workgroup 0: [0..7] the final select, [8..15] the threshold-only one, [16..23] a middle one; [24 + 10 * kind ..]
 // inside the radix select of that launch: after the AND / OR reduction, then (bins filled, digit published) per pass
@@ -708,13 +722,10 @@ __device__ __forceinline__ key_t64 radix_select_kth_regs(const key_t64 (&mine)[K
         }
         nz += __builtin_popcountll(__ballot(real));
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        a_hi &= (unsigned)__shfl_xor((int)a_hi, off);
-        o_hi |= (unsigned)__shfl_xor((int)o_hi, off);
-    }
+    a_hi = (unsigned)wave_scan_dpp((int)a_hi, -1, [](int x, int y) { return x & y; });
+    o_hi = (unsigned)wave_scan_dpp((int)o_hi, 0, [](int x, int y) { return x | y; });
     hist[tid] = 0;  // the bins of the first pass
-    if (lane == 0) {
+    if (lane == 63) {  // holds the reductions
         int* w = hist + 520 + wave * 3;
         w[0] = (int)a_hi;
         w[1] = (int)o_hi;
@@ -750,22 +761,17 @@ __device__ __forceinline__ key_t64 radix_select_kth_regs(const key_t64 (&mine)[K
         __syncthreads();
         if (pass < 4) RSEL_PROBE(1 + 2 * pass);
         if (wave == 0) {
-            // lane l owns bins 4l .. 4l+3; suffix sums: inside the lane, then over the lanes above it
-            const int4 h = *reinterpret_cast<const int4*>(bins + 4 * lane);
+            // lane l owns bins 252 - 4l .. 255 - 4l (the HIGH bins sit in the low lanes: a prefix scan over the lanes counts the keys
+            // above); suffix sums inside the lane, prefix scan over the lanes
+            const int4 h = *reinterpret_cast<const int4*>(bins + 252 - 4 * lane);
             const int s3 = h.w, s2 = s3 + h.z, s1 = s2 + h.y, s0 = s1 + h.x;
-            int v = s0;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int u = __shfl_down(v, off);
-                if (lane + off < 64) v += u;
-            }
-            const int above_lane = v - s0;  // keys in the bins of higher lanes
+            const int above_lane = wave_scan_dpp(s0, 0, [](int x, int y) { return x + y; }) - s0;  // keys in the bins of LOWER lanes
             const int ab[4] = {above_lane + s1, above_lane + s2, above_lane + s3, above_lane};
             const int hh[4] = {h.x, h.y, h.z, h.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (ab[j] < rank && rank <= ab[j] + hh[j]) {  // exactly one (lane, j) satisfies this
-                    hist[512] = 4 * lane + j;
+                    hist[512] = 252 - 4 * lane + j;
                     hist[513] = rank - ab[j];
                     hist[514] = hh[j];
                 }
