@@ -176,6 +176,11 @@ int vodhip_node_index_ntotal(const vodhip_node_index_t* index, int64_t* out);
 int vodhip_node_index_n_shards(const vodhip_node_index_t* index);
 int vodhip_node_index_shard(vodhip_node_index_t* index, int g, vodhip_index_t** shard, int64_t* id_base, int* device);
 int vodhip_node_index_set_param(vodhip_node_index_t* index, const char* key, int64_t value);  /* on every shard */
+/* The subset filter of vodhip_index_set_row_labels / _set_query_labels behind the one handle: `labels` = HOST int32 [n_rows] for the
+ * global rows 0 .. n_rows-1 (NULL clears); `q_labels` = int32 [nq, n_per_query] of the NEXT searches' batches, host memory or on
+ * devices[0] (`location`), caller-owned until cleared with NULL; replicated to every device with the queries. */
+int vodhip_node_index_set_row_labels(vodhip_node_index_t* index, const int32_t* labels, int64_t n_rows);
+int vodhip_node_index_set_query_labels(vodhip_node_index_t* index, const int32_t* q_labels, int n_per_query, int location);
 int vodhip_node_index_search(vodhip_node_index_t* index, const void* queries, int q_dtype, int64_t nq, int k, int location,
                              float* out_scores, int64_t* out_ids, void* stream);
 

@@ -110,3 +110,35 @@ def test_errors_are_reported_not_thrown_across_the_boundary():
     s = torch.randn(4, 3, 16, device="cuda")
     batch = {"section__score": torch.zeros(4, 3, device="cuda"), "section__relevance": torch.ones(4, 3, dtype=torch.int64, device="cuda")}
     assert torch.isfinite(RetrievalGradients()(batch=batch, query_encoding=q, section_encoding=s).loss)
+
+
+def test_subset_labels_travel_to_every_shard():
+    """Row labels split by shard, per-query allowed labels replicated with the queries: exact top-k over the eligible rows."""
+    from vod_amd.index import HipNodeIndex
+
+    q, x = _int_data(8, 30_000, 64, 12)
+    rng = np.random.default_rng(8)
+    labels = rng.integers(0, 7, size=len(x)).astype(np.int32)
+    subset = np.full((len(q), 3), -1, dtype=np.int32)
+    for r in range(len(q)):
+        picks = rng.choice(7, size=rng.integers(0, 4), replace=False)  # 0 picks = unrestricted
+        subset[r, : len(picks)] = picks
+    subset[3] = [-2, -1, -1]  # an unknown label: restricted and empty
+    k = 20
+    with HipNodeIndex(64, len(x), [0, 0, 0]) as nx:
+        nx.add(x)
+        nx.set_row_labels(labels)
+        s, i = nx.search(q, k, subset=subset)
+        ref = q.astype(np.float64) @ x.astype(np.float64).T
+        for r in range(len(q)):
+            allowed = subset[r][subset[r] != -1]
+            ok = np.ones(len(x), bool) if len(allowed) == 0 else np.isin(labels, allowed)
+            sc = np.where(ok, ref[r], -np.inf)
+            order = np.lexsort((np.arange(len(x)), -sc))[:k]
+            n_ok = int(min(k, ok.sum()))
+            np.testing.assert_array_equal(i[r, :n_ok], order[:n_ok])
+            np.testing.assert_array_equal(s[r, :n_ok], sc[order[:n_ok]].astype(np.float32))
+            assert (i[r, n_ok:] == -1).all()
+        s2, i2 = nx.search(q, k)  # cleared again: unrestricted
+        rs, ri = _oracle(q, x, k)
+        np.testing.assert_array_equal(i2, ri)

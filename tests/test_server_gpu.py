@@ -231,6 +231,54 @@ def test_multi_gpu_group_server_three_workers_sharing_the_gpu(tmp_path):
     np.testing.assert_array_equal(res.scores, ms)
 
 
+def test_single_process_node_server_three_shards(tmp_path):
+    """`devices=[0, 0, 0], group_backend="node"`: no worker processes - the ONE server process drives every device through
+    `vodhip_node_index_*` (the shape of the reference's server with `faiss.index_cpu_to_all_gpus(shard=True)`).  Same contract as
+    the worker groups above: the oracle's answer over the whole store, subset filter included, errors as HTTP 500."""
+    import requests
+
+    from oracle.flat_ip import flat_ip_topk, topk_desc_tiebreak
+    from vod_amd import store
+    from vod_amd.search.client import HipMipsClient, HipMipsMaster
+
+    rng = np.random.default_rng(22)
+    n, d, nq, k = 50_000, 128, 130, 100
+    x = rng.integers(-6, 7, size=(n, d)).astype(np.float32)
+    q = rng.integers(-6, 7, size=(nq, d)).astype(np.float32)
+    names = np.array([f"doc{v}" for v in rng.integers(0, 5, size=n)])
+    store.save_vectors(tmp_path / "v.npy", x, dtype=np.float16)
+    np.save(tmp_path / "subsets.npy", names)
+
+    class Master(HipMipsMaster):
+        def _make_cmd(self):
+            return super()._make_cmd() + ["--subset-ids-path", str(tmp_path / "subsets.npy")]
+
+    subset_ids = [[f"doc{r % 5}", "doc4"] if r % 2 else [] for r in range(40)]
+    with Master(tmp_path / "v.npy", port=-1, logging_level="warning", devices=[0, 0, 0], group_backend="node") as m:
+        c = HipMipsClient(host=m.host, port=m.port, forward_subset_ids=True)
+        assert c.ping()
+        for lo, hi, kk in [(0, nq, k), (5, 6, 3), (0, 70, 250)]:
+            res = c.search(vector=q[lo:hi], top_k=kk)
+            rs, ri = flat_ip_topk(q[lo:hi], x, kk)
+            np.testing.assert_array_equal(res.indices, ri)
+            np.testing.assert_array_equal(res.scores, rs)
+        for bad_k in (0, 5000):
+            with pytest.raises(requests.HTTPError):
+                c.search(vector=q[:4], top_k=bad_k)
+        with pytest.raises(requests.HTTPError):
+            c.search(vector=q[:4, :7], top_k=5)
+        assert c.ping()
+        res = c.search(vector=q[:40], subset_ids=subset_ids, top_k=20)
+    assert not m.get_client().ping()
+    masked = q[:40].astype(np.float64) @ x.astype(np.float64).T
+    for r, names_r in enumerate(subset_ids):
+        if names_r:
+            masked[r, ~np.isin(names, names_r)] = np.nan
+    ms, mi = topk_desc_tiebreak(masked, 20)
+    np.testing.assert_array_equal(res.indices, mi)
+    np.testing.assert_array_equal(res.scores, ms)
+
+
 def test_micro_batcher_on_the_gpu_engine_mixes_plain_and_subset_requests(tmp_path):
     """SURVEY 8(f) row 4 on the real engine: concurrent requests are fused into shared GPU batches, each caller gets its
     own rows / k, and subset requests (which bypass the batcher) are serialised with the fused batches by ONE lock

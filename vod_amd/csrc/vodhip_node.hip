@@ -44,7 +44,8 @@ struct ShardBuffers {
     void* q = nullptr;          // the query batch on this shard's device
     float* scores = nullptr;    // this shard's top-k [nq, k]
     int64_t* ids = nullptr;
-    size_t q_bytes = 0, res_elems = 0;
+    int32_t* q_labels = nullptr;  // the batch's allowed subset labels on this shard's device
+    size_t q_bytes = 0, res_elems = 0, q_label_elems = 0;
 };
 
 }  // namespace
@@ -64,6 +65,9 @@ struct vodhip_node_index {
     float* merged_scores = nullptr;    // devices[0]: [nq, k] (host-located outputs)
     int64_t* merged_ids = nullptr;
     size_t gathered_elems = 0, merged_elems = 0;
+    const int32_t* q_labels = nullptr;  // the caller's per-query labels for the next searches (host, or devices[0])
+    int q_labels_per_query = 0, q_labels_location = VODHIP_HOST;
+    bool has_row_labels = false;
 };
 
 namespace {
@@ -130,6 +134,7 @@ int vodhip_node_index_destroy(vodhip_node_index_t* nx) {
         (void)hipFree(nx->buf[g].q);
         (void)hipFree(nx->buf[g].scores);
         (void)hipFree(nx->buf[g].ids);
+        (void)hipFree(nx->buf[g].q_labels);
         if (nx->arrived[g]) (void)hipEventDestroy(nx->arrived[g]);
         if (nx->stream[g]) (void)hipStreamDestroy(nx->stream[g]);
     }
@@ -205,6 +210,33 @@ int vodhip_node_index_shard(vodhip_node_index_t* nx, int g, vodhip_index_t** sha
     return 0;
 }
 
+int vodhip_node_index_set_row_labels(vodhip_node_index_t* nx, const int32_t* labels, int64_t n_rows) {
+    if (!nx) return nfail("index is NULL");
+    if (labels && (n_rows < 0 || n_rows > nx->capacity)) return nfail("n_rows=%lld out of range", (long long)n_rows);
+    for (int g = 0; g < nx->n; ++g) {
+        const int64_t lo = std::min<int64_t>(n_rows, g * nx->rows_per_shard), hi = std::min<int64_t>(n_rows, lo + nx->rows_per_shard);
+        if (!labels) {
+            if (vodhip_index_set_row_labels(nx->shard[g], nullptr, 0, VODHIP_HOST, nullptr)) return -1;
+        } else if (vodhip_index_set_row_labels(nx->shard[g], labels + lo, hi - lo, VODHIP_HOST, nx->stream[g])) {
+            return -1;
+        }
+    }
+    nx->has_row_labels = labels != nullptr;
+    if (!labels) nx->q_labels = nullptr;
+    return 0;
+}
+
+int vodhip_node_index_set_query_labels(vodhip_node_index_t* nx, const int32_t* q_labels, int n_per_query, int location) {
+    if (!nx) return nfail("index is NULL");
+    if (q_labels && (n_per_query < 1 || n_per_query > 64)) return nfail("n_per_query must be in [1, 64]");
+    if (q_labels && !nx->has_row_labels) return nfail("set the row labels first (vodhip_node_index_set_row_labels)");
+    if (location != VODHIP_HOST && location != VODHIP_DEVICE) return nfail("invalid location %d", location);
+    nx->q_labels = q_labels;
+    nx->q_labels_per_query = q_labels ? n_per_query : 0;
+    nx->q_labels_location = location;
+    return 0;
+}
+
 int vodhip_node_index_set_param(vodhip_node_index_t* nx, const char* key, int64_t value) {
     if (!nx) return nfail("index is NULL");
     for (int g = 0; g < nx->n; ++g)
@@ -261,6 +293,19 @@ int vodhip_node_index_search(vodhip_node_index_t* nx, const void* queries, int q
             NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], nx->ready, 0));
             if (nx->device[g] == dev0) NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q, queries, q_bytes, hipMemcpyDeviceToDevice, nx->stream[g]));
             else NODE_HIP_OK(hipMemcpyPeerAsync(nx->buf[g].q, nx->device[g], queries, dev0, q_bytes, nx->stream[g]));
+        }
+        if (nx->q_labels) {  // the batch's subset labels travel with the queries
+            const size_t n_lab = (size_t)nq * (size_t)nx->q_labels_per_query;
+            if (ensure((void**)&nx->buf[g].q_labels, &nx->buf[g].q_label_elems, n_lab, sizeof(int32_t))) return -1;
+            if (nx->q_labels_location == VODHIP_HOST)
+                NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q_labels, nx->q_labels, n_lab * sizeof(int32_t), hipMemcpyHostToDevice, nx->stream[g]));
+            else if (nx->device[g] == dev0)
+                NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q_labels, nx->q_labels, n_lab * sizeof(int32_t), hipMemcpyDeviceToDevice, nx->stream[g]));
+            else
+                NODE_HIP_OK(hipMemcpyPeerAsync(nx->buf[g].q_labels, nx->device[g], nx->q_labels, dev0, n_lab * sizeof(int32_t), nx->stream[g]));
+            if (vodhip_index_set_query_labels(nx->shard[g], nx->buf[g].q_labels, nx->q_labels_per_query)) return -1;
+        } else if (nx->has_row_labels) {
+            if (vodhip_index_set_query_labels(nx->shard[g], nullptr, 0)) return -1;
         }
         // a G = 1 index writes the caller's / the merged buffers directly
         float* s_out = G == 1 ? final_scores : nx->buf[g].scores;

@@ -347,8 +347,28 @@ class HipNodeIndex:
         code = 2 if v.dtype == np.float32 else 0
         _native.check(self._lib.vodhip_node_index_add(self._h, v.ctypes.data, v.shape[0], code))
 
-    def search(self, queries: np.ndarray | torch.Tensor, k: int):
-        """NumPy in -> NumPy out (host buffers, synchronous); a tensor on `devices[0]` in -> tensors there, complete on the current stream."""
+    def set_row_labels(self, labels: np.ndarray | None) -> None:
+        """One int32 subset label per stored row (global row order; None clears): see `HipFlatIndex.set_row_labels`."""
+        if labels is None:
+            _native.check(self._lib.vodhip_node_index_set_row_labels(self._h, None, 0))
+            return
+        lab = np.ascontiguousarray(labels, dtype=np.int32)
+        _native.check(self._lib.vodhip_node_index_set_row_labels(self._h, lab.ctypes.data, lab.size))
+
+    def _set_subset(self, subset: np.ndarray | None, nq: int):
+        if subset is None:
+            _native.check(self._lib.vodhip_node_index_set_query_labels(self._h, None, 0, 0))
+            return None
+        sub = np.ascontiguousarray(subset, dtype=np.int32)
+        if sub.ndim != 2 or sub.shape[0] != nq:
+            raise ValueError(f"subset must be int32 [nq, n_per_query], got {tuple(sub.shape)}")
+        _native.check(self._lib.vodhip_node_index_set_query_labels(self._h, sub.ctypes.data, int(sub.shape[1]), 0))
+        return sub  # kept alive by the caller's frame until the search has returned
+
+    def search(self, queries: np.ndarray | torch.Tensor, k: int, subset: np.ndarray | None = None):
+        """NumPy in -> NumPy out (host buffers, synchronous); a tensor on `devices[0]` in -> tensors there, complete on the current stream.
+        `subset`: int32 [nq, n_per_query] allowed row labels per query (-1 = empty slot; host array)."""
+        _keep = self._set_subset(subset, int(queries.shape[0]))  # noqa: F841
         if isinstance(queries, torch.Tensor):
             if queries.device != self.device:
                 raise ValueError(f"queries live on {queries.device}, the merge device is {self.device}")

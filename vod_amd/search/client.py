@@ -222,7 +222,7 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         device: int = 0,
         devices: None | list[int] = None,
         serve_on_gpu: bool = True,  # noqa: ARG002 - accepted for call-site compatibility: this engine only exists on the GPU
-        group_backend: str = "nccl",  # with `devices`: "nccl" (RCCL, one GPU per worker) or "gloo" (host-staged; workers may share a GPU)
+        group_backend: str = "nccl",  # with `devices`: "nccl" (RCCL, one GPU per worker), "gloo" (host-staged; workers may share a GPU) or "node" (ONE server process drives every GPU: vodhip_node_index, no workers)
         micro_batch_wait_ms: float = 0.0,  # > 0: the server fuses requests that arrive within this window into one corpus scan
         http: str = "asyncio",  # the server's HTTP shell: "asyncio" (in-tree, default) or "uvicorn" (FastAPI)
     ):

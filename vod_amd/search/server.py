@@ -353,6 +353,60 @@ class HipEngine:
         return scores.cpu().numpy(), ids.cpu().numpy()
 
 
+class NodeHipEngine:
+    """`--devices a,b,... --group-backend node`: ONE server process drives every GPU through the library's node index
+    (`vodhip_node_index_*`: per-device row shards, peer copies of the per-shard top-k, merge on the first device) - no worker
+    processes and no process group.  This is the shape of the reference's own server, whose single process holds
+    `faiss.index_cpu_to_all_gpus(index, co)` with `co.shard = True` (/root/reference/src/vod_search/faiss_search/server.py:51-54).
+    Same `.ntotal` / `.search` as `HipEngine`."""
+
+    def __init__(self, vectors_path: str, devices: list[int], dtype: str = "float16", subset_ids_path: str | None = None):
+        import torch
+
+        from vod_amd import store
+        from vod_amd.index import HipNodeIndex
+
+        self.vocab: dict[str, int] = {}
+        if str(vectors_path).startswith("synthetic:"):
+            shape, _, seed = str(vectors_path)[len("synthetic:"):].partition(":")
+            n, d = (int(v) for v in shape.lower().split("x"))
+            self.index = HipNodeIndex(d, max(n, 1), devices, dtype=getattr(torch, dtype))
+            for rows in synthetic_rows(torch, torch.device("cuda", devices[0]), 0, n, d, int(seed or 0)):
+                self.index.add(rows.to(torch.float16).cpu().numpy())
+            self.n_store = n
+            return
+        vectors = store.open_vectors(vectors_path)
+        n, d = vectors.shape
+        self.n_store = n
+        self.index = HipNodeIndex(d, max(n, 1), devices, dtype=getattr(torch, dtype))
+        if hasattr(vectors, "iter_row_blocks"):
+            for _lo, rows in vectors.iter_row_blocks():
+                self.index.add(rows)
+        elif isinstance(vectors, np.ndarray) and vectors.dtype in (np.float32, np.float16) and vectors.flags.c_contiguous:
+            self.index.add(vectors)  # one call: every shard ingests its row range concurrently
+        else:
+            for b0 in range(0, n, 262144):
+                self.index.add(np.ascontiguousarray(vectors[b0 : min(n, b0 + 262144)]))
+        if subset_ids_path:
+            ids = np.load(subset_ids_path, allow_pickle=False)
+            if len(ids) != n:
+                raise ValueError(f"{subset_ids_path}: {len(ids)} subset ids for {n} vectors")
+            uniq, codes = np.unique(ids.astype(str), return_inverse=True)
+            self.vocab = {str(u): i for i, u in enumerate(uniq)}
+            self.index.set_row_labels(codes.astype(np.int32))
+
+    @property
+    def ntotal(self) -> int:
+        return self.index.ntotal
+
+    encode_subset = HipEngine.encode_subset
+
+    def search(self, query_vec: np.ndarray, top_k: int, subset_ids: list[list[str]] | None = None) -> tuple[np.ndarray, np.ndarray]:
+        if query_vec.shape[1] != self.index.dim:
+            raise ValueError(f"query dimension {query_vec.shape[1]} != index dimension {self.index.dim}")
+        return self.index.search(query_vec, top_k, subset=self.encode_subset(subset_ids))
+
+
 class GroupHipEngine:
     """Rank 0's engine of a multi-GPU group (`--devices`): same `.ntotal` / `.search` as `HipEngine`, but every search is
     broadcast to the N ranks, each searching its row shard on its own GPU, and merged (vod_amd.search.group)."""
@@ -389,9 +443,10 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument("--micro-batch-wait-ms", type=float, default=0.0,
                    help="> 0: fuse requests that arrive within this window into one GPU batch (default: serialise, as the reference)")
     # set by the owner process for its workers
-    p.add_argument("--group-backend", type=str, default="nccl", choices=["nccl", "gloo"],
+    p.add_argument("--group-backend", type=str, default="nccl", choices=["nccl", "gloo", "node"],
                    help="with --devices: the workers' process group.  nccl = RCCL over xGMI (one GPU per worker); gloo = requests "
-                        "and the per-shard top-k travel through host memory, so several workers may share a GPU (bring-up, tests)")
+                        "and the per-shard top-k travel through host memory, so several workers may share a GPU (bring-up, tests); "
+                        "node = no workers: this one process drives every GPU through the library's node index (the reference server's shape)")
     p.add_argument("--rank", type=int, default=None, help=argparse.SUPPRESS)
     p.add_argument("--master-port", type=int, default=0, help=argparse.SUPPRESS)
     return p.parse_args(argv)
@@ -523,6 +578,10 @@ def main(argv=None) -> None:
 
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    if args.devices is not None and args.group_backend == "node":
+        devices = [int(x) for x in args.devices.split(",") if x.strip() != ""]
+        engine = NodeHipEngine(args.vectors_path, devices, dtype=args.dtype, subset_ids_path=args.subset_ids_path)
+        return _serve(engine, args, re.sub(r"^(http|https)://", "", args.host))
     if args.devices is not None and args.rank is None:
         raise SystemExit(run_owner(args, argv))
     if args.devices is not None:
