@@ -641,3 +641,35 @@ def test_asyncio_server_fuses_concurrent_clients():
         assert Counting.calls < 32
     finally:
         stop()
+
+
+def test_usable_cpus_honours_affinity_and_quota(monkeypatch):
+    """`vod_amd.hostcpu`: the thread-pool cap of the server processes = scheduler affinity capped by the cgroup quota."""
+    import builtins
+    import io
+    import os
+
+    from vod_amd import hostcpu
+
+    monkeypatch.setattr(os, "sched_getaffinity", lambda _pid: set(range(256)), raising=False)
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if str(path) == "/sys/fs/cgroup/cpu.max":
+            return io.StringIO("1600000 100000\n")
+        return real_open(path, *a, **k)
+
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert hostcpu.usable_cpus() == 16
+    monkeypatch.setattr(builtins, "open", lambda path, *a, **k: io.StringIO("max 100000\n") if str(path) == "/sys/fs/cgroup/cpu.max" else real_open(path, *a, **k))
+    assert hostcpu.usable_cpus() == 256
+    monkeypatch.setattr(os, "sched_getaffinity", lambda _pid: {0, 1, 2}, raising=False)
+    assert hostcpu.usable_cpus() == 3
+    monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+    import torch
+
+    before = torch.get_num_threads()
+    try:
+        assert hostcpu.limit_cpu_threads(2) == 2 and os.environ["OMP_NUM_THREADS"] == "2" and torch.get_num_threads() <= 2
+    finally:
+        torch.set_num_threads(before)

@@ -3,7 +3,7 @@
 the client sends host float32 queries over HTTP - base64-in-JSON `/fast-search` (the reference's wire format,
 src/vod_search/faiss_search/server.py:76-91) and the raw-bytes `/raw-search` - and gets host arrays back.
 Prints median milliseconds per request and the resulting queries/s, next to the in-process device-resident time.
-usage: python tools/bench_http.py [rows] [dim] [group]   (`group`: serve through the multi-GPU worker group, devices=[0])"""
+usage: python tools/bench_http.py [rows] [dim] [single|group|gloo2|node2]"""
 import json
 import os
 import statistics
@@ -22,9 +22,13 @@ rng = np.random.default_rng(0)
 tmp = tempfile.mkdtemp()
 os.chdir(tmp)
 x = rng.standard_normal((rows, dim), dtype=np.float32).astype(np.float16)
-group = len(sys.argv) > 3 and sys.argv[3] == "group"
-master = factory.build_hip_mips_index(x, config={"port": -1, "logging_level": "warning"}, cache_dir=tmp, devices=[0] if group else None)
-out = {"rows": rows, "dim": dim, "server": "worker group, devices=[0]" if group else "single process", "requests": []}
+mode = sys.argv[3] if len(sys.argv) > 3 else "single"
+# group = worker group on RCCL, devices=[0]; gloo2 / node2 = TWO shards on the box's one GPU behind a gloo worker group / behind the
+# one-process node index (what the request broadcast + gather of a process group costs next to peer copies inside one process)
+devices, backend = {"single": (None, "nccl"), "group": ([0], "nccl"), "gloo2": ([0, 0], "gloo"), "node2": ([0, 0], "node")}[mode]
+master = factory.build_hip_mips_index(x, config={"port": -1, "logging_level": "warning", "group_backend": backend}, cache_dir=tmp, devices=devices)
+out = {"rows": rows, "dim": dim, "server": {"single": "single process", "group": "worker group, devices=[0]", "gloo2": "worker group on gloo, devices=[0, 0]",
+                                             "node2": "one process, node index, devices=[0, 0]"}[mode], "requests": []}
 with master:
     json_client = master.get_client()
     raw_client = type(json_client)(host=json_client.host, port=json_client.port, binary=True)

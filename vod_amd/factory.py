@@ -32,6 +32,8 @@ class HipMipsFactoryConfig:
     logging_level: str = "CRITICAL"
     device: int = 0
     devices: tuple[int, ...] | None = None  # row-shard the store over these GPUs behind one address
+    group_backend: str = "nccl"     # with `devices`: "nccl" / "gloo" = one worker process per GPU on a process group; "node" = ONE
+                                    # server process drives every GPU (vodhip_node_index: the reference server's own shape)
 
     def fingerprint(self) -> dict:
         return {"factory": self.factory, "metric": self.metric, "dtype": self.dtype}
@@ -106,4 +108,5 @@ def build_hip_mips_index(
         dtype=config.dtype,
         device=config.device,
         devices=None if devices is None else list(devices),
+        group_backend=config.group_backend,
     )

@@ -578,6 +578,13 @@ def main(argv=None) -> None:
 
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    if args.devices is None or args.rank is not None or args.group_backend == "node":
+        # every process that serves: thread pools sized for the CPUs the cgroup grants, not for the cores the host shows (see
+        # vod_amd/hostcpu.py: 200 ms stalls per request otherwise).  (The owner of a worker group only exports the defaults.)
+        from vod_amd.hostcpu import limit_cpu_threads, usable_cpus
+
+        n_workers = len([x for x in args.devices.split(",") if x.strip() != ""]) if (args.devices and args.rank is not None) else 1
+        limit_cpu_threads(max(1, usable_cpus() // max(1, n_workers)))  # the workers of a group share the grant
     if args.devices is not None and args.group_backend == "node":
         devices = [int(x) for x in args.devices.split(",") if x.strip() != ""]
         engine = NodeHipEngine(args.vectors_path, devices, dtype=args.dtype, subset_ids_path=args.subset_ids_path)
