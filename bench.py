@@ -471,6 +471,9 @@ def main() -> None:
         return launch_check(rank, world)
     import torch
 
+    from vod_amd.hostcpu import limit_cpu_threads, usable_cpus
+
+    limit_cpu_threads(max(1, usable_cpus() // world), export=False)  # torch's CPU pool: the cgroup's grant, shared by the ranks (vod_amd/hostcpu.py)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     if args.backend == "gloo":  # test rig: the ranks may share a GPU
