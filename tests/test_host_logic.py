@@ -673,3 +673,63 @@ def test_usable_cpus_honours_affinity_and_quota(monkeypatch):
         assert hostcpu.limit_cpu_threads(2) == 2 and os.environ["OMP_NUM_THREADS"] == "2" and torch.get_num_threads() <= 2
     finally:
         torch.set_num_threads(before)
+
+
+def test_micro_batcher_lanes_gather_the_next_batch_while_the_engine_is_busy():
+    """Two collector lanes: requests that arrive while a batch is on the (slow) engine end up in ONE following batch, the engine is
+    never entered twice at a time, and a request of another dimension fails alone."""
+    import threading
+    import time
+
+    from oracle.flat_ip import flat_ip_topk
+    from vod_amd.search.server import MicroBatcher
+
+    rng = np.random.default_rng(3)
+    x = rng.integers(-4, 5, size=(300, 8)).astype(np.float32)
+
+    class Slow(_OracleEngine):
+        def __init__(self, rows):
+            super().__init__(rows)
+            self.sizes, self.inside, self.overlap = [], 0, False
+
+        def search(self, q, k):
+            self.inside += 1
+            self.overlap |= self.inside > 1
+            self.sizes.append(len(q))
+            time.sleep(0.15)
+            try:
+                if q.shape[1] != 8:
+                    raise ValueError("query dimension")
+                return super().search(q, k)
+            finally:
+                self.inside -= 1
+
+    eng = Slow(x)
+    mb = MicroBatcher(eng, max_wait_s=0.005)
+    qs = [rng.integers(-4, 5, size=(2, 8)).astype(np.float32) for _ in range(9)]
+    out, errs = [None] * 9, []
+
+    def work(i):
+        out[i] = mb.search(qs[i], 5)
+
+    def bad():
+        try:
+            mb.search(np.zeros((1, 5), dtype=np.float32), 3)
+        except ValueError as e:
+            errs.append(e)
+
+    first = threading.Thread(target=work, args=(0,))
+    first.start()
+    time.sleep(0.05)  # request 0 is on the engine now; the other eight (and the malformed one) arrive during its 150 ms
+    rest = [threading.Thread(target=work, args=(i,)) for i in range(1, 9)] + [threading.Thread(target=bad)]
+    for t in rest:
+        t.start()
+    for t in [first] + rest:
+        t.join(timeout=30)
+    assert not eng.overlap
+    assert eng.sizes[0] == 2 and 16 in eng.sizes, eng.sizes       # the eight waiting requests went out as one batch of 16 queries
+    assert len(errs) == 1
+    for i in range(9):
+        rs, ri = flat_ip_topk(qs[i], x, 5)
+        np.testing.assert_array_equal(out[i][1], ri)
+        np.testing.assert_array_equal(out[i][0], rs)
