@@ -355,3 +355,49 @@ def test_multi_gpu_group_server_eight_workers_sharing_the_gpu(tmp_path):
         raw = HipMipsClient(host=m.host, port=m.port, binary=True, wire_dtype="float16").search(vector=q[:7], top_k=13)
         np.testing.assert_array_equal(raw.indices, ri[:7, :13])
     assert not m.get_client().ping()
+
+
+def test_engine_orders_concurrent_callers_itself(tmp_path):
+    """`HipEngine.search` from many threads at once: every caller takes a ticket at enqueue time (up to three searches are in flight on
+    the one stream; their result rows are written straight into pinned host buffers) and completes in FIFO order - each must get
+    ITS answer, subset requests and a malformed one included."""
+    import concurrent.futures
+
+    from oracle.flat_ip import flat_ip_topk, topk_desc_tiebreak
+    from vod_amd import store
+    from vod_amd.search.server import HipEngine
+
+    rng = np.random.default_rng(31)
+    n, d = 40_000, 64
+    x = rng.integers(-8, 9, size=(n, d)).astype(np.float32)
+    names = np.array([f"doc{v}" for v in rng.integers(0, 4, size=n)])
+    store.save_vectors(tmp_path / "v.npy", x, dtype=np.float16)
+    np.save(tmp_path / "subsets.npy", names)
+    engine = HipEngine(str(tmp_path / "v.npy"), subset_ids_path=str(tmp_path / "subsets.npy"))
+    jobs = []
+    for j in range(60):
+        q = rng.integers(-8, 9, size=(int(rng.integers(1, 200)), d)).astype(np.float32)
+        k = int(rng.choice([1, 7, 64, 100, 300]))
+        sub = [["doc2"] for _ in range(len(q))] if j % 5 == 0 else None
+        jobs.append((q, k, sub))
+
+    def call(job):
+        q, k, sub = job
+        return engine.search(q, k, subset_ids=sub)
+
+    with concurrent.futures.ThreadPoolExecutor(12) as pool:
+        futs = [pool.submit(call, job) for job in jobs]
+        bad = pool.submit(engine.search, np.zeros((3, d), np.float32), 5000)  # refused at enqueue: holds no ticket, blocks nobody
+        results = [f.result(timeout=120) for f in futs]
+        with pytest.raises(Exception, match="out of range"):
+            bad.result(timeout=120)
+    assert engine.in_flight() == 0
+    for (q, k, sub), (s, i) in zip(jobs, results):
+        if sub is None:
+            rs, ri = flat_ip_topk(q, x, k)
+        else:
+            full = q.astype(np.float64) @ x.astype(np.float64).T
+            full[:, names != "doc2"] = np.nan
+            rs, ri = topk_desc_tiebreak(full, k)
+        np.testing.assert_array_equal(i, ri)
+        np.testing.assert_array_equal(s, rs)

@@ -53,6 +53,22 @@ class FastSearchResponse(pydantic.BaseModel):
     indices: str
 
 
+class _NoLock:
+    """Stands in for the engine lock when the engine serialises its callers itself."""
+
+    def acquire(self, blocking: bool = True) -> bool:  # noqa: ARG002
+        return True
+
+    def release(self) -> None:
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc) -> None:
+        pass
+
+
 class MicroBatcher:
     """Fuse concurrent requests into one GPU batch.
 
@@ -109,7 +125,10 @@ class MicroBatcher:
                 while n < self.max_queries:
                     remaining = deadline - time.monotonic()
                     if remaining <= 0:
-                        if self.lock.acquire(blocking=False):
+                        # a pipelined engine is "free" while fewer than two batches are on it: the next one is enqueued BEHIND the
+                        # running one (no gap on the GPU) and this lane keeps collecting only when two are already queued
+                        busy = getattr(self.engine, "pipelined", False) and self.engine.in_flight() >= 2
+                        if not busy and self.lock.acquire(blocking=False):
                             held = True
                             break
                         remaining = 0.0005
@@ -164,7 +183,9 @@ class Endpoints:
 
     def __init__(self, engine, micro_batch_wait_ms: float = 0.0):
         self.engine = engine
-        self.lock = threading.Lock()
+        # an engine that orders its own callers (`HipEngine`: tickets over the library's FIFO of in-flight searches) needs no lock here:
+        # concurrent requests are enqueued back to back on the GPU instead of waiting for each other's host-side work
+        self.lock = _NoLock() if getattr(engine, "pipelined", False) else threading.Lock()
         self.batcher = MicroBatcher(engine, max_wait_s=micro_batch_wait_ms / 1e3, lock=self.lock) if micro_batch_wait_ms > 0 else None
 
     # -- the search itself --------------------------------------------------------------------------------------------
@@ -377,11 +398,67 @@ class HipEngine:
             subset[r, : len(names)] = [self.vocab.get(str(nm), -2) for nm in names]
         return subset
 
-    def search(self, query_vec: np.ndarray, top_k: int, subset_ids: list[list[str]] | None = None) -> tuple[np.ndarray, np.ndarray]:
+    # -- searching: thread-safe and pipelined ---------------------------------------------------------------------------
+    # Up to MAX_IN_FLIGHT searches are enqueued back to back on the one stream (`vodhip_index_search_async`); the library completes
+    # them in FIFO order, so every caller takes a ticket at enqueue time and completes when its ticket is up.  The final select kernel
+    # of a search writes its result rows STRAIGHT INTO PINNED HOST MEMORY (a slot of a small ring of pinned buffers): completing a
+    # search is an event wait, no device-to-host copy that would queue behind the younger searches' kernels.
+    pipelined = True
+    MAX_IN_FLIGHT = 3
+
+    def _pipeline(self):
+        st = getattr(self, "_pipe", None)
+        if st is None:
+            st = self._pipe = {"submit": threading.Lock(), "turn": threading.Condition(), "next_ticket": 0, "next_done": 0, "slots": {}}
+        return st
+
+    def in_flight(self) -> int:
+        st = self._pipeline()
+        return st["next_ticket"] - st["next_done"]
+
+    def _pinned_out(self, ticket: int, nq: int, k: int):
+        torch = self._torch
+        st = self._pipeline()
+        slot = ticket % (self.MAX_IN_FLIGHT + 1)
+        have = st["slots"].get(slot)
+        if have is None or have[0].numel() < nq * k:
+            n = max(nq * k, 4096)
+            have = (torch.empty((n,), dtype=torch.float32, pin_memory=True), torch.empty((n,), dtype=torch.int64, pin_memory=True))
+            st["slots"][slot] = have
+        return have[0][: nq * k].view(nq, k), have[1][: nq * k].view(nq, k)
+
+    def search_enqueue(self, query_vec: np.ndarray, top_k: int, subset_ids: list[list[str]] | None = None):
         if query_vec.shape[1] != self.index.dim:
             raise ValueError(f"query dimension {query_vec.shape[1]} != index dimension {self.index.dim}")
-        scores, ids = self.index.search(query_vec, top_k, id_base=self.row_lo, subset=self.encode_subset(subset_ids))
-        return scores.cpu().numpy(), ids.cpu().numpy()
+        subset = self.encode_subset(subset_ids)
+        st = self._pipeline()
+        with st["submit"]:
+            with st["turn"]:
+                st["turn"].wait_for(lambda: st["next_ticket"] - st["next_done"] < self.MAX_IN_FLIGHT)
+            ticket = st["next_ticket"]
+            out = self._pinned_out(ticket, int(query_vec.shape[0]), int(top_k))
+            with self._torch.cuda.device(self.index.device):
+                self.index.search_async(query_vec, top_k, id_base=self.row_lo, out=out, subset=subset)
+            st["next_ticket"] = ticket + 1  # only a search the library accepted holds a ticket
+        return ticket, out
+
+    def search_complete(self, handle) -> tuple[np.ndarray, np.ndarray]:
+        ticket, (scores, ids) = handle
+        st = self._pipeline()
+        with st["turn"]:
+            st["turn"].wait_for(lambda: st["next_done"] == ticket)
+        try:
+            with self._torch.cuda.device(self.index.device):
+                self.index.finish()
+            # copies: the pinned slot is written again MAX_IN_FLIGHT + 1 searches from now
+            return scores.numpy().copy(), ids.numpy().copy()
+        finally:
+            with st["turn"]:
+                st["next_done"] = ticket + 1
+                st["turn"].notify_all()
+
+    def search(self, query_vec: np.ndarray, top_k: int, subset_ids: list[list[str]] | None = None) -> tuple[np.ndarray, np.ndarray]:
+        return self.search_complete(self.search_enqueue(query_vec, top_k, subset_ids))
 
 
 class NodeHipEngine:
