@@ -12,7 +12,7 @@ ranks (strong scaling: the corpus is fixed, each rank holds N_total / N rows).  
 per-shard top-k, merge.  Inputs are synthetic N(0,1) embeddings generated on the device (corpus seed 1234,
 query seed 4321); queries are resident in HBM when the timed region starts.  `--data clustered` sorts the
 rows by topic cluster and draws the queries from the LAST clusters (documents ingested in topic order:
-the row order a real corpus has, /root/reference/src/vod_search/faiss_search/build.py:65-73); `--data duplicates`
+the row order a real corpus has, /root/reference/src/vod_search/faiss_search/build.py:65-73); `--data normalized` scales rows and queries to norm 10 (the encoder's scaled-cosine pooler); `--data duplicates`
 repeats ONE section over the last tenth of the store and aims every query at it (candidate-list overflow and
 per-query recovery on the rank that holds those rows, and only there).
 
@@ -46,7 +46,7 @@ def parse_args() -> argparse.Namespace:
     p.add_argument("--nq", type=int, default=1024)
     p.add_argument("--k", type=int, default=100)
     p.add_argument("--dtype", choices=["f16", "bf16"], default="f16")
-    p.add_argument("--data", choices=["iid", "clustered", "duplicates"], default="iid")
+    p.add_argument("--data", choices=["iid", "clustered", "duplicates", "normalized"], default="iid")
     p.add_argument("--tile", type=int, default=0)
     p.add_argument("--growth", type=int, default=0, help="stage growth factor x100 (0 = library default)")
     p.add_argument("--force-collective", action="store_true",
@@ -149,6 +149,8 @@ def make_rows(torch, dev, tdt, data: str, chunk: int, rows: int, d: int, n_total
     if data == "duplicates":  # the last tenth of the store is ONE section repeated: every query ties > cand_cap rows at its top score
         ridx = torch.arange(chunk * GEN_CHUNK, chunk * GEN_CHUNK + rows, device=dev, dtype=torch.int64)
         x = torch.where((ridx >= n_total - n_total // 10)[:, None], cluster_centers(torch, dev, 1, d)[0][None, :], x)
+    if data == "normalized":  # L2-normalised rows x 10 (the encoder's `mpool-scaled-cosine` pooler, scaler 100 = sqrt(100) per side)
+        x = 10.0 * torch.nn.functional.normalize(x, dim=1)
     return x.to(tdt)
 
 
@@ -167,6 +169,8 @@ def make_queries(torch, dev, tdt, data: str, nq: int, d: int, n_total: int):
         q = 0.6 * q + 0.8 * centers[late]
     if data == "duplicates":  # every query scores the repeated section far above any other row
         q = 0.6 * q + 0.8 * cluster_centers(torch, dev, 1, d)[0][None, :]
+    if data == "normalized":
+        q = 10.0 * torch.nn.functional.normalize(q, dim=1)
     return q.to(tdt)
 
 
@@ -516,7 +520,8 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": {"iid": "synthetic", "clustered": "synthetic, rows sorted by topic cluster, queries from the last clusters",
-                     "duplicates": "synthetic, one section repeated over the last tenth of the store, every query aimed at it"}[args.data],
+                     "duplicates": "synthetic, one section repeated over the last tenth of the store, every query aimed at it",
+                     "normalized": "synthetic, rows and queries L2-normalised x 10 (scaled-cosine embeddings)"}[args.data],
             "config": {
                 "workload": f"{n_total} sections x {d} {args.dtype}, batch {nq} queries, top-{k}, exact brute force",
                 "rows_per_gpu": m["n_local"],

@@ -605,7 +605,7 @@ def test_pipelined_subset_search_recovers_with_its_own_labels():
     np.testing.assert_array_equal(b[1].cpu().numpy(), ui)
 
 
-def _full_size_properties(n, d, nq, k, dtype, chunk=500_000, n_check=64):
+def _full_size_properties(n, d, nq, k, dtype, chunk=500_000, n_check=64, normalized=False):
     """Size-independent properties at a BASELINE config's full size: sorted, unique valid ids, scores reproduce from the
     stored rows, shard-merge == whole, and exactness of a query sample against a chunked fp32 matmul of the stored rows."""
     from vod_amd.index import merge_topk
@@ -615,9 +615,11 @@ def _full_size_properties(n, d, nq, k, dtype, chunk=500_000, n_check=64):
     with _index(np.zeros((0, d), np.float16), dtype=tdt, capacity=n) as whole:
         for c, lo in enumerate(range(0, n, chunk)):
             g = torch.Generator(device=dev).manual_seed(1234 + c)
-            whole.add(torch.randn((min(chunk, n - lo), d), generator=g, device=dev, dtype=torch.float32).to(tdt))
+            rows = torch.randn((min(chunk, n - lo), d), generator=g, device=dev, dtype=torch.float32)
+            whole.add((10.0 * torch.nn.functional.normalize(rows, dim=1) if normalized else rows).to(tdt))
         gq = torch.Generator(device=dev).manual_seed(4321)
-        q = torch.randn((nq, d), generator=gq, device=dev, dtype=torch.float32).to(tdt)
+        q = torch.randn((nq, d), generator=gq, device=dev, dtype=torch.float32)
+        q = (10.0 * torch.nn.functional.normalize(q, dim=1) if normalized else q).to(tdt)
         ws, wi = whole.search(q, k)
         assert whole.get_stat("last_overflow") == 0
         assert torch.all(ws[:, 1:] <= ws[:, :-1])
@@ -676,6 +678,12 @@ def test_full_size_c2_properties():
     """BASELINE configs[1]: 1 M x 768 fp16, batch 256, top-100 on one GPU (the single-q-tile / `nt` cache-policy path of the
     persistent kernel, different code from C3's four q-tiles)."""
     _full_size_properties(1_000_000, 768, 256, 100, "float16", n_check=256)
+
+
+def test_full_size_c2_scaled_cosine_embeddings():
+    """SURVEY 8(d)'s second C2 input: rows and queries L2-normalised x 10 (the encoder's `mpool-scaled-cosine` pooler, scaler 100 =
+    sqrt(100) per side): a score distribution 8x narrower than N(0, 1) rows give, i.e. many more near-ties around the k-th score."""
+    _full_size_properties(1_000_000, 768, 256, 100, "float16", n_check=256, normalized=True)
 
 
 @pytest.fixture(scope="module")
