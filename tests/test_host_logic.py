@@ -499,7 +499,7 @@ def test_master_command_line_for_a_multi_gpu_group(tmp_path):
 
 
 # ---- the asyncio HTTP shell (production) speaks the same contract over real sockets ------------------------------------------
-def _serve_in_thread(engine, micro_batch_wait_ms=0.0):
+def _serve_in_thread(engine, micro_batch_wait_ms=0.0, uds=None):
     import asyncio
     import threading
 
@@ -515,7 +515,7 @@ def _serve_in_thread(engine, micro_batch_wait_ms=0.0):
             state["loop"], state["stop"] = asyncio.get_running_loop(), asyncio.Event()
             ready = asyncio.Event()
             task = asyncio.create_task(fastserver.serve(Endpoints(engine, micro_batch_wait_ms), "127.0.0.1", port, workers=16, ready=ready,
-                                                        stop=state["stop"]))
+                                                        stop=state["stop"], uds=uds))
             await ready.wait()
             state["ready"] = True
             await task
@@ -603,6 +603,38 @@ def test_asyncio_server_routes_wire_format_and_errors():
         s.close()
     finally:
         stop()
+
+
+def test_asyncio_server_on_a_unix_domain_socket(tmp_path):
+    """the same routes on a Unix-domain socket (`--uds`); the client's searches go through it, `ping` keeps using TCP,
+    a pickled client (DataLoader worker) re-opens its own connection, and the socket file is removed on shutdown."""
+    import os
+
+    from oracle.flat_ip import flat_ip_topk
+
+    rng = np.random.default_rng(6)
+    x = rng.integers(-4, 5, size=(200, 8)).astype(np.float32)
+    q = rng.integers(-4, 5, size=(5, 8)).astype(np.float32)
+    path = str(tmp_path / "vodhip.sock")
+    port, stop = _serve_in_thread(_OracleEngine(x), uds=path)
+    try:
+        assert os.path.exists(path)
+        rs, ri = flat_ip_topk(q, x, 9)
+        for binary in (False, True):
+            c = vclient.HipMipsClient("http://127.0.0.1", port, binary=binary, uds=path)
+            assert c.ping()
+            for _ in range(3):
+                res = c.search(vector=q, top_k=9)
+            np.testing.assert_array_equal(res.indices, ri)
+            np.testing.assert_array_equal(res.scores, rs)
+            assert type(c._local.conn).__name__ == "_UnixHTTPConnection"
+            clone = pickle.loads(pickle.dumps(c))
+            np.testing.assert_array_equal(clone.search(vector=q, top_k=9).indices, ri)
+        with pytest.raises(Exception):
+            vclient.HipMipsClient("http://127.0.0.1", port, uds=str(tmp_path / "nobody-listens.sock")).search(vector=q, top_k=3)
+    finally:
+        stop()
+    assert not os.path.exists(path)
 
 
 def test_asyncio_server_fuses_concurrent_clients():

@@ -32,6 +32,7 @@ class HipMipsFactoryConfig:
     logging_level: str = "CRITICAL"
     device: int = 0
     devices: tuple[int, ...] | None = None  # row-shard the store over these GPUs behind one address
+    uds: bool = False               # also serve on a Unix-domain socket and hand its path to the clients (single-host jobs)
     group_backend: str = "nccl"     # with `devices`: "nccl" / "gloo" = one worker process per GPU on a process group; "node" = ONE
                                     # server process drives every GPU (vodhip_node_index: the reference server's own shape)
 
@@ -109,4 +110,5 @@ def build_hip_mips_index(
         device=config.device,
         devices=None if devices is None else list(devices),
         group_backend=config.group_backend,
+        uds=config.uds,
     )

@@ -8,6 +8,7 @@ which owns the GPU-resident index; clients stay plain HTTP so they can be pickle
 """
 from __future__ import annotations
 
+import http.client
 import os
 import pathlib
 import sys
@@ -24,15 +25,34 @@ from vod_amd.search import base
 from vod_amd.search.socket import find_available_port
 
 
+class _UnixHTTPConnection(http.client.HTTPConnection):
+    """HTTP/1.1 over a Unix-domain socket (the server's `--uds` listener)."""
+
+    def __init__(self, path: str, timeout: float = 120):
+        super().__init__("localhost", timeout=timeout)
+        self._uds_path = path
+
+    def connect(self) -> None:
+        import socket
+
+        sock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        sock.settimeout(self.timeout)
+        sock.connect(self._uds_path)
+        self.sock = sock
+
+
 class HipMipsClient(base.SearchClient):
     """HTTP client of the HIP MIPS server."""
 
     requires_vectors = True
 
     def __init__(self, host: str = "http://localhost", port: int = 7678, binary: bool = False, forward_subset_ids: bool = False,
-                 wire_dtype: str | None = None):
+                 wire_dtype: str | None = None, uds: str | None = None):
         self.host = host
         self.port = port
+        # a Unix-domain socket path the server also listens on (`--uds`): the searches go through it (same HTTP, no TCP stack);
+        # `ping()` keeps using host:port, so a client on another host simply leaves it unset
+        self.uds = uds
         self.binary = binary  # use the raw-bytes route (`/raw-search`) instead of base64-in-JSON (`/fast-search`)
         # The reference's faiss client drops `subset_ids`; set this to let the GPU index honour them (the server must
         # have been started with `--subset-ids-path`).
@@ -53,6 +73,7 @@ class HipMipsClient(base.SearchClient):
     def __setstate__(self, state: dict) -> None:
         self.__dict__.update(state)
         self.__dict__.setdefault("wire_dtype", None)
+        self.__dict__.setdefault("uds", None)
         self._local = threading.local()
 
     @property
@@ -91,9 +112,12 @@ class HipMipsClient(base.SearchClient):
 
         loc = self._local
         if getattr(loc, "conn", None) is None or loc.conn_pid != os.getpid():  # a forked / unpickled worker opens its own socket
-            u = urllib.parse.urlsplit(self.host if "://" in self.host else "http://" + self.host)
-            cls = http.client.HTTPSConnection if u.scheme == "https" else http.client.HTTPConnection
-            loc.conn = cls(u.hostname, self.port, timeout=timeout)
+            if self.uds:
+                loc.conn = _UnixHTTPConnection(self.uds, timeout=timeout)
+            else:
+                u = urllib.parse.urlsplit(self.host if "://" in self.host else "http://" + self.host)
+                cls = http.client.HTTPSConnection if u.scheme == "https" else http.client.HTTPConnection
+                loc.conn = cls(u.hostname, self.port, timeout=timeout)
             loc.conn_pid = os.getpid()
         elif loc.conn.sock is not None:
             loc.conn.sock.settimeout(timeout)
@@ -225,6 +249,7 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         group_backend: str = "nccl",  # with `devices`: "nccl" (RCCL, one GPU per worker), "gloo" (host-staged; workers may share a GPU) or "node" (ONE server process drives every GPU: vodhip_node_index, no workers)
         micro_batch_wait_ms: float = 0.0,  # > 0: the server fuses requests that arrive within this window into one corpus scan
         http: str = "asyncio",  # the server's HTTP shell: "asyncio" (in-tree, default) or "uvicorn" (FastAPI)
+        uds: bool | str = False,  # also listen on a Unix-domain socket (True = a path under the temp dir); `get_client()` then uses it
     ):
         super().__init__(skip_setup=skip_setup, free_resources=free_resources)
         self.vectors_path = vectors_path if str(vectors_path).startswith("synthetic:") else pathlib.Path(vectors_path)
@@ -240,6 +265,11 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         self.group_backend = group_backend
         self.micro_batch_wait_ms = float(micro_batch_wait_ms)
         self.http = http
+        if uds is True:
+            import tempfile
+
+            uds = os.path.join(tempfile.gettempdir(), f"vodhip-{os.getpid()}-{self.port}.sock")
+        self.uds = uds or None
 
     def _make_env(self) -> dict[str, str]:
         env = copy(dict(os.environ))
@@ -257,12 +287,13 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
             "--dtype", self.dtype,
             "--http", self.http,
             *(["--micro-batch-wait-ms", str(self.micro_batch_wait_ms)] if self.micro_batch_wait_ms > 0 else []),
+            *(["--uds", str(self.uds)] if self.uds else []),
             *(["--devices", ",".join(map(str, self.devices)), "--group-backend", self.group_backend]
               if self.devices is not None else ["--device", str(self.device)]),
         ]
 
     def get_client(self) -> HipMipsClient:
-        return HipMipsClient(host=self.host, port=self.port)
+        return HipMipsClient(host=self.host, port=self.port, uds=self.uds)
 
     @property
     def url(self) -> str:

@@ -158,12 +158,23 @@ class _Connection(asyncio.BufferedProtocol):
 
 
 async def serve(endpoints, host: str, port: int, workers: int = 64, ready: "asyncio.Event | None" = None, stop: "asyncio.Event | None" = None,
-                max_body: int = MAX_BODY) -> None:
+                max_body: int = MAX_BODY, uds: "str | None" = None) -> None:
     """Serve until `stop` is set (or forever).  `workers`: handler threads = requests that may be in flight at once (each DataLoader
     worker of each trainer rank holds one connection: src/vod_dataloaders/realm_dataloader.py:92-118)."""
     loop = asyncio.get_running_loop()
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix="vodhip-http")
     server = await loop.create_server(lambda: _Connection(endpoints, pool, max_body), host=host, port=port, reuse_address=True, backlog=256)
+    # `uds`: the same routes on a Unix-domain socket as well (SURVEY 8f-4: clients on the server's host - the dataloader workers of a
+    # single-node job - skip the TCP stack: no checksums, no loopback MTU segmentation of multi-megabyte bodies)
+    unix_server = None
+    if uds:
+        import os
+
+        try:
+            os.unlink(uds)
+        except FileNotFoundError:
+            pass
+        unix_server = await loop.create_unix_server(lambda: _Connection(endpoints, pool, max_body), path=uds, backlog=256)
     if ready is not None:
         ready.set()
     try:
@@ -174,10 +185,19 @@ async def serve(endpoints, host: str, port: int, workers: int = 64, ready: "asyn
     finally:
         server.close()
         await server.wait_closed()
+        if unix_server is not None:
+            unix_server.close()
+            await unix_server.wait_closed()
+            try:
+                import os
+
+                os.unlink(uds)
+            except OSError:
+                pass
         pool.shutdown(wait=False, cancel_futures=True)
 
 
-def run(endpoints, host: str, port: int, workers: int = 64, max_body: int = MAX_BODY) -> None:
+def run(endpoints, host: str, port: int, workers: int = 64, max_body: int = MAX_BODY, uds: "str | None" = None) -> None:
     """Blocking entry point (the server process's main thread): SIGTERM / SIGINT stop it cleanly."""
     import signal
 
@@ -189,6 +209,6 @@ def run(endpoints, host: str, port: int, workers: int = 64, max_body: int = MAX_
                 loop.add_signal_handler(sig, stop.set)
             except (NotImplementedError, RuntimeError):  # pragma: no cover - not the main thread
                 pass
-        await serve(endpoints, host, port, workers=workers, stop=stop, max_body=max_body)
+        await serve(endpoints, host, port, workers=workers, stop=stop, max_body=max_body, uds=uds)
 
     asyncio.run(main())

@@ -548,6 +548,7 @@ def parse_args(argv=None) -> argparse.Namespace:
                    help="HTTP shell: the in-tree asyncio server (socket reads land in the request buffer, codec in place) or uvicorn + FastAPI")
     p.add_argument("--http-workers", type=int, default=64, help="handler threads = requests that may be in flight at once")
     p.add_argument("--max-body-mb", type=int, default=512, help="largest request body the asyncio shell accepts (413 above it)")
+    p.add_argument("--uds", type=str, default=None, help="also serve on this Unix-domain socket path (asyncio shell; clients on the same host)")
     p.add_argument("--micro-batch-wait-ms", type=float, default=0.0,
                    help="> 0: fuse requests that arrive within this window into one GPU batch (default: serialise, as the reference)")
     # set by the owner process for its workers
@@ -678,7 +679,7 @@ def _serve(engine, args: argparse.Namespace, host: str) -> None:
         from vod_amd.search import fastserver
 
         fastserver.run(Endpoints(engine, micro_batch_wait_ms=args.micro_batch_wait_ms), host, args.port, workers=args.http_workers,
-                       max_body=args.max_body_mb << 20)
+                       max_body=args.max_body_mb << 20, uds=args.uds)
 
 
 def main(argv=None) -> None:
