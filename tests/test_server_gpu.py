@@ -401,3 +401,30 @@ def test_engine_orders_concurrent_callers_itself(tmp_path):
             rs, ri = topk_desc_tiebreak(full, k)
         np.testing.assert_array_equal(i, ri)
         np.testing.assert_array_equal(s, rs)
+
+
+def test_master_with_a_unix_domain_socket(tmp_path):
+    """`HipMipsMaster(uds=True)`: the spawned server also listens on a Unix-domain socket, `get_client()` searches through it
+    (SURVEY 8f-4's transport item), results equal the oracle; the socket file goes away with the server."""
+    import os
+
+    from oracle.flat_ip import flat_ip_topk
+    from vod_amd import store
+    from vod_amd.search.client import HipMipsMaster
+
+    rng = np.random.default_rng(41)
+    x = rng.integers(-6, 7, size=(20_000, 64)).astype(np.float32)
+    q = rng.integers(-6, 7, size=(70, 64)).astype(np.float32)
+    store.save_vectors(tmp_path / "v.npy", x, dtype=np.float16)
+    with HipMipsMaster(tmp_path / "v.npy", port=-1, logging_level="warning", uds=True) as m:
+        c = m.get_client()
+        assert c.uds and os.path.exists(c.uds) and c.ping()
+        for binary in (False, True):
+            cl = type(c)(host=c.host, port=c.port, uds=c.uds, binary=binary)
+            res = cl.search(vector=q, top_k=50)
+            rs, ri = flat_ip_topk(q, x, 50)
+            np.testing.assert_array_equal(res.indices, ri)
+            np.testing.assert_array_equal(res.scores, rs)
+            assert type(cl._local.conn).__name__ == "_UnixHTTPConnection"
+        path = c.uds
+    assert not os.path.exists(path)
