@@ -16,7 +16,7 @@ import torch
 
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[2]))  # the repo root
 from oracle.flat_ip import topk_desc_tiebreak  # noqa: E402
-from vod_amd.index import HipFlatIndex  # noqa: E402
+from vod_amd.index import HipFlatIndex, HipNodeIndex  # noqa: E402
 
 
 def draw(rng):
@@ -43,6 +43,8 @@ def draw(rng):
     c["id_base"] = int(rng.choice([0, 0, 12345, 1 << 33]))
     c["build"] = str(rng.choice(["once", "once", "chunks", "reset_refill"]))
     c["rng_seed"] = int(rng.integers(0, 2**31))
+    # one trial in six goes through the one-process node index (`vodhip_node_index_*`): 1-5 shards, all on device 0
+    c["node_shards"] = int(rng.choice([0, 0, 0, 0, 0, 1, 2, 3, 5])) if rng.random() < 0.5 else 0
     return c
 
 
@@ -61,7 +63,63 @@ def make_rows(rng, kind, n, d):
     return x[np.argsort(x @ w, kind="stable")]
 
 
+def run_node_trial(c):
+    """The same draw behind `HipNodeIndex` (host buffers in and out, row shards on device 0): id_base 0, host rows only."""
+    rng = np.random.default_rng(c["rng_seed"])
+    n, d, nq, k = c["n"], c["d"], c["nq"], c["k"]
+    tdt = torch.float16 if c["dtype"] == "f16" else torch.bfloat16
+    lim = 4 if c["dtype"] == "bf16" else 8
+    x = np.clip(make_rows(rng, c["data"], n, d), -lim, lim)
+    q = rng.integers(-lim, lim + 1, size=(nq, d)).astype(np.float32)
+    labels = subset = None
+    with HipNodeIndex(d, n, [0] * c["node_shards"], dtype=tdt) as nx:
+        if c["cand_cap"] and c["cand_cap"] >= k:
+            nx.set_param("cand_cap", c["cand_cap"])
+        for key in ("dense_rows", "sample_div", "growth"):
+            if c[key]:
+                nx.set_param(key, c[key])
+        if c["tile"]:
+            nx.set_param("tile", c["tile"])
+        if c["build"] == "reset_refill":
+            nx.add(rng.integers(-lim, lim + 1, size=(n, d)).astype(np.float32))
+            nx.reset()
+        if c["build"] == "chunks":
+            cuts = sorted(set([0, n] + [int(v) for v in rng.integers(0, n + 1, size=3)]))
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                if hi > lo:
+                    nx.add(x[lo:hi])
+        else:
+            nx.add(x)
+        assert nx.ntotal == n
+        if c["subset"]:
+            labels = rng.integers(0, 6, size=n).astype(np.int32)
+            subset = np.full((nq, 2), -1, dtype=np.int32)
+            for r in range(nq):
+                m = int(rng.integers(0, 3))
+                subset[r, :m] = rng.choice(7, size=m, replace=False)
+            nx.set_row_labels(labels)
+        if subset is None and rng.random() < 0.5:  # device-side entry: queries and results on devices[0]
+            ts, ti = nx.search(torch.from_numpy(q).cuda(), k)
+            gs, gi = ts.cpu().numpy(), ti.cpu().numpy()
+        else:
+            gs, gi = nx.search(q, k, subset=subset)
+        gs2, gi2 = nx.search(q, k, subset=subset)  # determinism / stale buffers
+    full = q.astype(np.float64) @ x.astype(np.float64).T
+    if subset is not None:
+        for r in range(nq):
+            allowed = subset[r][subset[r] >= 0]
+            if allowed.size:
+                full[r, ~np.isin(labels, allowed)] = np.nan
+    rs, ri = topk_desc_tiebreak(full, k)
+    assert np.array_equal(gi, ri), f"node index ({c['node_shards']} shards): ids differ: first bad row {np.argwhere((gi != ri).any(axis=1))[:3].ravel().tolist()}"
+    assert np.array_equal(gs, rs), "node index: scores differ"
+    assert np.array_equal(gi2, gi) and np.array_equal(gs2, gs), "node index: second search differs"
+    return {"last_chunks": 0, "last_safe_reruns": 0, "last_recovered_queries": 0}
+
+
 def run_trial(c):
+    if c.get("node_shards"):
+        return run_node_trial(c)
     rng = np.random.default_rng(c["rng_seed"])
     n, d, nq, k = c["n"], c["d"], c["nq"], c["k"]
     tdt = torch.float16 if c["dtype"] == "f16" else torch.bfloat16
