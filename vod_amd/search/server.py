@@ -406,10 +406,15 @@ class HipEngine:
     pipelined = True
     MAX_IN_FLIGHT = 3
 
+    _pipe_create = threading.Lock()
+
     def _pipeline(self):
         st = getattr(self, "_pipe", None)
         if st is None:
-            st = self._pipe = {"submit": threading.Lock(), "turn": threading.Condition(), "next_ticket": 0, "next_done": 0, "slots": {}}
+            with HipEngine._pipe_create:  # first use from several handler threads at once: ONE state object
+                st = getattr(self, "_pipe", None)
+                if st is None:
+                    st = self._pipe = {"submit": threading.Lock(), "turn": threading.Condition(), "next_ticket": 0, "next_done": 0, "slots": {}}
         return st
 
     def in_flight(self) -> int:
