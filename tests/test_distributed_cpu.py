@@ -188,3 +188,43 @@ def test_bench_launcher_eight_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.lstrip().startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0]) == {"launch_check": "ok", "world": 8, "rank_sum": 28.0}
+
+
+def _one_sided_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vod_amd.distributed import ShardedFlatIndex
+    from vod_amd.search.group import GroupDispatcher
+
+    def local_search(queries, kk, base, subset=None):
+        if rank == 1:  # stands for a HIP out-of-memory / launch failure on ONE shard
+            raise RuntimeError("injected: hipErrorOutOfMemory on this shard only")
+        return torch.zeros((len(queries), kk)), torch.zeros((len(queries), kk), dtype=torch.int64)
+
+    disp = GroupDispatcher(ShardedFlatIndex(None, 0, local_search=local_search, merge=lambda s, i: (s[0], i[0])), rank, world,
+                           torch.device("cpu"), dim=4)
+    if rank != 0:
+        disp.worker_loop()  # must not return: the one-sided failure ends the process with a non-zero code
+        os._exit(0)
+    disp.search(np.zeros((2, 4), np.float32), 3)  # blocks in the all-gather rank 1 never joins - until the test kills it
+    os._exit(0)
+
+
+def test_group_worker_dies_on_a_one_sided_failure():
+    """Round-3 advisor: a worker that swallows an error only IT raised skips the all-gather the other ranks are blocked in, and every
+    later request hangs.  Such a failure must end the worker non-zero (the owner process then tears the group down and reports it);
+    errors every rank raises alike before the collective are still survived (`test_group_dispatcher_two_ranks_gloo`)."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_one_sided_worker, args=(r, 2, port)) for r in range(2)]
+    for p in procs:
+        p.start()
+    procs[1].join(timeout=120)
+    try:
+        assert procs[1].exitcode == 3, f"the failing worker left with {procs[1].exitcode}"
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+            p.join(timeout=30)

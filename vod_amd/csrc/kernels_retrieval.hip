@@ -91,7 +91,9 @@ template <int DT, bool S3D, bool PRE = false>
 __global__ __launch_bounds__(RT_THREADS) void retrieval_forward_kernel(
     const void* __restrict__ q, const void* __restrict__ s, int D, int H, const float* __restrict__ score,
     const int64_t* __restrict__ relevance, const float* __restrict__ sparse, const float* __restrict__ dense,
-    float* __restrict__ retriever_scores, float* __restrict__ d_scores, float* __restrict__ workspace, RetrievalAux aux,
+    // the two outputs carry no `restrict`: in the PRE instantiation `pre_slabs` may point INTO them (the contraction's slab(s)
+    // when the caller's workspace has no room); the row is read into LDS, a barrier follows, then it is written
+    float* retriever_scores, float* d_scores, float* __restrict__ workspace, RetrievalAux aux,
     const float* pre_slabs = nullptr /* may alias the two outputs: read into LDS first */, int n_slabs = 0, int64_t slab_stride = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qrow = (float*)smem;   // [H]

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <deque>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -96,6 +97,7 @@ struct vodhip_index {
     int* q_map = nullptr;                   // device [MAX_IN_FLIGHT][OVF_ROWS]: the rows a slot's recovery pass re-searches
     hipEvent_t done[MAX_IN_FLIGHT] = {};    // recorded after a search's overflow word is copied back
     std::deque<PendingSearch> inflight;     // oldest first
+    int unfinished = 0;                     // searches popped by a vodhip_index_search_finish that is still waiting for their event
     int next_slot = 0;
     // tunables
     int64_t cand_cap = 16384;
@@ -114,6 +116,10 @@ struct vodhip_index {
     int64_t last_recovery_launches = 0, last_recovery_ns = 0;  // filter launches of the recovery passes (with "profile")
     std::vector<hipEvent_t> ev_pool;  // pairs (start, stop), reused across searches
     size_t ev_used = 0;
+    // Every entry point that touches `inflight`, the shared workspace (`ws`, incl. its host-side `extra`) or the event pool holds
+    // this: a server thread may enqueue search i + 1 while another completes (and, after an overflow, RE-ENQUEUES recovery passes of)
+    // search i on the same handle.  The wait for a search's completion event happens outside it.
+    std::mutex mu;
 };
 
 namespace {
@@ -576,6 +582,7 @@ int vodhip_index_set_query_labels(vodhip_index_t* ix, const int32_t* q_labels_de
     if (!ix) return fail("index is NULL");
     if (q_labels_dev && (n_per_query < 1 || n_per_query > 64)) return fail("n_per_query must be in [1, 64]");
     if (q_labels_dev && !ix->row_label) return fail("set the row labels first (vodhip_index_set_row_labels)");
+    std::lock_guard<std::mutex> guard(ix->mu);
     ix->q_label = q_labels_dev;
     ix->n_qlab = q_labels_dev ? n_per_query : 0;
     return 0;
@@ -587,8 +594,9 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
     if (k < 1 || k > VODHIP_MAX_K) return fail("k=%d out of range [1, %d]", k, VODHIP_MAX_K);
     if (nq < 0 || (nq > 0 && (!queries || !out_scores || !out_ids))) return fail("invalid query / output pointers");
     if (q_dtype < 0 || q_dtype > 2) return fail("invalid q_dtype %d", q_dtype);
+    std::lock_guard<std::mutex> guard(ix->mu);
     if (ix->cand_cap < ROW_ALIGN || ix->cand_cap < k) return fail("cand_cap too small");
-    if ((int)ix->inflight.size() >= MAX_IN_FLIGHT)
+    if ((int)ix->inflight.size() + ix->unfinished >= MAX_IN_FLIGHT)
         return fail("%d searches are already in flight on this index: call vodhip_index_search_finish first", MAX_IN_FLIGHT);
     HIP_OK(hipSetDevice(ix->device));
     PendingSearch ps;
@@ -603,7 +611,7 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
     ps.q_label = ix->q_label;
     ps.n_qlab = ix->n_qlab;
     ps.slot = ix->next_slot;
-    if (ix->inflight.empty()) ix->ev_used = 0;  // profile events are recycled once nothing refers to them
+    if (ix->inflight.empty() && ix->unfinished == 0) ix->ev_used = 0;  // profile events are recycled once nothing refers to them
     ps.ev_begin = ix->ev_used;
     if (nq > 0 && enqueue_search(ix, ps, ix->force_safe != 0, 0, (hipStream_t)stream_)) return -1;
     ps.ev_end = ix->ev_used;
@@ -614,18 +622,29 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
 
 int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
     if (!ix) return fail("index is NULL");
-    if (ix->inflight.empty()) return fail("no search is pending on this index");
     hipStream_t stream = (hipStream_t)stream_;
+    std::unique_lock<std::mutex> guard(ix->mu);
+    if (ix->inflight.empty()) return fail("no search is pending on this index");
     HIP_OK(hipSetDevice(ix->device));
     PendingSearch ps = ix->inflight.front();
     ix->inflight.pop_front();
+    if (ps.nq > 0) {
+        // this search only: younger ones keep the device busy - and other threads may enqueue more meanwhile (the slot and its
+        // event are not reused before MAX_IN_FLIGHT further searches, which cannot be accepted while this one counts as unfinished:
+        // `unfinished` below)
+        ++ix->unfinished;
+        guard.unlock();
+        const hipError_t ev_rc = hipEventSynchronize(ix->done[ps.slot]);
+        guard.lock();
+        --ix->unfinished;
+        HIP_OK(ev_rc);
+    }
     ix->last_overflow = 0;
     ix->last_safe_reruns = 0;
     ix->last_recovered_queries = 0;
     ix->last_recovery_launches = 0;
     ix->last_recovery_ns = 0;
     if (ps.nq > 0) {
-        HIP_OK(hipEventSynchronize(ix->done[ps.slot]));  // this search only: younger ones keep the device busy
         // A candidate list overflowed: the result is valid (real rows, real scores) but may miss hits.  Recovery
         // passes re-scan the store against thresholds seeded from that result - its k-th score is a lower bound of the
         // true k-th best, so few rows survive - in 1, 2, 4, ... FILTER stages, and in the exhaustive schedule (dense

@@ -40,6 +40,9 @@ class ShardedFlatIndex:
             from vod_amd.index import merge_topk as merge  # HIP k-way merge
         self._merge = merge
         self._packed = None
+        # set while a search is between its first collective call and its return: an exception raised there (or any one-sided
+        # failure before it) leaves the ranks out of step - the group server treats it as fatal (vod_amd/search/group.py)
+        self.entered_collective = False
 
     def _all_gather(self, dst: torch.Tensor, src: torch.Tensor) -> None:
         """ONE all-gather of the packed result.  RCCL moves device buffers directly; a gloo group (the server's
@@ -60,6 +63,7 @@ class ShardedFlatIndex:
         """queries [nq, d] (and `subset` int32 [nq, S] allowed row labels, optional), identical on every rank.
         Returns (scores f32 [nq, k], global ids i64 [nq, k])."""
         world = self.world
+        self.entered_collective = False
         if self._native_path and (world > 1 or (self.always_exchange and dist.is_initialized())):
             from vod_amd.index import PackedTopk
 
@@ -69,14 +73,20 @@ class ShardedFlatIndex:
                 self._gathered = torch.empty((world * self._packed.nbytes,), dtype=torch.uint8, device=self.local_index.device)
             p = self._packed
             self.local_index.search(queries, k, id_base=self.row_offset, out=(p.scores, p.ids), subset=subset)
+            self.entered_collective = True
             self._all_gather(self._gathered, p.buffer)  # 12 * nq * k bytes per rank, one collective
-            return p.merge_gathered(self._gathered, world)
+            out = p.merge_gathered(self._gathered, world)
+            self.entered_collective = False
+            return out
         s, i = self._local_search(queries, k, self.row_offset) if subset is None else self._local_search(queries, k, self.row_offset, subset)
         if world == 1:
             return s, i
         nq, kk = s.shape
         gs = torch.empty((world * nq, kk), dtype=s.dtype, device=s.device)  # rank-major concatenation
         gi = torch.empty((world * nq, kk), dtype=i.dtype, device=i.device)
+        self.entered_collective = True
         dist.all_gather_into_tensor(gs, s.contiguous(), group=self.group)
         dist.all_gather_into_tensor(gi, i.contiguous(), group=self.group)
-        return self._merge(gs.view(world, nq, kk), gi.view(world, nq, kk))
+        out = self._merge(gs.view(world, nq, kk), gi.view(world, nq, kk))
+        self.entered_collective = False
+        return out

@@ -202,7 +202,10 @@ def find_payload_spans(body, payload_keys: tuple[str, ...]) -> tuple[dict, dict[
         colon = mv.find(b":", i + len(tag))
         j = mv.find(b'"', colon + 1)
         k = mv.find(b'"', j + 1)
-        if colon < 0 or j < 0 or k < 0 or mv[colon + 1 : j].strip() or mv.find(b"\\", j + 1, k) >= 0:
+        # the shortcut only holds when the match IS the top-level key followed by a plain string: anything else - the text occurring
+        # twice (e.g. inside `subset_ids`), something between key and colon, a non-string value, an escape - goes through `json.loads`
+        twice = k >= 0 and mv.find(tag, k + 1) >= 0  # (the payload itself is base64 text: no quote, so only the rest is searched)
+        if twice or colon < 0 or j < 0 or k < 0 or mv[i + len(tag) : colon].strip() or mv[colon + 1 : j].strip() or mv.find(b"\\", j + 1, k) >= 0:
             full = json.loads(bytes(mv))
             if not isinstance(full, dict):
                 raise ValueError("expected a JSON object")

@@ -268,8 +268,12 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         if uds is True:
             import tempfile
 
-            uds = os.path.join(tempfile.gettempdir(), f"vodhip-{os.getpid()}-{self.port}.sock")
+            # named after the PORT only: a rank built with `skip_setup=True` (it only connects) must derive the same path as the
+            # rank that spawned the server, whatever its pid
+            uds = os.path.join(tempfile.gettempdir(), f"vodhip-{self.port}.sock")
         self.uds = uds or None
+        if self.uds and http == "uvicorn":
+            raise ValueError("`uds` needs the in-tree HTTP shells (http='native' | 'asyncio'): the uvicorn shell does not open the socket")
 
     def _make_env(self) -> dict[str, str]:
         env = copy(dict(os.environ))

@@ -10,7 +10,8 @@ concurrent clients are accepted - and fused by the `MicroBatcher` - while anothe
 
 Same contract as the FastAPI app (`vod_amd.search.server.create_app`, kept for ASGI hosting and tests): both are thin shells
 around `server.Endpoints`, which owns routes, validation and error mapping (422 for a malformed document, 500 with the trace
-for a failing search).  Connections are keep-alive; `Expect: 100-continue` and chunked request bodies are answered per RFC 9110.
+for a failing search).  Connections are keep-alive; `Expect: 100-continue` is honoured; chunked REQUEST bodies are not supported (501: send Content-Length,
+as every client of this service does).
 """
 from __future__ import annotations
 

@@ -68,8 +68,30 @@ class GroupDispatcher:
             dist.broadcast(q, 0, group=self.group)
             if sub is not None:
                 dist.broadcast(sub, 0, group=self.group)
-        scores, ids = self._local(q, int(top_k), sub)
+        try:
+            scores, ids = self._local(q, int(top_k), sub)
+        except Exception as exc:
+            if self.world > 1 and not self._same_on_every_rank(exc):
+                self._fatal(exc)
+            raise
         return scores.cpu().numpy(), ids.cpu().numpy()
+
+    def _same_on_every_rank(self, exc: BaseException) -> bool:
+        """An argument error raised BEFORE the search's collective is raised by every rank alike (same request, same checks): the
+        ranks stay in step and the request becomes an HTTP 500.  Anything else - a HIP / RCCL failure, an out-of-memory on one shard,
+        any error after the all-gather was entered - is one-sided: the other ranks are (or will be) blocked in a collective this rank
+        skipped."""
+        return isinstance(exc, (ValueError, TypeError)) and not getattr(self.sharded, "entered_collective", False)
+
+    def _fatal(self, exc: BaseException) -> None:
+        """Fail fast: leave non-zero so that the owner process sees a dead rank, terminates the group and reports it
+        (`server.run_owner`) - instead of every later request hanging until the client's timeout."""
+        import os
+
+        logging.getLogger(__name__).critical("rank %d: one-sided failure inside a group search (%s: %s): terminating the group",
+                                             self.rank, type(exc).__name__, exc, exc_info=exc)
+        logging.shutdown()
+        os._exit(3)
 
     def _local(self, q: torch.Tensor, k: int, sub: torch.Tensor | None) -> tuple[torch.Tensor, torch.Tensor]:
         if self.search_device != self.device:
@@ -100,10 +122,12 @@ class GroupDispatcher:
                 dist.broadcast(sub, 0, group=self.group)
             try:
                 self._local(q, k, sub)
-            except Exception:  # noqa: BLE001
-                # rank 0 validated the request before broadcasting it, so what is left are argument errors that every
+            except Exception as exc:  # noqa: BLE001
+                # rank 0 validated the request before broadcasting it, so what may be left are argument errors that every
                 # rank raises alike BEFORE its collective (rank 0 turns its own into that request's HTTP 500): log and keep
-                # serving - one bad request must not take the group down
+                # serving - one bad request must not take the group down.  A one-sided failure must: see `_fatal`
+                if not self._same_on_every_rank(exc):
+                    self._fatal(exc)
                 logging.getLogger(__name__).exception("rank %d: search failed; still serving", self.rank)
                 self.errors += 1
             served += 1
