@@ -62,6 +62,8 @@ def parse_args() -> argparse.Namespace:
                    help="skip the side workloads (C2, nq = 256, clustered C3, the 1.25 M-row shard with the exchange) the default 1-GPU run appends as `side`")
     p.add_argument("--verify-queries", type=int, default=64)
     p.add_argument("--cpu-seconds", type=float, default=15.0)
+    p.add_argument("--init-timeout", type=float, default=300.0,
+                   help="seconds a rank waits for the process-group rendezvous + the first collective before it exits non-zero (code 75)")
     p.add_argument("--launch-check", action="store_true",
                    help="CPU-only check of the launcher: every rank joins a gloo group, all-reduces its rank, rank 0 prints one JSON line")
     return p.parse_args()
@@ -92,23 +94,66 @@ def _free_rendezvous_port(socket) -> int:
         return s.getsockname()[1]
 
 
-def launch_ranks(n: int) -> int:
+def visible_gpu_count() -> "int | None":
+    """GPUs this process would see, WITHOUT touching the HIP runtime (the launcher's parent must never initialise a GPU): the KFD
+    topology in sysfs (nodes with SIMDs are GPUs), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None = cannot tell."""
+    fake = os.environ.get("VODHIP_BENCH_FAKE_GPUS")  # tests of the preflight on a box without a GPU
+    if fake is not None:
+        return int(fake)
+    if not os.path.exists("/dev/kfd"):
+        return 0  # no compute device node at all: ROCm cannot open any GPU from this process
+    n = None
+    try:
+        nodes = pathlib.Path("/sys/class/kfd/kfd/topology/nodes")
+        n = 0
+        for node in nodes.iterdir():
+            props = dict(ln.split()[:2] for ln in (node / "properties").read_text().splitlines() if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        n = None
+    if n is None:
+        try:
+            n = len([d for d in os.listdir("/dev/dri") if d.startswith("renderD")])
+        except OSError:
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def launch_ranks(n: int, launch_check_only: bool = False) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh children (one per GPU) and wait for them.
 
     The parent never touches the GPU (it does not even import torch): a process that has initialised HIP must not be
-    replaced or forked into ranks.  Rank 0 inherits stdout, so its JSON line is this command's output."""
+    replaced or forked into ranks.  Rank 0 inherits stdout, so its JSON line is this command's output.  Every rank's stderr
+    (and the other ranks' stdout) is kept in a scratch directory; when a rank leaves non-zero - it died, or its own init
+    watchdog fired - the others are terminated (they would wait in a collective for ever) and the tails of ALL ranks' logs are
+    printed, failing rank first, so the one record of a failed N-GPU run says which rank failed and why."""
     import socket
     import subprocess
+    import tempfile
 
+    if not launch_check_only:
+        have = visible_gpu_count()
+        if have is not None and have < n:
+            print(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node (KFD topology / *_VISIBLE_DEVICES): refusing to start "
+                  f"{n} ranks that would share or miss devices", file=sys.stderr)
+            return 2
     port = _free_rendezvous_port(socket)
-    procs = []
+    logdir = pathlib.Path(tempfile.mkdtemp(prefix="vodhip_bench_"))
+    procs, files = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, str(pathlib.Path(__file__).resolve()), *sys.argv[1:]], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
+        err = open(logdir / f"rank{r}.err", "wb")
+        out = None if r == 0 else open(logdir / f"rank{r}.out", "wb")
+        files += [f for f in (err, out) if f is not None]
+        procs.append(subprocess.Popen([sys.executable, str(pathlib.Path(__file__).resolve()), *sys.argv[1:]], env=env, stdout=out, stderr=err))
+    rc, failed = 0, None
     alive = list(procs)
     while alive:
         time.sleep(0.05)
@@ -119,19 +164,83 @@ def launch_ranks(n: int) -> int:
             alive.remove(p)
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 1
+                failed = procs.index(p)
                 for other in alive:  # a rank died: the others would wait in a collective for ever
                     other.terminate()
+                deadline = time.monotonic() + 10.0
+                while any(o.poll() is None for o in alive) and time.monotonic() < deadline:
+                    time.sleep(0.05)
+                for other in alive:
+                    if other.poll() is None:
+                        other.kill()
+    for f in files:
+        f.close()
+
+    def tail(path: pathlib.Path, n_bytes: int = 3000) -> str:
+        try:
+            data = path.read_bytes()
+        except OSError:
+            return ""
+        return data[-n_bytes:].decode("utf-8", "replace")
+
+    if rc != 0:
+        order = [failed] + [r for r in range(n) if r != failed]
+        print(f"bench.py --gpus {n}: rank {failed} left with exit code {rc}; the other ranks were terminated.  Per-rank stderr tails:", file=sys.stderr)
+        for r in order:
+            print(f"---- rank {r} (exit {procs[r].returncode}) ----\n{tail(logdir / f'rank{r}.err')}", file=sys.stderr)
+    else:
+        sys.stderr.write(tail(logdir / "rank0.err", 20000))  # rank 0's warnings stay visible on a clean run
+        import shutil
+
+        shutil.rmtree(logdir, ignore_errors=True)
     return rc
 
 
-def launch_check(rank: int, world: int) -> None:
+def _init_watchdog(seconds: float, what: str):
+    """A rank that cannot finish `what` within `seconds` (a peer that never arrives, an RCCL bootstrap that hangs) prints why and
+    leaves with code 75 - the launcher then ends the other ranks and reports.  Returns the function that disarms it."""
+    import threading
+
+    def fire():
+        print(f"[bench rank {os.environ.get('RANK', '?')}] {what} did not complete within {seconds:.0f} s: giving up "
+              f"(MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} WORLD_SIZE={os.environ.get('WORLD_SIZE')})",
+              file=sys.stderr, flush=True)
+        os._exit(75)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t.cancel
+
+
+def _test_fault(stage: str, rank: int) -> None:
+    """Fault injection for the launcher's CPU tests (VODHIP_BENCH_TEST_FAULT=die:RANK | hang:RANK at the process-group init)."""
+    spec = os.environ.get("VODHIP_BENCH_TEST_FAULT", "")
+    if not spec or stage != "init":
+        return
+    kind, _, r = spec.partition(":")
+    if int(r or -1) != rank:
+        return
+    if kind == "die":
+        print(f"[bench rank {rank}] injected failure before the process-group init", file=sys.stderr, flush=True)
+        os._exit(41)
+    if kind == "hang":
+        time.sleep(3600)
+
+
+def launch_check(rank: int, world: int, init_timeout: float) -> None:
+    import datetime
+
     import torch
     import torch.distributed as dist
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    disarm = _init_watchdog(init_timeout, "the process-group rendezvous")
+    _test_fault("init", rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=init_timeout + 30))
     t = torch.tensor([float(rank)])
     dist.all_reduce(t)
     dist.barrier()
+    disarm()
     if rank == 0:
         print(json.dumps({"launch_check": "ok", "world": world, "rank_sum": float(t.item())}), flush=True)
     dist.destroy_process_group()
@@ -181,9 +290,11 @@ PRACTICAL_HBM = 6.29e12    # B/s of a streaming copy (MI355X_MICROARCH.md:34-43)
 class Rig:
     """Process-wide state of one bench process: device, rank, the (lazily created) process group."""
 
-    def __init__(self, torch, dev, rank, world, backend="nccl"):
+    def __init__(self, torch, dev, rank, world, backend="nccl", init_timeout: float = 300.0):
         self.torch, self.dev, self.rank, self.world, self.backend = torch, dev, rank, world, backend
         self.dist = None
+        self.init_timeout = init_timeout
+        self.comm = None  # what the process group reports about itself once it is up (goes into the JSON line)
 
     def ensure_group(self):
         if self.dist is None:
@@ -194,11 +305,31 @@ class Rig:
                 import socket
 
                 os.environ["MASTER_PORT"] = str(_free_rendezvous_port(socket))
+            import datetime
+
+            # rendezvous + communicator + FIRST collective under a watchdog: a rank that cannot get through leaves with code 75 and a
+            # message instead of hanging the node's one measurement (the launcher then ends the other ranks and prints every rank's stderr)
+            disarm = _init_watchdog(self.init_timeout, f"the {self.backend} process-group init + first all-reduce")
+            _test_fault("init", self.rank)
+            t0 = time.perf_counter()
+            limit = datetime.timedelta(seconds=self.init_timeout + 30)
             if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.dev, rank=self.rank, world_size=self.world)
+                dist.init_process_group("nccl", device_id=self.dev, rank=self.rank, world_size=self.world, timeout=limit)
             else:
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=limit)
             self.dist = dist
+            seen = self.all_reduce_scalar(1.0, "SUM")  # the first collective builds the communicator: every rank must show up in it
+            self.torch.cuda.synchronize()
+            disarm()
+            rccl = None
+            try:
+                rccl = ".".join(str(v) for v in self.torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                pass
+            self.comm = {"backend": "rccl" if self.backend == "nccl" else "gloo", "world_size": dist.get_world_size(),
+                         "ranks_in_first_all_reduce": int(round(seen)), "rccl_version": rccl, "comm_init_s": round(time.perf_counter() - t0, 3)}
+            if int(round(seen)) != self.world:
+                raise SystemExit(f"rank {self.rank}: the first all-reduce saw {seen} ranks, WORLD_SIZE is {self.world}")
         return self.dist
 
     def all_gather(self, dst, src) -> None:
@@ -327,36 +458,53 @@ def run_workload(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, 
         n_v = min(nq, max(1, verify_queries))
         sample = [int(round(j * (nq - 1) / max(1, n_v - 1))) for j in range(n_v)] if n_v > 1 else [0]
         sample = sorted(set(sample))
-        # local brute force on this rank's shard with torch (fp32 matmul on the stored rows), merged over ranks
+        # local brute force on this rank's shard: a chunked FLOAT64 product over the STORED (rounded) rows - every fp16 x fp16
+        # product is exact in fp64 and the 768-1024-term sums carry ~1e-13 relative error, so `max_abs_score_diff` is the
+        # kernel's own fp32-accumulation error, not a mix of two fp32 summation orders (round 3 compared with an fp32 matmul)
         kk = min(k, n_local)
-        ls = torch.full((len(sample), kk), float("-inf"), device=dev)
+        ls = torch.full((len(sample), kk), float("-inf"), device=dev, dtype=torch.float64)
         li = torch.full((len(sample), kk), -1, dtype=torch.int64, device=dev)
-        qs = queries[sample].float()
-        for lo in range(0, n_local, 1_000_000):  # stable sorts: ties keep the smaller id first, like the product
-            blk = index.stored_rows(lo, min(1_000_000, n_local - lo)).float()
-            ts, ti = torch.sort(qs @ blk.T, dim=1, descending=True, stable=True)
-            ts, ti = ts[:, :kk], ti[:, :kk]
+        qs = queries[sample].double()
+        step_rows = 250_000
+        for lo in range(0, n_local, step_rows):  # stable sorts: ties keep the smaller id first, like the product
+            blk = index.stored_rows(lo, min(step_rows, n_local - lo)).double()
+            sc = qs @ blk.T
+            kb = min(kk, sc.shape[1])
+            ts, ti = torch.sort(sc, dim=1, descending=True, stable=True)
+            ts, ti = ts[:, :kb], ti[:, :kb]
             cs, ci = torch.cat([ls, ts], dim=1), torch.cat([li, ti + (lo + row_lo)], dim=1)
             top = torch.sort(cs, dim=1, descending=True, stable=True)
             ls, li = top.values[:, :kk], torch.gather(ci, 1, top.indices[:, :kk])
-            del blk
+            del blk, sc
         if multi:
-            pad_s = torch.full((len(sample), k), float("-inf"), device=dev)
+            pad_s = torch.full((len(sample), k), float("-inf"), device=dev, dtype=torch.float64)
             pad_i = torch.full((len(sample), k), -1, dtype=torch.int64, device=dev)
             pad_s[:, : ls.shape[1]] = ls
             pad_i[:, : li.shape[1]] = li
-            as_ = torch.empty((world * len(sample), k), device=dev)
+            as_ = torch.empty((world * len(sample), k), device=dev, dtype=torch.float64)
             ai_ = torch.empty((world * len(sample), k), dtype=torch.int64, device=dev)
             rig.all_gather(as_, pad_s)
             rig.all_gather(ai_, pad_i)
-            ls, li = merge_topk(as_.view(world, len(sample), k), ai_.view(world, len(sample), k))
+            # merge of the per-rank reference lists in fp64 (rank-major = ascending ids: the stable sort keeps the tie-break)
+            cs = as_.view(world, len(sample), k).permute(1, 0, 2).reshape(len(sample), world * k)
+            ci = ai_.view(world, len(sample), k).permute(1, 0, 2).reshape(len(sample), world * k)
+            top = torch.sort(cs, dim=1, descending=True, stable=True)
+            ls, li = top.values[:, :k], torch.gather(ci, 1, top.indices[:, :k])
         got_i = fi[sample].cpu()
         ref_i = li.cpu()
         hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got_i, ref_i))
+        got_s = fs[sample][:, : ls.shape[1]].double().cpu()
+        ref_s = ls.cpu()
+        fin = torch.isfinite(ref_s) & torch.isfinite(got_s)
+        diff = (got_s - ref_s).abs()[fin]
+        scale = float(ref_s[fin].abs().max()) if bool(fin.any()) else 0.0
         verify = {
-            "recall_at_k_vs_torch_fp32": hits / float(ref_i.numel()),
+            "comparator": "float64 chunked product over the stored rows (ties -> smaller id)",
+            "recall_at_k": hits / float(ref_i.numel()),
             "rows_with_identical_id_order": float((got_i[:, : ref_i.shape[1]] == ref_i).all(dim=1).float().mean()),
-            "max_abs_score_diff": float((fs[sample][:, : ls.shape[1]].cpu() - ls.cpu()).abs().max()),
+            "max_abs_score_diff": float(diff.max()) if diff.numel() else 0.0,
+            "max_rel_score_diff": float((diff / ref_s[fin].abs().clamp_min(1e-30)).max()) if diff.numel() else 0.0,
+            "score_scale": scale,  # largest |score| among the checked hits: the 1e-3 absolute tolerance is a statement about |score| <~ 200
             "queries_checked": len(sample),
         }
     return {"elapsed": elapsed, "filter_ns": state["ns"], "filter_launches": state["launches"], "recovery_passes": state["recovery_passes"],
@@ -425,21 +573,23 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
     the headline fields."""
     out = []
 
-    def one(name, *, rows, nq, data="iid", multi=False, steps, warmup, index=None, row_lo=0):
+    def one(name, *, rows, nq, data="iid", multi=False, steps, warmup, index=None, row_lo=0, dim=None, k=None, dtype=None):
+        dim, k, dtype = dim or args.dim, k or args.k, dtype or args.dtype
         try:
             own = index is None
             t_build = None
             if own:
-                index, row_lo, t_build = build_index(rig, rows=rows, dim=args.dim, dtype=args.dtype, data=data)
+                index, row_lo, t_build = build_index(rig, rows=rows, dim=dim, dtype=dtype, data=data)
             try:
-                m = run_workload(rig, index, row_lo, rows=rows, dim=args.dim, nq=nq, k=args.k, dtype=args.dtype, data=data,
+                m = run_workload(rig, index, row_lo, rows=rows, dim=dim, nq=nq, k=k, dtype=dtype, data=data,
                                  multi=multi, steps=steps, warmup=warmup, verify_queries=args.verify_queries)
             finally:
                 if own:
                     index.close()
+                    rig.torch.cuda.empty_cache()
             out.append({
                 "name": name,
-                "workload": f"{rows} sections x {args.dim} {args.dtype}, batch {nq} queries, top-{args.k}" + ("" if data == "iid" else ", rows sorted by topic cluster")
+                "workload": f"{rows} sections x {dim} {dtype}, batch {nq} queries, top-{k}" + ("" if data == "iid" else ", rows sorted by topic cluster")
                             + (", + RCCL all-gather (1 rank) + merge" if multi else ""),
                 "steps": steps, "warmup": warmup,
                 "ms_per_step": m["elapsed"] / steps * 1e3,
@@ -458,13 +608,28 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
     one("C3_clustered", rows=args.rows, nq=args.nq, data="clustered", steps=max(5, args.steps), warmup=3)
     one("C3_shard_of_8", rows=args.rows // 8, nq=args.nq, steps=100, warmup=10)
     one("C3_shard_of_8_with_exchange", rows=args.rows // 8, nq=args.nq, multi=True, steps=100, warmup=10)
+    # BASELINE configs[3] (C4: 40 M x 1024 bf16, batch 512, top-200): what each of its 8 GPUs holds, and the whole store on this ONE GPU (82 GB)
+    one("C4_shard_of_8", rows=5_000_000, dim=1024, nq=512, k=200, dtype="bf16", steps=40, warmup=5)
+    free_b = rig.torch.cuda.mem_get_info(rig.dev)[0]
+    if free_b > 110e9:
+        one("C4_one_gpu", rows=40_000_000, dim=1024, nq=512, k=200, dtype="bf16", steps=10, warmup=3)
+    else:
+        out.append({"name": "C4_one_gpu", "skipped": f"{free_b / 1e9:.0f} GB of HBM free: the 82 GB store + workspace do not fit next to the headline store"})
+    # BASELINE configs[4] (C5: hybrid merge + priority sampling + in-batch retrieval loss, batch 64 x 32 sections)
+    try:
+        sys.path.insert(0, str(ROOT / "tools"))
+        import side_c5  # noqa: PLC0415  (tools/side_c5.py: timings + fixture verification of the collate-side chain and the loss)
+
+        out.append(side_c5.measure(rig.dev, cpu_baseline=not args.no_cpu_baseline))
+    except Exception as exc:  # noqa: BLE001
+        out.append({"name": "C5", "error": f"{type(exc).__name__}: {exc}"[:400]})
     return out
 
 
 def main() -> None:
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(launch_ranks(args.gpus))
+        raise SystemExit(launch_ranks(args.gpus, launch_check_only=args.launch_check or args.backend == "gloo")  # (gloo test rig: ranks may share a GPU))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool (before HIP starts)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -472,7 +637,7 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.launch_check:
-        return launch_check(rank, world)
+        return launch_check(rank, world, args.init_timeout)
     import torch
 
     from vod_amd.hostcpu import limit_cpu_threads, usable_cpus
@@ -482,12 +647,14 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     if args.backend == "gloo":  # test rig: the ranks may share a GPU
         local_rank %= torch.cuda.device_count()
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) are visible to this process")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_collective  # the exchange step runs (with one rank it gathers from itself)
     if rank != 0:  # only rank 0 reports: keep the other ranks' library banners out of the launcher's merged stdout
         os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
-    rig = Rig(torch, dev, rank, world, args.backend)
+    rig = Rig(torch, dev, rank, world, args.backend, init_timeout=args.init_timeout)
     if multi:
         os.environ.setdefault("MASTER_PORT", "29517")
         rig.ensure_group()
@@ -531,6 +698,8 @@ def main() -> None:
             },
             "roofline": roofline_of(m, world),
         }
+        if rig.comm is not None:  # did the collective library see N ranks?  (answerable from the record alone)
+            line["comm"] = rig.comm
         if m["verify"] is not None:
             line["verify"] = m["verify"]
         if side is not None:

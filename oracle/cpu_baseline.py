@@ -151,7 +151,8 @@ def time_cpu_baseline(dim: int, nq: int, k: int, n_full: int, target_seconds: fl
     return {
         "value": nq / t_full,
         "unit": "queries/s",
-        "cores": threads,
+        "cores": effective_cpus(),  # the CPUs this process may use (affinity capped by the cgroup quota) ...
+        "threads": threads,         # ... and the BLAS / OpenMP threads the fastest probe ran on (oversubscription can pay for sgemm)
         "kind": "port",
         "sample": f"faiss-CPU restated (MKL sgemm + threshold-filtered k-best buffer, fp32): {nq} queries x {rows} of {n_full} rows x {dim}, "
                   f"top-{k}, {t:.2f} s measured ({gflops:.0f} GFLOP/s end to end) on {threads} threads "
