@@ -629,7 +629,7 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
 def main() -> None:
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(launch_ranks(args.gpus, launch_check_only=args.launch_check or args.backend == "gloo")  # (gloo test rig: ranks may share a GPU))
+        raise SystemExit(launch_ranks(args.gpus, launch_check_only=args.launch_check or args.backend == "gloo"))  # (gloo test rig: ranks may share a GPU)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool (before HIP starts)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
