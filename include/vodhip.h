@@ -369,6 +369,86 @@ int vodhip_collate(const vodhip_collate_args_t* args, void* stream);
 int64_t vodhip_b64url_encode(const uint8_t* head, int64_t n_head, const uint8_t* data, int64_t n_data, char* out);
 int64_t vodhip_b64url_decode(const char* src, int64_t n, uint8_t* out);
 
+/* ---------------------------------------------------------------------------------------------
+ * H6  serving: request fusion in front of one index + an HTTP/1.1 front for the search service's hot routes
+ *     (host code only; native threads, no interpreter on the request path).
+ * Replaces: the reference's single uvicorn worker, which runs `faiss_index.search` for ONE request at a time
+ *           (src/vod_search/faiss_search/server.py:57-98) while every DataLoader worker of every trainer rank sends its own small
+ *           batch (src/vod_dataloaders/realm_dataloader.py:92-118, core/search.py:128-146); and the wire codec of
+ *           src/vod_search/io.py:17-32 on the server side of /fast-search.
+ *
+ * vodhip_batcher   fuses concurrent searches into shared corpus scans (a brute-force scan reads the whole store whatever the batch
+ *   size).  Exactly one engine: `index` (searches are pipelined on the batcher's own stream, up to "depth" batches on the device,
+ *   result rows written straight into device-visible host memory), `node` (the node index; one batch at a time) or `fn` (a host
+ *   callback `fn(user, float32 queries [nq, dim], nq, k, subset | NULL, n_subset, out_scores, out_ids) -> 0 | error`, e.g. a
+ *   multi-process group; needs no GPU in this process).  The batcher OWNS the engine's search path while it exists: do not call
+ *   vodhip_index_search* on the same handle from elsewhere.
+ *   search: blocking, thread-safe; host pointers; q_dtype F32 | F16 (| BF16 for index / node); `subset` = int32 [nq, n_subset]
+ *     allowed row labels (vodhip_index_set_query_labels semantics; such a request runs as its own batch) or NULL; `client` = a tag
+ *     of the requester (connection id; 0 = anonymous).  Results are identical to separate vodhip_index_search calls: the fused batch
+ *     runs with k = max(k_i) and a prefix of a top-k' list is the top-k.
+ *   policy (no fixed wait window): a request that finds the engine idle runs at once, unless other clients that searched a moment
+ *     ago have nothing pending yet and the batch still fits one query tile ("flat_queries", 256: the scan costs the same with them
+ *     aboard) - then it waits for them at most min("grace_us", "grace_pct" % of a measured scan); requests that arrive while a batch
+ *     is on the device are fused, and enqueued behind it once they exceed one query tile (time is linear from there) or when it
+ *     completes.  params: "max_queries" (2048), "flat_queries", "grace_us" (1000; 0 = never wait), "grace_pct" (35), "window_us"
+ *     (0; > 0 = additionally wait this long for company, round 3's --micro-batch-wait-ms), "depth" (2).
+ *   stats: "batches", "requests", "queries", "fused_requests_max", "grace_waits", "grace_expired", "idle_ns", "busy_ns",
+ *     "last_batch_queries", "last_batch_requests", "flat_scan_ns", "in_flight", "pending", "active_clients".
+ * ------------------------------------------------------------------------------------------- */
+typedef struct vodhip_batcher vodhip_batcher_t;
+typedef int (*vodhip_search_fn)(void* user, const float* queries, int64_t nq, int k, const int32_t* subset, int n_subset,
+                                float* out_scores, int64_t* out_ids);
+int vodhip_batcher_create(vodhip_index_t* index, vodhip_node_index_t* node, vodhip_search_fn fn, void* user, int64_t dim,
+                          int64_t id_base, vodhip_batcher_t** out);
+int vodhip_batcher_destroy(vodhip_batcher_t* batcher);
+int vodhip_batcher_set_param(vodhip_batcher_t* batcher, const char* key, int64_t value);
+int vodhip_batcher_get_stat(vodhip_batcher_t* batcher, const char* key, int64_t* out);
+int vodhip_batcher_search(vodhip_batcher_t* batcher, const void* queries, int q_dtype, int64_t nq, int k, const int32_t* subset,
+                          int n_subset, uint64_t client, float* out_scores, int64_t* out_ids);
+int vodhip_batcher_forget_client(vodhip_batcher_t* batcher, uint64_t client);  /* the requester went away (connection closed) */
+
+/* vodhip_http  HTTP/1.1 server, one native thread per (keep-alive) connection, in front of a batcher:
+ *   POST /fast-search  {"vectors": "<urlsafe-b64(np.save(float32|float16 [nq, dim]))>", "top_k": K}
+ *                      -> {"scores": "<b64(npy f32 [nq, K])>", "indices": "<b64(npy i64 [nq, K])>"}   (server.py:76-91, io.py:17-32;
+ *                      reply bytes identical to the reference's FastSearchResponse as this package's Python shell writes it)
+ *   POST /raw-search?top_k=K   body = raw .npy bytes -> scores f32 [nq, K] || ids i64 [nq, K], shapes in x-nq / x-k
+ *   GET  /stats        batcher + front counters as JSON (not in the reference)
+ * are parsed, decoded, searched and encoded natively WHEN the request is the plain hot case (known keys, escape-free payload, version
+ * 1.0 C-order 2-D .npy of the index dimension, 1 <= top_k <= VODHIP_MAX_K, no subset filter).  Every other request - GET /, POST
+ * /search, subset filters, unknown fields, malformed payloads, out-of-range top_k - is handed unchanged to `fallback`, which answers
+ * through vodhip_http_reply_set (status, content type, payload, extra "name: value\r\n" header lines): validation and error mapping
+ * (422 / 500 + trace, models.py:43-79, server.py:89-91) live in ONE place, the host's.  `fallback` is called on the connection's
+ * thread; NULL answers 404.  listen_tcp binds every address `host` resolves to and returns the port (port 0 = pick one);
+ * start spawns the accept thread and returns; stop closes listeners and connections and waits for the connection threads. */
+typedef struct vodhip_http vodhip_http_t;
+typedef struct vodhip_http_reply vodhip_http_reply_t;
+typedef void (*vodhip_http_fallback_fn)(void* user, const char* method, const char* target, const uint8_t* body, int64_t n_body,
+                                        uint64_t client, vodhip_http_reply_t* reply);
+int vodhip_http_reply_set(vodhip_http_reply_t* reply, int status, const char* content_type, const uint8_t* payload, int64_t n,
+                          const char* extra_headers);
+int vodhip_http_create(vodhip_batcher_t* batcher, int64_t dim, vodhip_http_fallback_fn fallback, void* user, int64_t max_body_bytes,
+                       vodhip_http_t** out);
+int vodhip_http_listen_tcp(vodhip_http_t* http, const char* host, int port);
+int vodhip_http_listen_unix(vodhip_http_t* http, const char* path);
+int vodhip_http_start(vodhip_http_t* http);
+int vodhip_http_stop(vodhip_http_t* http);
+int vodhip_http_destroy(vodhip_http_t* http);
+int vodhip_http_get_stat(vodhip_http_t* http, const char* key, int64_t* out);  /* "requests_native", "requests_fallback", "connections", "open_connections" */
+
+/* The native front's wire pieces, exposed so that they can be checked byte for byte against NumPy / the Python codec without a
+ * socket or a GPU (tests/test_host_logic.py):
+ *   npy_header         np.lib.format.write_array_header_1_0 for a C-ordered [rows, cols] array; dtype VODHIP_F32 | VODHIP_F16 | 3 (int64);
+ *                      out >= 192 bytes; returns the header length (the data offset)
+ *   parse_npy          0 + dtype / rows / cols / data offset for a version-1.0 little-endian float32 | float16 C-order 2-D array
+ *                      whose data is complete; -1 for anything else (not an error: the host's reader takes over)
+ *   parse_fast_search  0 + the [begin, end) span of the "vectors" payload and top_k (default 3) for the plain hot document; 1 otherwise
+ *   fast_search_reply  the /fast-search reply body; out = NULL returns the size needed */
+int64_t vodhip_wire_npy_header(int dtype, int64_t rows, int64_t cols, uint8_t* out, int64_t cap);
+int vodhip_wire_parse_npy(const uint8_t* data, int64_t n, int* dtype, int64_t* rows, int64_t* cols, int64_t* data_offset);
+int vodhip_wire_parse_fast_search(const char* body, int64_t n, int64_t* vec_begin, int64_t* vec_end, int64_t* top_k);
+int64_t vodhip_wire_fast_search_reply(const float* scores, const int64_t* ids, int64_t nq, int k, char* out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif
