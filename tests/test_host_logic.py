@@ -290,10 +290,18 @@ def test_store_roundtrip_and_factory_protocol(tmp_path):
         factory.build_hip_mips_index(x, config={"factory": "IVF100,Flat"}, cache_dir=tmp_path)
 
 
-def test_micro_batcher_fuses_concurrent_requests_and_splits_results():
+def _native_error():
+    from vod_amd._native import NativeLibraryError
+
+    return NativeLibraryError
+
+
+def test_native_batcher_fuses_concurrent_requests_and_splits_results():
+    """`vodhip_batcher` with a callback engine (no GPU needed): four callers, held together by a fixed window, go out as fewer scans with
+    k = max(k_i); every caller gets its own rows and columns - identical to separate searches."""
     import threading
 
-    from vod_amd.search.server import MicroBatcher
+    from vod_amd.search.native import NativeBatcher
 
     rng = np.random.default_rng(2)
     x = rng.integers(-4, 5, size=(500, 8)).astype(np.float32)
@@ -308,13 +316,13 @@ def test_micro_batcher_fuses_concurrent_requests_and_splits_results():
             return super().search(q, k)
 
     eng = Counting(x)
-    mb = MicroBatcher(eng, max_wait_s=0.25)
+    mb = NativeBatcher(engine=eng, dim=8, window_us=250_000)
     qs = [rng.integers(-4, 5, size=(n, 8)).astype(np.float32) for n in (3, 1, 5, 2)]
     ks = [4, 9, 2, 9]
     out = [None] * 4
 
     def work(i):
-        out[i] = mb.search(qs[i], ks[i])
+        out[i] = mb.search(qs[i], ks[i], client=i + 1)
 
     threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
     for t in threads:
@@ -323,15 +331,20 @@ def test_micro_batcher_fuses_concurrent_requests_and_splits_results():
         t.join(timeout=20)
     assert Counting.calls < 4 and sum(n for n, _ in Counting.sizes) == 11      # fused into fewer scans
     assert all(k == 9 for n, k in Counting.sizes if n > 5) or Counting.calls >= 1
+    st = mb.stats()
+    assert st["requests"] == 4 and st["queries"] == 11 and st["batches"] == Counting.calls and st["fused_requests_max"] >= 2
     from oracle.flat_ip import flat_ip_topk
 
     for i in range(4):
         rs, ri = flat_ip_topk(qs[i], x, ks[i])
         np.testing.assert_array_equal(out[i][1], ri)                               # identical to separate searches
         np.testing.assert_array_equal(out[i][0], rs)
-    # errors reach every waiting caller
+    # argument errors come back as errors of THAT call; the engine's own exception type survives the callback
+    with pytest.raises(_native_error()):
+        mb.search(qs[0], 0)
     with pytest.raises(ValueError):
-        mb.search(np.zeros((1, 5), dtype=np.float32), 3)
+        mb.search(np.zeros((2, 5), np.float32), 3)
+    mb.close()
 
 
 # ---- zarr v2 vector store (the reference's tensorstore hand-off format, ts_factory.py:57-92) ----
@@ -498,10 +511,31 @@ def test_master_command_line_for_a_multi_gpu_group(tmp_path):
     assert cmd1[cmd1.index("--device") + 1] == "2" and "--devices" not in cmd1
 
 
-# ---- the asyncio HTTP shell (production) speaks the same contract over real sockets ------------------------------------------
-def _serve_in_thread(engine, micro_batch_wait_ms=0.0, uds=None):
+# ---- the HTTP shells - libvodhip's native front (production) and the asyncio server - speak the same contract over real sockets ---
+SHELLS = ["native", "asyncio"]
+
+
+def _serve_in_thread(engine, micro_batch_wait_ms=0.0, uds=None, shell="asyncio"):
     import asyncio
     import threading
+
+    if shell == "native":
+        from vod_amd.search.native import NativeHttpFront
+        from vod_amd.search.server import Endpoints
+
+        endpoints = Endpoints(engine, micro_batch_wait_ms)
+        batcher = endpoints._batcher_for(8)  # the test engines have no fixed dimension of their own: every store here is 8 wide
+        endpoints.batcher = batcher
+        front = NativeHttpFront(batcher, endpoints)
+        port = front.listen("127.0.0.1", 0, uds)
+        front.start()
+
+        def stop_native():
+            front.close()
+            endpoints.close()
+
+        stop_native.front = front
+        return port, stop_native
 
     from vod_amd.search import fastserver
     from vod_amd.search.server import Endpoints
@@ -537,7 +571,8 @@ def _serve_in_thread(engine, micro_batch_wait_ms=0.0, uds=None):
     return port, stop
 
 
-def test_asyncio_server_routes_wire_format_and_errors():
+@pytest.mark.parametrize("shell", SHELLS)
+def test_http_shell_routes_wire_format_and_errors(shell):
     import http.client
 
     import requests
@@ -545,7 +580,7 @@ def test_asyncio_server_routes_wire_format_and_errors():
     rng = np.random.default_rng(0)
     x = rng.integers(-4, 5, size=(50, 8)).astype(np.float32)
     q = rng.integers(-4, 5, size=(3, 8)).astype(np.float32)
-    port, stop = _serve_in_thread(_OracleEngine(x))
+    port, stop = _serve_in_thread(_OracleEngine(x), shell=shell)
     try:
         url = f"http://127.0.0.1:{port}"
         c = vclient.HipMipsClient("http://127.0.0.1", port)
@@ -601,11 +636,21 @@ def test_asyncio_server_routes_wire_format_and_errors():
             assert chunk, "connection closed before both pipelined replies arrived"
             got += chunk
         s.close()
+        # reply bytes: identical whichever shell (and, for the native front, whichever side - native codec or host fallback) wrote them
+        want = bytes(vio.json_body_with_arrays({"scores": scores[:, :4], "indices": ids[:, :4]}))
+        assert requests.post(url + "/fast-search", data=body).content == want
+        assert requests.post(url + "/fast-search", data=body[:-1] + b', "subset_ids": null}').content == want
+        if shell == "native":
+            st = requests.get(url + "/stats").json()
+            assert st["requests_native"] >= 20 and st["requests_fallback"] >= 8 and st["queries"] >= 60
+            # requests the native parser leaves to the host end up in the same batcher: counted once, answered identically
+            assert stop.front.get_stat("open_connections") >= 0
     finally:
         stop()
 
 
-def test_asyncio_server_on_a_unix_domain_socket(tmp_path):
+@pytest.mark.parametrize("shell", SHELLS)
+def test_http_shell_on_a_unix_domain_socket(tmp_path, shell):
     """the same routes on a Unix-domain socket (`--uds`); the client's searches go through it, `ping` keeps using TCP,
     a pickled client (DataLoader worker) re-opens its own connection, and the socket file is removed on shutdown."""
     import os
@@ -616,7 +661,7 @@ def test_asyncio_server_on_a_unix_domain_socket(tmp_path):
     x = rng.integers(-4, 5, size=(200, 8)).astype(np.float32)
     q = rng.integers(-4, 5, size=(5, 8)).astype(np.float32)
     path = str(tmp_path / "vodhip.sock")
-    port, stop = _serve_in_thread(_OracleEngine(x), uds=path)
+    port, stop = _serve_in_thread(_OracleEngine(x), uds=path, shell=shell)
     try:
         assert os.path.exists(path)
         rs, ri = flat_ip_topk(q, x, 9)
@@ -637,8 +682,9 @@ def test_asyncio_server_on_a_unix_domain_socket(tmp_path):
     assert not os.path.exists(path)
 
 
-def test_asyncio_server_fuses_concurrent_clients():
-    """32 concurrent clients with micro-batching on: every caller gets its own exact rows, and the engine saw fewer, larger batches."""
+@pytest.mark.parametrize("shell", SHELLS)
+def test_http_shell_fuses_concurrent_clients(shell):
+    """32 concurrent clients: every caller gets its own exact rows, and the engine saw fewer, larger batches."""
     import concurrent.futures
 
     from oracle.flat_ip import flat_ip_topk
@@ -653,7 +699,8 @@ def test_asyncio_server_fuses_concurrent_clients():
             Counting.calls += 1
             return super().search(q, k)
 
-    port, stop = _serve_in_thread(Counting(x), micro_batch_wait_ms=20.0)
+    Counting.calls = 0
+    port, stop = _serve_in_thread(Counting(x), micro_batch_wait_ms=20.0, shell=shell)
     try:
         qs = [rng.integers(-4, 5, size=(1 + i % 5, 8)).astype(np.float32) for i in range(32)]
 
@@ -707,14 +754,14 @@ def test_usable_cpus_honours_affinity_and_quota(monkeypatch):
         torch.set_num_threads(before)
 
 
-def test_micro_batcher_lanes_gather_the_next_batch_while_the_engine_is_busy():
-    """Two collector lanes: requests that arrive while a batch is on the (slow) engine end up in ONE following batch, the engine is
-    never entered twice at a time, and a request of another dimension fails alone."""
+def test_native_batcher_gathers_the_next_batch_while_the_engine_is_busy():
+    """Batch-while-busy, no window: the first request runs at once; requests that arrive while it is on the (slow) engine end up in ONE
+    following batch; the engine is never entered twice at a time; a failing batch fails its own callers only."""
     import threading
     import time
 
     from oracle.flat_ip import flat_ip_topk
-    from vod_amd.search.server import MicroBatcher
+    from vod_amd.search.native import NativeBatcher
 
     rng = np.random.default_rng(3)
     x = rng.integers(-4, 5, size=(300, 8)).astype(np.float32)
@@ -730,38 +777,185 @@ def test_micro_batcher_lanes_gather_the_next_batch_while_the_engine_is_busy():
             self.sizes.append(len(q))
             time.sleep(0.15)
             try:
-                if q.shape[1] != 8:
-                    raise ValueError("query dimension")
+                if k == 7:
+                    raise KeyError("injected engine failure")
                 return super().search(q, k)
             finally:
                 self.inside -= 1
 
     eng = Slow(x)
-    mb = MicroBatcher(eng, max_wait_s=0.005)
+    mb = NativeBatcher(engine=eng, dim=8)
     qs = [rng.integers(-4, 5, size=(2, 8)).astype(np.float32) for _ in range(9)]
     out, errs = [None] * 9, []
 
     def work(i):
-        out[i] = mb.search(qs[i], 5)
-
-    def bad():
-        try:
-            mb.search(np.zeros((1, 5), dtype=np.float32), 3)
-        except ValueError as e:
-            errs.append(e)
+        out[i] = mb.search(qs[i], 5, client=100 + i)
 
     first = threading.Thread(target=work, args=(0,))
+    t0 = time.monotonic()
     first.start()
-    time.sleep(0.05)  # request 0 is on the engine now; the other eight (and the malformed one) arrive during its 150 ms
-    rest = [threading.Thread(target=work, args=(i,)) for i in range(1, 9)] + [threading.Thread(target=bad)]
+    time.sleep(0.05)  # request 0 is on the engine now; the other eight arrive during its 150 ms
+    rest = [threading.Thread(target=work, args=(i,)) for i in range(1, 9)]
     for t in rest:
         t.start()
     for t in [first] + rest:
         t.join(timeout=30)
+    assert time.monotonic() - t0 < 0.15 * 2 + 0.12    # request 0 did not wait for anybody, the eight others shared ONE scan
     assert not eng.overlap
-    assert eng.sizes[0] == 2 and 16 in eng.sizes, eng.sizes       # the eight waiting requests went out as one batch of 16 queries
-    assert len(errs) == 1
+    assert eng.sizes == [2, 16], eng.sizes               # the eight waiting requests went out as one batch of 16 queries
     for i in range(9):
         rs, ri = flat_ip_topk(qs[i], x, 5)
         np.testing.assert_array_equal(out[i][1], ri)
         np.testing.assert_array_equal(out[i][0], rs)
+
+    def bad():
+        try:
+            mb.search(qs[0], 7)
+        except KeyError as e:
+            errs.append(e)
+
+    bt = threading.Thread(target=bad)
+    bt.start()
+    bt.join(timeout=30)
+    assert len(errs) == 1
+    s1, i1 = mb.search(qs[1], 5)                        # the batcher keeps serving after a failed batch
+    np.testing.assert_array_equal(i1, flat_ip_topk(qs[1], x, 5)[1])
+    mb.close()
+
+
+def test_native_batcher_waits_for_expected_company_only():
+    """The grace rule: with several recently active clients an idle engine waits (a bounded moment) for the ones still missing, so closed-loop
+    clients stay in ONE batch instead of falling into two alternating groups; a lone client never waits."""
+    import threading
+    import time
+
+    from vod_amd.search.native import NativeBatcher
+
+    rng = np.random.default_rng(4)
+    x = rng.integers(-4, 5, size=(200, 8)).astype(np.float32)
+
+    class Timed(_OracleEngine):
+        def __init__(self, rows):
+            super().__init__(rows)
+            self.sizes = []
+
+        def search(self, q, k):
+            self.sizes.append(len(q))
+            time.sleep(0.04)  # a "scan" of 40 ms
+            return super().search(q, k)
+
+    eng = Timed(x)
+    mb = NativeBatcher(engine=eng, dim=8, grace_us=30_000, grace_pct=60)   # grace = min(30 ms, 60 % of the measured scan) = 24 ms
+    q = rng.integers(-4, 5, size=(2, 8)).astype(np.float32)
+    t0 = time.monotonic()
+    for _ in range(3):
+        mb.search(q, 3, client=1)                       # a lone client: three scans, no waiting (also measures the scan)
+    lone = (time.monotonic() - t0) / 3
+    assert lone < 0.04 + 0.015, lone
+    assert mb.get_stat("flat_scan_ns") > 30e6
+
+    # four closed-loop clients whose turn-around (5-15 ms) is shorter than the grace: every round must be ONE batch of all four
+    eng.sizes.clear()
+    rounds = 5
+
+    def loop(c):
+        for _ in range(rounds):
+            mb.search(q, 3, client=10 + c)
+            time.sleep(0.005 + 0.003 * c)
+
+    threads = [threading.Thread(target=loop, args=(c,)) for c in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+    full = sum(1 for n in eng.sizes if n == 8)
+    assert full >= rounds - 1, eng.sizes                # (the very first round may split before every client is known)
+    assert mb.get_stat("grace_waits") >= rounds - 1
+    # a client that went away is not waited for once it is forgotten
+    for c in range(1, 4):
+        mb.forget_client(10 + c)
+    t0 = time.monotonic()
+    mb.search(q, 3, client=10)
+    assert time.monotonic() - t0 < 0.04 + 0.015
+    mb.close()
+
+
+def _np_header(arr):
+    import io as _io
+
+    head = _io.BytesIO()
+    np.lib.format.write_array_header_1_0(head, np.lib.format.header_data_from_array_1_0(arr))
+    return head.getvalue()
+
+
+def test_native_wire_pieces_match_numpy_and_the_python_codec():
+    """The native front's codec against NumPy and `vod_amd.io`, byte for byte, without a socket: the `.npy` header it writes, the
+    headers it accepts, the /fast-search document it takes (and the ones it leaves to the host), the reply body it builds."""
+    import ctypes
+    import json
+
+    from vod_amd import _native
+    from vod_amd import io as vio
+
+    lib = _native.load_library()
+    buf = (ctypes.c_uint8 * 256)()
+    rng = np.random.default_rng(9)
+    for rows, cols in [(1, 1), (32, 100), (64, 768), (1024, 768), (7, 2048), (99999, 3), (123456789, 12), (5, 10 ** 6), (10 ** 11, 1)]:
+        for code, dt in ((2, np.float32), (0, np.float16), (3, np.int64)):
+            n = lib.vodhip_wire_npy_header(code, rows, cols, buf, 256)
+            want = _np_header(np.lib.stride_tricks.as_strided(np.zeros(1, dt), shape=(rows, cols), strides=(0, 0)))
+            assert bytes(buf[:n]) == want, (rows, cols, dt)
+    # parse: what NumPy writes for 2-D float32 / float16 is accepted with the right geometry; other layouts are left to the host
+    dt_c, r_c, c_c, off_c = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+
+    def parse(raw: bytes):
+        rc = lib.vodhip_wire_parse_npy(raw, len(raw), ctypes.byref(dt_c), ctypes.byref(r_c), ctypes.byref(c_c), ctypes.byref(off_c))
+        return rc, dt_c.value, r_c.value, c_c.value, off_c.value
+
+    import io as _io
+
+    for arr in (rng.normal(size=(3, 8)).astype(np.float32), rng.normal(size=(17, 5)).astype(np.float16), np.zeros((0, 4), np.float32)):
+        f = _io.BytesIO()
+        np.save(f, arr)
+        raw = f.getvalue()
+        rc, dt, r, c, off = parse(raw)
+        assert rc == 0 and (r, c) == arr.shape and dt == (2 if arr.dtype == np.float32 else 0)
+        assert np.array_equal(np.frombuffer(raw, arr.dtype, offset=off).reshape(arr.shape), arr)
+        assert parse(raw[:-1])[0] == -1 if arr.size else True                   # truncated data
+    for arr in (np.zeros((3, 8), np.float64), np.zeros(5, np.float32), np.zeros((2, 3, 4), np.float32), np.asfortranarray(np.ones((3, 4), np.float32)),
+                np.zeros((3, 4), ">f4"), np.zeros((3, 4), np.int32)):
+        f = _io.BytesIO()
+        np.save(f, arr)
+        assert parse(f.getvalue())[0] == -1, arr.dtype
+    assert parse(b"not an npy file at all")[0] == -1
+    # the /fast-search document
+    vb, ve, tk = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+
+    def doc(body: bytes):
+        rc = lib.vodhip_wire_parse_fast_search(body, len(body), ctypes.byref(vb), ctypes.byref(ve), ctypes.byref(tk))
+        return rc, body[vb.value : ve.value] if rc == 0 else None, tk.value
+
+    arr = rng.normal(size=(4, 8)).astype(np.float32)
+    body = bytes(vio.json_body_with_arrays({"vectors": arr}, {"top_k": 7}))             # what `HipMipsClient` sends
+    rc, payload, k = doc(body)
+    assert rc == 0 and k == 7 and np.array_equal(vio.deserialize_np_array(payload), arr)
+    ref_body = json.dumps({"vectors": vio.serialize_np_array(arr), "top_k": 12}).encode()  # what the reference's client sends (requests json=)
+    rc, payload, k = doc(ref_body)
+    assert rc == 0 and k == 12 and payload == vio.serialize_np_array(arr).encode()
+    assert doc(b' {"top_k":5 ,\n "vectors" : "QUJD" , "subset_ids": null } ')[::2] == (0, 5)
+    assert doc(b'{"vectors": "QUJD"}')[::2] == (0, 3)                                    # the model's default (models.py)
+    for other in (b'{"vectors": "QUJD", "top_k": 5, "extra": 1}', b'{"vectors": "QU\\u0041", "top_k": 5}', b'{"vectors": "QUJD", "top_k": 5.0}',
+                  b'{"vectors": "QUJD", "top_k": "5"}', b'{"vectors": "QUJD", "subset_ids": [["a"]]}', b'{"top_k": 5}', b'[1, 2]',
+                  b'{"vectors": "QUJD", "vectors": "QUJD"}', b'{"vectors": "QUJD", "top_k": 5} trailing', b'{"vectors": ["QUJD"]}', b'{"vectors": "QUJD"', b''):
+        assert doc(other)[0] == 1, other
+    # the reply body = the Python shell's, byte for byte (and so the golden wire strings of tests/golden/io_codec.json)
+    for nq, k in [(1, 1), (3, 10), (32, 100), (64, 7), (5, 2048)]:
+        scores = rng.normal(size=(nq, k)).astype(np.float32)
+        scores[0, -1] = -np.inf
+        ids = rng.integers(-1, 10 ** 9, size=(nq, k)).astype(np.int64)
+        want = bytes(vio.json_body_with_arrays({"scores": scores, "indices": ids}))
+        need = lib.vodhip_wire_fast_search_reply(None, None, nq, k, None, 0)
+        assert need == len(want)
+        out = ctypes.create_string_buffer(need)
+        assert lib.vodhip_wire_fast_search_reply(scores.ctypes.data, ids.ctypes.data, nq, k, out, need) == need
+        assert out.raw == want

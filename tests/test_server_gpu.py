@@ -358,9 +358,9 @@ def test_multi_gpu_group_server_eight_workers_sharing_the_gpu(tmp_path):
 
 
 def test_engine_orders_concurrent_callers_itself(tmp_path):
-    """`HipEngine.search` from many threads at once: every caller takes a ticket at enqueue time (up to three searches are in flight on
-    the one stream; their result rows are written straight into pinned host buffers) and completes in FIFO order - each must get
-    ITS answer, subset requests and a malformed one included."""
+    """`HipEngine.search` from many threads at once: the library's batcher fuses the callers into shared scans (up to two batches in
+    flight on its stream; result rows written straight into device-visible host memory) - each must get ITS answer, subset requests
+    (never fused) and a malformed one included."""
     import concurrent.futures
 
     from oracle.flat_ip import flat_ip_topk, topk_desc_tiebreak
@@ -391,7 +391,7 @@ def test_engine_orders_concurrent_callers_itself(tmp_path):
         results = [f.result(timeout=120) for f in futs]
         with pytest.raises(Exception, match="out of range"):
             bad.result(timeout=120)
-    assert engine.in_flight() == 0
+    assert engine.batcher.get_stat("in_flight") == 0 and engine.batcher.get_stat("pending") == 0
     for (q, k, sub), (s, i) in zip(jobs, results):
         if sub is None:
             rs, ri = flat_ip_topk(q, x, k)
@@ -401,6 +401,42 @@ def test_engine_orders_concurrent_callers_itself(tmp_path):
             rs, ri = topk_desc_tiebreak(full, k)
         np.testing.assert_array_equal(i, ri)
         np.testing.assert_array_equal(s, rs)
+
+
+def test_concurrent_callers_while_every_search_overflows(tmp_path):
+    """Round-3 advisor (high): `finish` of search i ran its recovery passes on the shared workspace while another thread enqueued search
+    i + 1 on the same handle.  Now the handle carries a mutex and ONE completion thread finishes: many threads, candidate lists of 256
+    entries and a store whose top scores are tied thousands of times (every batch overflows and recovers) - results must equal the
+    serial answers, which equal the oracle."""
+    import concurrent.futures
+
+    from oracle.flat_ip import flat_ip_topk
+    from vod_amd import store
+    from vod_amd.search.server import HipEngine
+
+    rng = np.random.default_rng(77)
+    n, d = 60_000, 64
+    x = rng.integers(-3, 4, size=(n, d)).astype(np.float32)
+    x[n // 2 :] = x[n // 2]  # 30 k copies of one row: every query ties far more rows than a candidate list holds
+    store.save_vectors(tmp_path / "v.npy", x, dtype=np.float16)
+    engine = HipEngine(str(tmp_path / "v.npy"))
+    engine.index.set_param("cand_cap", 256)
+    jobs = [(np.sign(x[n // 2])[None, :] * rng.integers(1, 4, size=(int(rng.integers(1, 40)), d))).astype(np.float32) for _ in range(48)]
+    ks = [int(rng.choice([5, 50, 200])) for _ in jobs]
+    with concurrent.futures.ThreadPoolExecutor(16) as pool:
+        results = list(pool.map(lambda a: engine.search(a[0], a[1]), zip(jobs, ks)))
+    assert engine.index.get_stat("last_safe_reruns") >= 0
+    recovered = 0
+    for q, k, (s, i) in zip(jobs, ks, results):
+        rs, ri = flat_ip_topk(q, x, k)
+        np.testing.assert_array_equal(i, ri)
+        np.testing.assert_array_equal(s, rs)
+    # the same jobs one by one: the recovery path really ran
+    for q, k in list(zip(jobs, ks))[:6]:
+        engine.search(q, k)
+        recovered += engine.index.get_stat("last_safe_reruns") > 0
+    assert recovered >= 1
+    engine.close()
 
 
 def test_master_with_a_unix_domain_socket(tmp_path):

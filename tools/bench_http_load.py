@@ -7,7 +7,11 @@ P concurrent client PROCESSES (pickled `HipMipsClient`s, like DataLoader workers
 Per cell: aggregate queries/s, request latency p50 / p99, and the ratio to the device-resident rate of ONE fused batch of
 P * nq queries (what a perfect boundary in front of the same kernels would deliver).
 
-    python tools/bench_http_load.py [--rows 10000000] [--dim 768] [--k 100] [--seconds 2.5] [--out profiles/r03_http_load.json]
+Round 4: the server's DEFAULT settings are what is measured (`--http native`: libvodhip's front + batch-while-busy request fusion, no
+wait window); `--http asyncio` / `--micro-batch-ms` reproduce round 3's shells for an A/B.  Per cell the server's own counters
+(GET /stats) give the mean fused batch and the share of the cell the engine sat idle.
+
+    python tools/bench_http_load.py [--rows 10000000] [--dim 768] [--k 100] [--seconds 2.5] [--out profiles/r04_http_load.json]
 """
 import argparse
 import json
@@ -67,8 +71,10 @@ def main():
     ap.add_argument("--seconds", type=float, default=2.5)
     ap.add_argument("--clients", type=int, nargs="+", default=[1, 8, 32])
     ap.add_argument("--nq", type=int, nargs="+", default=[32, 64, 256])
-    ap.add_argument("--micro-batch-ms", type=float, nargs="+", default=[0.0, 1.0])
-    ap.add_argument("--http", default="asyncio", choices=["asyncio", "uvicorn"])
+    ap.add_argument("--micro-batch-ms", type=float, nargs="+", default=[0.0])
+    ap.add_argument("--http", default="native", choices=["native", "asyncio", "uvicorn"])
+    ap.add_argument("--routes", nargs="+", default=["fast", "raw"], choices=["fast", "raw"])
+    ap.add_argument("--batcher-param", action="append", default=[], metavar="KEY=VALUE")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import torch
@@ -79,8 +85,11 @@ def main():
 
     os.chdir(tempfile.mkdtemp())
     spec = f"synthetic:{a.rows}x{a.dim}:7"
+    from vod_amd.hostcpu import usable_cpus
+
     out = {"store": f"{a.rows} x {a.dim} fp16 (synthetic N(0,1), generated on the device)", "k": a.k, "http": a.http, "seconds_per_cell": a.seconds,
-           "host_cpus": len(os.sched_getaffinity(0)), "device_resident": {}, "cells": []}
+           "host_cpus_visible": len(os.sched_getaffinity(0)), "host_cpus_usable": usable_cpus(), "batcher_params": a.batcher_param,
+           "note": "client processes and the server share the usable host CPUs", "device_resident": {}, "cells": []}
     # device-resident reference: the same store in this process, one fused batch of B queries resident in HBM
     dev = torch.device("cuda", 0)
     ix = HipFlatIndex(a.dim, a.rows, dtype=torch.float16, device=0)
@@ -106,12 +115,30 @@ def main():
     del ix
     torch.cuda.empty_cache()
     for mb in a.micro_batch_ms:
-        with HipMipsMaster(spec, port=-1, logging_level="warning", micro_batch_wait_ms=mb, http=a.http) as master:
-            for binary in (False, True):
+        bparams = {kv.partition("=")[0]: int(kv.partition("=")[2]) for kv in a.batcher_param}
+        with HipMipsMaster(spec, port=-1, logging_level="warning", micro_batch_wait_ms=mb, http=a.http, batcher_params=bparams) as master:
+            import requests
+
+            def stats():
+                try:
+                    return requests.get(f"{master.host}:{master.port}/stats", timeout=10).json()
+                except Exception:  # noqa: BLE001
+                    return {}
+
+            for binary in [r == "raw" for r in a.routes]:
                 client = HipMipsClient(host=master.host, port=master.port, binary=binary)
                 for P in a.clients:
                     for nq in a.nq:
+                        s0 = stats()
                         cell = run_cell(client, P, nq, a.dim, a.k, a.seconds)
+                        s1 = stats()
+                        if s0 and s1 and s1.get("batches", 0) > s0.get("batches", 0):
+                            nb = s1["batches"] - s0["batches"]
+                            busy, idle = s1["busy_ns"] - s0["busy_ns"], s1["idle_ns"] - s0["idle_ns"]
+                            cell["server"] = {"batches": nb, "mean_queries_per_batch": (s1["queries"] - s0["queries"]) / nb,
+                                              "mean_requests_per_batch": (s1["requests"] - s0["requests"]) / nb,
+                                              "engine_idle_fraction": idle / max(1, busy + idle), "grace_waits": s1["grace_waits"] - s0["grace_waits"],
+                                              "grace_expired": s1["grace_expired"] - s0["grace_expired"]}
                         fused = str(min(2048, P * nq))
                         cell.update(route="/raw-search" if binary else "/fast-search", micro_batch_wait_ms=mb,
                                     device_resident_qps_at_fused_batch=out["device_resident"][fused]["qps"],

@@ -95,7 +95,30 @@ SIGNATURES: dict[str, tuple] = {
     "vodhip_gather_by_id": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vodhip_b64url_encode": (_i64, [_vp, _i64, _vp, _i64, _vp]),
     "vodhip_b64url_decode": (_i64, [_vp, _i64, _vp]),
+    # H6 serving (vodhip_serve.hip)
+    "vodhip_batcher_create": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _c.POINTER(_vp)]),
+    "vodhip_batcher_destroy": (_i32, [_vp]),
+    "vodhip_batcher_set_param": (_i32, [_vp, _c.c_char_p, _i64]),
+    "vodhip_batcher_get_stat": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i64)]),
+    "vodhip_batcher_search": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _i32, _c.c_uint64, _vp, _vp]),
+    "vodhip_batcher_forget_client": (_i32, [_vp, _c.c_uint64]),
+    "vodhip_http_reply_set": (_i32, [_vp, _i32, _c.c_char_p, _vp, _i64, _c.c_char_p]),
+    "vodhip_http_create": (_i32, [_vp, _i64, _vp, _vp, _i64, _c.POINTER(_vp)]),
+    "vodhip_http_listen_tcp": (_i32, [_vp, _c.c_char_p, _i32]),
+    "vodhip_http_listen_unix": (_i32, [_vp, _c.c_char_p]),
+    "vodhip_http_start": (_i32, [_vp]),
+    "vodhip_http_stop": (_i32, [_vp]),
+    "vodhip_http_destroy": (_i32, [_vp]),
+    "vodhip_http_get_stat": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i64)]),
+    "vodhip_wire_npy_header": (_i64, [_i32, _i64, _i64, _vp, _i64]),
+    "vodhip_wire_parse_npy": (_i32, [_vp, _i64, _c.POINTER(_i32), _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64)]),
+    "vodhip_wire_parse_fast_search": (_i32, [_vp, _i64, _c.POINTER(_i64), _c.POINTER(_i64), _c.POINTER(_i64)]),
+    "vodhip_wire_fast_search_reply": (_i64, [_vp, _vp, _i64, _i32, _vp, _i64]),
 }
+
+# callback types of the serving layer (include/vodhip.h: vodhip_search_fn, vodhip_http_fallback_fn)
+SEARCH_FN = _c.CFUNCTYPE(_i32, _vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp)
+HTTP_FALLBACK_FN = _c.CFUNCTYPE(None, _vp, _c.c_char_p, _c.c_char_p, _vp, _i64, _c.c_uint64, _vp)
 
 
 class CollateArgs(ctypes.Structure):

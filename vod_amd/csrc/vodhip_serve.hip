@@ -873,7 +873,7 @@ int vodhip_wire_parse_fast_search(const char* body, int64_t n, int64_t* vec_begi
 }
 
 int64_t vodhip_wire_fast_search_reply(const float* scores, const int64_t* ids, int64_t nq, int k, char* out, int64_t cap) {
-    if (nq < 0 || k < 0 || (nq * k > 0 && (!scores || !ids))) return sfail("invalid arguments");
+    if (nq < 0 || k < 0 || (out && nq * k > 0 && (!scores || !ids))) return sfail("invalid arguments");
     return fast_search_reply(scores, ids, nq, k, out, cap);
 }
 

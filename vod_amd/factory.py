@@ -35,6 +35,12 @@ class HipMipsFactoryConfig:
     uds: bool = False               # also serve on a Unix-domain socket and hand its path to the clients (single-host jobs)
     group_backend: str = "nccl"     # with `devices`: "nccl" / "gloo" = one worker process per GPU on a process group; "node" = ONE
                                     # server process drives every GPU (vodhip_node_index: the reference server's own shape)
+    http: str = "native"            # the server's HTTP shell: libvodhip's native front | "asyncio" | "uvicorn"
+    # Request fusion is ON by default (the DataLoader workers of every trainer rank each send their own small batch:
+    # src/vod_dataloaders/realm_dataloader.py:92-118): concurrent requests share corpus scans, a lone request never waits.
+    micro_batch_wait_ms: float = 0.0  # > 0: every batch additionally waits this long for company (a fixed window; not needed)
+    batcher_params: tuple[tuple[str, int], ...] = ()  # vodhip_batcher_set_param pairs, e.g. (("grace_us", 0),) = never wait for
+                                    # expected company, (("max_queries", 1024),) = smaller fused batches
 
     def fingerprint(self) -> dict:
         return {"factory": self.factory, "metric": self.metric, "dtype": self.dtype}
@@ -111,4 +117,7 @@ def build_hip_mips_index(
         devices=None if devices is None else list(devices),
         group_backend=config.group_backend,
         uds=config.uds,
+        http=config.http,
+        micro_batch_wait_ms=config.micro_batch_wait_ms,
+        batcher_params=dict(config.batcher_params),
     )

@@ -247,8 +247,9 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         devices: None | list[int] = None,
         serve_on_gpu: bool = True,  # noqa: ARG002 - accepted for call-site compatibility: this engine only exists on the GPU
         group_backend: str = "nccl",  # with `devices`: "nccl" (RCCL, one GPU per worker), "gloo" (host-staged; workers may share a GPU) or "node" (ONE server process drives every GPU: vodhip_node_index, no workers)
-        micro_batch_wait_ms: float = 0.0,  # > 0: the server fuses requests that arrive within this window into one corpus scan
-        http: str = "asyncio",  # the server's HTTP shell: "asyncio" (in-tree, default) or "uvicorn" (FastAPI)
+        micro_batch_wait_ms: float = 0.0,  # > 0: every batch additionally waits this long for company (concurrent requests are fused by default)
+        http: str = "native",  # the server's HTTP shell: "native" (libvodhip's front, default), "asyncio" (in-tree Python) or "uvicorn" (FastAPI)
+        batcher_params: None | dict[str, int] = None,  # vodhip_batcher_set_param on the server (max_queries, grace_us, grace_pct, flat_queries, depth)
         uds: bool | str = False,  # also listen on a Unix-domain socket (True = a path under the temp dir); `get_client()` then uses it
     ):
         super().__init__(skip_setup=skip_setup, free_resources=free_resources)
@@ -265,6 +266,7 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         self.group_backend = group_backend
         self.micro_batch_wait_ms = float(micro_batch_wait_ms)
         self.http = http
+        self.batcher_params = dict(batcher_params or {})
         if uds is True:
             import tempfile
 
@@ -292,6 +294,7 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
             "--http", self.http,
             *(["--micro-batch-wait-ms", str(self.micro_batch_wait_ms)] if self.micro_batch_wait_ms > 0 else []),
             *(["--uds", str(self.uds)] if self.uds else []),
+            *[a for k, v in self.batcher_params.items() for a in ("--batcher-param", f"{k}={int(v)}")],
             *(["--devices", ",".join(map(str, self.devices)), "--group-backend", self.group_backend]
               if self.devices is not None else ["--device", str(self.device)]),
         ]

@@ -6,7 +6,7 @@ joined, then copied again by starlette - several milliseconds before the handler
 socket reads land DIRECTLY in one preallocated body buffer (`get_buffer` / `buffer_updated`: no per-chunk objects), the
 handler decodes the base64 text in place and writes the reply's base64 text straight into the response buffer
 (`vod_amd.io.json_body_with_arrays`).  Handlers run on a thread pool (the codec releases the GIL inside libvodhip), so
-concurrent clients are accepted - and fused by the `MicroBatcher` - while another request is being decoded.
+concurrent clients are accepted - and fused by the library's batcher - while another request is being decoded.
 
 Same contract as the FastAPI app (`vod_amd.search.server.create_app`, kept for ASGI hosting and tests): both are thin shells
 around `server.Endpoints`, which owns routes, validation and error mapping (422 for a malformed document, 500 with the trace
@@ -121,7 +121,7 @@ class _Connection(asyncio.BufferedProtocol):
         self.busy = True
         self.transport.pause_reading()  # a pipelined request stays in the socket (and in what `head` already holds) until this one is answered
         loop = asyncio.get_running_loop()
-        fut = loop.run_in_executor(self.pool, self.endpoints.handle, method, path, query, body)
+        fut = loop.run_in_executor(self.pool, self.endpoints.handle, method, path, query, body, id(self))  # the connection = the client tag
         fut.add_done_callback(lambda f: self._reply(f, keep))
 
     def _reply(self, fut, keep: bool) -> None:
@@ -156,6 +156,9 @@ class _Connection(asyncio.BufferedProtocol):
 
     def connection_lost(self, exc) -> None:
         self.transport = None
+        batcher = getattr(self.endpoints, "batcher", None)
+        if batcher is not None:
+            batcher.forget_client(id(self))  # nobody should wait for this client's next request
 
 
 async def serve(endpoints, host: str, port: int, workers: int = 64, ready: "asyncio.Event | None" = None, stop: "asyncio.Event | None" = None,

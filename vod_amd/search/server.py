@@ -53,185 +53,108 @@ class FastSearchResponse(pydantic.BaseModel):
     indices: str
 
 
-class _NoLock:
-    """Stands in for the engine lock when the engine serialises its callers itself."""
+class _CallbackEngine:
+    """What the batcher's callback engine calls: `search(float32 [nq, d], k)` and - for subset-filtered batches - the engine's
+    `search_encoded(q, k, subset=int32 [nq, S])` (the labels were encoded by `engine.encode_subset` before they entered the batcher)."""
 
-    def acquire(self, blocking: bool = True) -> bool:  # noqa: ARG002
-        return True
-
-    def release(self) -> None:
-        pass
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc) -> None:
-        pass
-
-
-class MicroBatcher:
-    """Fuse concurrent requests into one GPU batch.
-
-    Every dataloader worker of every trainer rank sends its own small batch (the reference serialises them on one
-    uvicorn worker, server.py:69,78,98).  A brute-force scan reads the whole corpus per batch whatever its size, so
-    answering R waiting requests with ONE scan costs about as much as answering one.  Requests wait at most
-    `max_wait_s` for company; the fused batch runs with k = max(k_i) and each caller gets its own rows and columns
-    (a top-k prefix of a top-k' list is the top-k, so results are identical to separate searches).
-    """
-
-    def __init__(self, engine, max_wait_s: float = 0.001, max_queries: int = 2048, lock: "threading.Lock | None" = None, lanes: int = 2):
-        import queue
-
+    def __init__(self, engine):
         self.engine = engine
-        # the engine (one index handle, one stream, shared workspace) is not re-entrant: every call into it - the fused
-        # batches here and the subset / serialised searches of `create_app` - runs under ONE lock
-        self.lock = lock or threading.Lock()
-        self.max_wait_s = max_wait_s
-        self.max_queries = max_queries
-        self._q: "queue.Queue" = queue.Queue()
-        # TWO collector threads ("lanes"): while one lane's batch is on the GPU the other gathers the requests that arrive meanwhile -
-        # already copied into its fused buffer - and searches the moment the engine is free.  With one lane the GPU idled while the
-        # batch was fused, split and answered and while the (closed-loop) clients turned around: 32 dataloader workers x 64 queries
-        # reached 69 % of the device-resident rate; the clients now fall into two alternating groups.
-        self._threads = [threading.Thread(target=self._run, daemon=True, name=f"vodhip-microbatch-{i}") for i in range(max(1, lanes))]
-        for t in self._threads:
-            t.start()
 
-    def search(self, query_vec: np.ndarray, top_k: int) -> tuple[np.ndarray, np.ndarray]:
-        import concurrent.futures
-
-        fut: "concurrent.futures.Future" = concurrent.futures.Future()
-        self._q.put((query_vec, top_k, fut))
-        return fut.result()
-
-    def _run(self) -> None:
-        import queue
-        import time
-
-        fused = None  # this lane's [max_queries, dim] float32 buffer: requests are copied in as they arrive
-        while True:
-            batch = [self._q.get()]
-            deadline = time.monotonic() + self.max_wait_s
-            n = 0
-            held = False
-            try:
-                first = np.asarray(batch[0][0])
-                dim = first.shape[1]
-                if fused is None or fused.shape[1] != dim or fused.shape[0] < max(self.max_queries, len(first)):
-                    fused = np.empty((max(self.max_queries, len(first)), dim), dtype=np.float32)
-                fused[: len(first)] = first
-                n = len(first)
-                # company: until the window closes AND the engine is free (a busy engine means waiting costs nothing), or the batch is full
-                while n < self.max_queries:
-                    remaining = deadline - time.monotonic()
-                    if remaining <= 0:
-                        # a pipelined engine is "free" while fewer than two batches are on it: the next one is enqueued BEHIND the
-                        # running one (no gap on the GPU) and this lane keeps collecting only when two are already queued
-                        busy = getattr(self.engine, "pipelined", False) and self.engine.in_flight() >= 2
-                        if not busy and self.lock.acquire(blocking=False):
-                            held = True
-                            break
-                        remaining = 0.0005
-                    try:
-                        item = self._q.get(timeout=remaining)
-                    except queue.Empty:
-                        continue
-                    vec = np.asarray(item[0])
-                    if vec.shape[1] != dim or n + len(vec) > fused.shape[0]:
-                        self._q.put(item)  # another dimension (its own error / batch) or no room: the next batch takes it
-                        if vec.shape[1] != dim:
-                            time.sleep(0)  # let the other lane pick it up
-                        if not held:
-                            self.lock.acquire()
-                            held = True
-                        break
-                    fused[n : n + len(vec)] = vec
-                    n += len(vec)
-                    batch.append(item)
-                if not held:
-                    self.lock.acquire()
-                    held = True
-                k_max = max(b[1] for b in batch)
-                try:
-                    scores, indices = self.engine.search(fused[:n], k_max)
-                finally:
-                    self.lock.release()
-                    held = False
-                lo = 0
-                for vec, k, fut in batch:
-                    hi = lo + len(vec)
-                    fut.set_result((np.asarray(scores[lo:hi, :k]), np.asarray(indices[lo:hi, :k])))
-                    lo = hi
-            except Exception as exc:  # every waiting caller gets the error (HTTP 500 with the trace)
-                if held:
-                    self.lock.release()
-                for _, _, fut in batch:
-                    if not fut.done():
-                        fut.set_exception(exc)
+    def search(self, q: np.ndarray, k: int, subset: np.ndarray | None = None):
+        if subset is None:
+            return self.engine.search(q, k)
+        if not hasattr(self.engine, "search_encoded"):
+            raise ValueError("this engine cannot filter by subset id")
+        return self.engine.search_encoded(q, k, subset)
 
 
 class Endpoints:
     """Routes, validation and error mapping of the search service, independent of the HTTP shell around them.
 
-    `handle(method, path, query, body)` -> (status, content type, payload bytes-like, extra headers).  Both shells - the asyncio
-    server of `vod_amd.search.fastserver` (production) and the FastAPI app of `create_app` (ASGI hosting, tests) - answer with
-    exactly what this returns, so the contract is the reference's whatever carries it:
+    `handle(method, path, query, body)` -> (status, content type, payload bytes-like, extra headers).  Every shell - libvodhip's native
+    front (production: it answers the plain hot requests itself and hands everything else here), the asyncio server of
+    `vod_amd.search.fastserver` and the FastAPI app of `create_app` (ASGI hosting, tests) - answers with exactly what this returns, so
+    the contract is the reference's whatever carries it:
       422 + `{"detail": [...]}` for a document that fails the pydantic model (`extra="forbid"`, wrong types: models.py:43-79),
       500 + `{"detail": <trace>}` for a failing search (server.py:89-91), 404 / 405 for unknown routes.
-    Requests are serialised (one GPU stream, like the reference's single uvicorn worker running faiss synchronously,
-    server.py:69,78,98) or, with `micro_batch_wait_ms > 0`, fused into shared GPU batches by `MicroBatcher`."""
+    Searches go through the library's request fusion (`vodhip_batcher`, include/vodhip.h H6): concurrent requests share corpus scans,
+    a lone request runs at once (the reference's single uvicorn worker runs faiss for one request at a time, server.py:69,78,98).
+    `micro_batch_wait_ms > 0` additionally makes every batch wait that long for company (round 3's fixed window; not needed)."""
 
     def __init__(self, engine, micro_batch_wait_ms: float = 0.0):
+        from vod_amd.search.native import NativeBatcher
+
         self.engine = engine
-        # an engine that orders its own callers (`HipEngine`: tickets over the library's FIFO of in-flight searches) needs no lock here:
-        # concurrent requests are enqueued back to back on the GPU instead of waiting for each other's host-side work
-        self.lock = _NoLock() if getattr(engine, "pipelined", False) else threading.Lock()
-        self.batcher = MicroBatcher(engine, max_wait_s=micro_batch_wait_ms / 1e3, lock=self.lock) if micro_batch_wait_ms > 0 else None
+        self._window_us = int(micro_batch_wait_ms * 1e3)
+        self._make = NativeBatcher
+        self._lock = threading.Lock()
+        self._generic: dict[int, "NativeBatcher"] = {}  # engines without a native handle: one callback batcher per query dimension
+        # `HipEngine` / `NodeHipEngine` own the batcher that owns their index's search path; any other engine (the multi-process group,
+        # test doubles) is called back by one
+        self.batcher = getattr(engine, "batcher", None)
+        if self.batcher is None and getattr(engine, "dim", None):
+            self.batcher = self._batcher_for(int(engine.dim))
+        if self.batcher is not None and self._window_us > 0:
+            self.batcher.set_param("window_us", self._window_us)
+
+    def _batcher_for(self, dim: int):
+        if self.batcher is not None:
+            if dim != self.batcher.dim:
+                raise ValueError(f"query dimension {dim} != index dimension {self.batcher.dim}")
+            return self.batcher
+        with self._lock:
+            b = self._generic.get(dim)
+            if b is None:
+                b = self._generic[dim] = self._make(engine=_CallbackEngine(self.engine), dim=dim)
+                if self._window_us > 0:
+                    b.set_param("window_us", self._window_us)
+            return b
+
+    def close(self) -> None:
+        for b in self._generic.values():
+            b.close()
+        self._generic.clear()
 
     # -- the search itself --------------------------------------------------------------------------------------------
-    def search(self, query_vec: np.ndarray, top_k: int, subset_ids=None) -> tuple[np.ndarray, np.ndarray]:
+    def search(self, query_vec: np.ndarray, top_k: int, subset_ids=None, client: int = 0) -> tuple[np.ndarray, np.ndarray]:
         if query_vec.ndim != 2:
             raise ValueError(f"Expected 2D array, got {query_vec.ndim}D array")
+        subset = None
         if subset_ids is not None and any(len(s) for s in subset_ids):
             if len(subset_ids) != len(query_vec):
                 raise ValueError("`subset_ids` must have one list per query")
-            with self.lock:
-                scores, indices = self.engine.search(query_vec, top_k, subset_ids=subset_ids)
-        elif self.batcher is not None:
-            scores, indices = self.batcher.search(query_vec, top_k)
-        else:
-            with self.lock:
-                scores, indices = self.engine.search(query_vec, top_k)
+            subset = self.engine.encode_subset(subset_ids)
+        scores, indices = self._batcher_for(int(query_vec.shape[1])).search(query_vec, top_k, subset=subset, client=client)
         return np.asarray(scores, dtype=np.float32), np.asarray(indices, dtype=np.int64)
 
     # -- routes -------------------------------------------------------------------------------------------------------
     def health(self) -> str:
         return "ERROR: Index is empty" if self.engine.ntotal == 0 else "OK"
 
-    def legacy_search(self, document: dict) -> dict:
+    def legacy_search(self, document: dict, client: int = 0) -> dict:
         """POST /search (server.py:68-73): JSON lists in, JSON lists out."""
         query = SearchQuery(**document)
-        scores, indices = self.search(np.asarray(query.vectors, dtype=np.float32), query.top_k)
+        scores, indices = self.search(np.asarray(query.vectors, dtype=np.float32), query.top_k, client=client)
         rows = [[(None if np.isneginf(v) else float(v)) for v in r] for r in scores]
         return SearchResponse(scores=rows, indices=indices.tolist()).model_dump()
 
-    def fast_search(self, body) -> bytearray:
+    def fast_search(self, body, client: int = 0) -> bytearray:
         """POST /fast-search (server.py:76-91).  The multi-megabyte base64 field is located in the body, validated as the
         `str` the model asks for, and decoded where it lies; the reply's base64 text is written straight into its buffer."""
         small, spans = io.find_payload_spans(body, ("vectors",))
         query = FastSearchQuery(**small)  # raises pydantic.ValidationError -> 422
         try:
             vectors = io.deserialize_np_array_span(body, *spans["vectors"]) if "vectors" in spans else io.deserialize_np_array(query.vectors)
-            scores, indices = self.search(vectors, query.top_k, query.subset_ids)
+            scores, indices = self.search(vectors, query.top_k, query.subset_ids, client=client)
             return io.json_body_with_arrays({"scores": scores, "indices": indices})
         except Exception as exc:
             raise _SearchFailed(traceback.format_exc()) from exc
 
-    def raw_search(self, body, top_k: int) -> tuple[bytes, dict]:
+    def raw_search(self, body, top_k: int, client: int = 0) -> tuple[bytes, dict]:
         """POST /raw-search?top_k=K (not in the reference): body = raw `.npy` bytes of the [nq, d] queries (float32
         or float16), reply = raw bytes `scores float32 [nq, k]` followed by `indices int64 [nq, k]`; shapes in the headers."""
         try:
-            scores, indices = self.search(io.load_npy_view(body), top_k)
+            scores, indices = self.search(io.load_npy_view(body), top_k, client=client)
             scores, indices = np.ascontiguousarray(scores), np.ascontiguousarray(indices)
             payload = bytearray(scores.nbytes + indices.nbytes)
             if scores.nbytes:
@@ -241,7 +164,7 @@ class Endpoints:
         except Exception as exc:
             raise _SearchFailed(traceback.format_exc()) from exc
 
-    def handle(self, method: str, path: str, query: dict, body) -> tuple[int, str, "bytes | bytearray", dict]:
+    def handle(self, method: str, path: str, query: dict, body, client: int = 0) -> tuple[int, str, "bytes | bytearray", dict]:
         import json
 
         js = "application/json"
@@ -250,18 +173,20 @@ class Endpoints:
                 if method != "GET":
                     return 405, js, b'{"detail":"Method Not Allowed"}', {}
                 return 200, js, json.dumps(self.health()).encode(), {}
+            if path == "/stats" and method == "GET":
+                return 200, js, json.dumps({} if self.batcher is None else self.batcher.stats()).encode(), {}
             if path not in ("/search", "/fast-search", "/raw-search"):
                 return 404, js, b'{"detail":"Not Found"}', {}
             if method != "POST":
                 return 405, js, b'{"detail":"Method Not Allowed"}', {}
             if path == "/fast-search":
-                return 200, js, self.fast_search(body), {}
+                return 200, js, self.fast_search(body, client), {}
             if path == "/raw-search":
                 try:
                     top_k = int(query.get("top_k", 3))
                 except ValueError:
                     return 422, js, b'{"detail":"top_k must be an integer"}', {}
-                payload, headers = self.raw_search(body, top_k)
+                payload, headers = self.raw_search(body, top_k, client)
                 return 200, "application/octet-stream", payload, headers
             try:
                 document = json.loads(bytes(body))
@@ -270,7 +195,7 @@ class Endpoints:
             except ValueError as exc:
                 return 422, js, json.dumps({"detail": f"invalid request body: {exc}"}).encode(), {}
             try:
-                return 200, js, json.dumps(self.legacy_search(document)).encode(), {}
+                return 200, js, json.dumps(self.legacy_search(document, client)).encode(), {}
             except pydantic.ValidationError:
                 raise
             except Exception:
@@ -398,72 +323,43 @@ class HipEngine:
             subset[r, : len(names)] = [self.vocab.get(str(nm), -2) for nm in names]
         return subset
 
-    # -- searching: thread-safe and pipelined ---------------------------------------------------------------------------
-    # Up to MAX_IN_FLIGHT searches are enqueued back to back on the one stream (`vodhip_index_search_async`); the library completes
-    # them in FIFO order, so every caller takes a ticket at enqueue time and completes when its ticket is up.  The final select kernel
-    # of a search writes its result rows STRAIGHT INTO PINNED HOST MEMORY (a slot of a small ring of pinned buffers): completing a
-    # search is an event wait, no device-to-host copy that would queue behind the younger searches' kernels.
-    pipelined = True
-    MAX_IN_FLIGHT = 3
+    # -- searching -------------------------------------------------------------------------------------------------------------
+    # The library's batcher owns the index's search path: callers from any number of threads are fused into shared scans, up to two
+    # batches are enqueued back to back on the batcher's stream, the final select kernel of a search writes its result rows straight
+    # into device-visible host memory and every caller copies its own rows out (vodhip_serve.hip).  Round 3 did this here in Python
+    # (tickets over the library's FIFO, a ring of pinned torch buffers) - and raced with itself (advisor, round 3).
+    @property
+    def dim(self) -> int:
+        return self.index.dim
 
-    _pipe_create = threading.Lock()
+    @property
+    def batcher(self):
+        b = getattr(self, "_batcher", None)
+        if b is None:
+            with HipEngine._batcher_create:
+                b = getattr(self, "_batcher", None)
+                if b is None:
+                    from vod_amd.search.native import NativeBatcher
 
-    def _pipeline(self):
-        st = getattr(self, "_pipe", None)
-        if st is None:
-            with HipEngine._pipe_create:  # first use from several handler threads at once: ONE state object
-                st = getattr(self, "_pipe", None)
-                if st is None:
-                    st = self._pipe = {"submit": threading.Lock(), "turn": threading.Condition(), "next_ticket": 0, "next_done": 0, "slots": {}}
-        return st
+                    b = self._batcher = NativeBatcher(index=self.index, dim=self.index.dim, id_base=self.row_lo)
+        return b
 
-    def in_flight(self) -> int:
-        st = self._pipeline()
-        return st["next_ticket"] - st["next_done"]
+    _batcher_create = threading.Lock()
 
-    def _pinned_out(self, ticket: int, nq: int, k: int):
-        torch = self._torch
-        st = self._pipeline()
-        slot = ticket % (self.MAX_IN_FLIGHT + 1)
-        have = st["slots"].get(slot)
-        if have is None or have[0].numel() < nq * k:
-            n = max(nq * k, 4096)
-            have = (torch.empty((n,), dtype=torch.float32, pin_memory=True), torch.empty((n,), dtype=torch.int64, pin_memory=True))
-            st["slots"][slot] = have
-        return have[0][: nq * k].view(nq, k), have[1][: nq * k].view(nq, k)
-
-    def search_enqueue(self, query_vec: np.ndarray, top_k: int, subset_ids: list[list[str]] | None = None):
-        if query_vec.shape[1] != self.index.dim:
-            raise ValueError(f"query dimension {query_vec.shape[1]} != index dimension {self.index.dim}")
-        subset = self.encode_subset(subset_ids)
-        st = self._pipeline()
-        with st["submit"]:
-            with st["turn"]:
-                st["turn"].wait_for(lambda: st["next_ticket"] - st["next_done"] < self.MAX_IN_FLIGHT)
-            ticket = st["next_ticket"]
-            out = self._pinned_out(ticket, int(query_vec.shape[0]), int(top_k))
-            with self._torch.cuda.device(self.index.device):
-                self.index.search_async(query_vec, top_k, id_base=self.row_lo, out=out, subset=subset)
-            st["next_ticket"] = ticket + 1  # only a search the library accepted holds a ticket
-        return ticket, out
-
-    def search_complete(self, handle) -> tuple[np.ndarray, np.ndarray]:
-        ticket, (scores, ids) = handle
-        st = self._pipeline()
-        with st["turn"]:
-            st["turn"].wait_for(lambda: st["next_done"] == ticket)
-        try:
-            with self._torch.cuda.device(self.index.device):
-                self.index.finish()
-            # copies: the pinned slot is written again MAX_IN_FLIGHT + 1 searches from now
-            return scores.numpy().copy(), ids.numpy().copy()
-        finally:
-            with st["turn"]:
-                st["next_done"] = ticket + 1
-                st["turn"].notify_all()
+    def search_encoded(self, query_vec: np.ndarray, top_k: int, subset: np.ndarray | None = None, client: int = 0):
+        if query_vec.ndim != 2 or query_vec.shape[1] != self.index.dim:
+            raise ValueError(f"query dimension {query_vec.shape[-1]} != index dimension {self.index.dim}")
+        return self.batcher.search(query_vec, top_k, subset=subset, client=client)
 
     def search(self, query_vec: np.ndarray, top_k: int, subset_ids: list[list[str]] | None = None) -> tuple[np.ndarray, np.ndarray]:
-        return self.search_complete(self.search_enqueue(query_vec, top_k, subset_ids))
+        return self.search_encoded(query_vec, top_k, self.encode_subset(subset_ids))
+
+    def close(self) -> None:
+        b = getattr(self, "_batcher", None)
+        if b is not None:
+            b.close()
+            self._batcher = None
+        self.index.close()
 
 
 class NodeHipEngine:
@@ -514,10 +410,36 @@ class NodeHipEngine:
 
     encode_subset = HipEngine.encode_subset
 
+    @property
+    def dim(self) -> int:
+        return self.index.dim
+
+    @property
+    def batcher(self):
+        b = getattr(self, "_batcher", None)
+        if b is None:
+            with HipEngine._batcher_create:
+                b = getattr(self, "_batcher", None)
+                if b is None:
+                    from vod_amd.search.native import NativeBatcher
+
+                    b = self._batcher = NativeBatcher(node=self.index, dim=self.index.dim)
+        return b
+
+    def search_encoded(self, query_vec: np.ndarray, top_k: int, subset: np.ndarray | None = None, client: int = 0):
+        if query_vec.ndim != 2 or query_vec.shape[1] != self.index.dim:
+            raise ValueError(f"query dimension {query_vec.shape[-1]} != index dimension {self.index.dim}")
+        return self.batcher.search(query_vec, top_k, subset=subset, client=client)
+
     def search(self, query_vec: np.ndarray, top_k: int, subset_ids: list[list[str]] | None = None) -> tuple[np.ndarray, np.ndarray]:
-        if query_vec.shape[1] != self.index.dim:
-            raise ValueError(f"query dimension {query_vec.shape[1]} != index dimension {self.index.dim}")
-        return self.index.search(query_vec, top_k, subset=self.encode_subset(subset_ids))
+        return self.search_encoded(query_vec, top_k, self.encode_subset(subset_ids))
+
+    def close(self) -> None:
+        b = getattr(self, "_batcher", None)
+        if b is not None:
+            b.close()
+            self._batcher = None
+        self.index.close()
 
 
 class GroupHipEngine:
@@ -531,10 +453,21 @@ class GroupHipEngine:
     def ntotal(self) -> int:
         return self.local.n_store
 
-    def search(self, query_vec: np.ndarray, top_k: int, subset_ids: list[list[str]] | None = None) -> tuple[np.ndarray, np.ndarray]:
+    @property
+    def dim(self) -> int:
+        return self.local.index.dim
+
+    def encode_subset(self, subset_ids):
+        return self.local.encode_subset(subset_ids)
+
+    def search_encoded(self, query_vec: np.ndarray, top_k: int, subset: np.ndarray | None = None) -> tuple[np.ndarray, np.ndarray]:
+        # called by the batcher's callback engine, ONE fused batch at a time: the collective sequence of the group stays serial
         if query_vec.shape[1] != self.local.index.dim:
             raise ValueError(f"query dimension {query_vec.shape[1]} != index dimension {self.local.index.dim}")
-        return self.dispatcher.search(query_vec, top_k, subset=self.local.encode_subset(subset_ids))
+        return self.dispatcher.search(query_vec, top_k, subset=subset)
+
+    def search(self, query_vec: np.ndarray, top_k: int, subset_ids: list[list[str]] | None = None) -> tuple[np.ndarray, np.ndarray]:
+        return self.search_encoded(query_vec, top_k, self.local.encode_subset(subset_ids))
 
 
 def parse_args(argv=None) -> argparse.Namespace:
@@ -549,13 +482,17 @@ def parse_args(argv=None) -> argparse.Namespace:
                    help="comma-separated GPU ids: the store is row-sharded over them, one worker process per GPU on an RCCL "
                         "group, rank 0 answers HTTP (the reference's `--serve-on-gpu` = faiss index_cpu_to_all_gpus, server.py:51-54)")
     p.add_argument("--subset-ids-path", type=str, default=None, help=".npy with one subset id (string) per vector")
-    p.add_argument("--http", type=str, default="asyncio", choices=["asyncio", "uvicorn"],
-                   help="HTTP shell: the in-tree asyncio server (socket reads land in the request buffer, codec in place) or uvicorn + FastAPI")
+    p.add_argument("--http", type=str, default="native", choices=["native", "asyncio", "uvicorn"],
+                   help="HTTP shell: libvodhip's native front (default: the hot routes never enter the interpreter), the in-tree asyncio "
+                        "server, or uvicorn + FastAPI")
     p.add_argument("--http-workers", type=int, default=64, help="handler threads = requests that may be in flight at once")
     p.add_argument("--max-body-mb", type=int, default=512, help="largest request body the asyncio shell accepts (413 above it)")
     p.add_argument("--uds", type=str, default=None, help="also serve on this Unix-domain socket path (asyncio shell; clients on the same host)")
     p.add_argument("--micro-batch-wait-ms", type=float, default=0.0,
-                   help="> 0: fuse requests that arrive within this window into one GPU batch (default: serialise, as the reference)")
+                   help="> 0: every batch additionally waits this long for company.  Not needed: concurrent requests are fused by default "
+                        "(batch-while-busy, no fixed window: vodhip_batcher in include/vodhip.h)")
+    p.add_argument("--batcher-param", action="append", default=[], metavar="KEY=VALUE",
+                   help="vodhip_batcher_set_param, repeatable (max_queries, flat_queries, grace_us, grace_pct, window_us, depth)")
     # set by the owner process for its workers
     p.add_argument("--group-backend", type=str, default="nccl", choices=["nccl", "gloo", "node"],
                    help="with --devices: the workers' process group.  nccl = RCCL over xGMI (one GPU per worker); gloo = requests "
@@ -678,13 +615,30 @@ def _serve(engine, args: argparse.Namespace, host: str) -> None:
     if args.http == "uvicorn":
         import uvicorn
 
-        uvicorn.run(create_app(engine, micro_batch_wait_ms=args.micro_batch_wait_ms), host=host, port=args.port, workers=1,
-                    log_level=args.logging_level.lower())
+        if args.uds:
+            raise SystemExit("--uds needs --http native or --http asyncio (the uvicorn shell does not open the socket)")
+        app = create_app(engine, micro_batch_wait_ms=args.micro_batch_wait_ms)
+        _apply_batcher_params(app.state.endpoints, args)
+        uvicorn.run(app, host=host, port=args.port, workers=1, log_level=args.logging_level.lower())
+        return
+    endpoints = Endpoints(engine, micro_batch_wait_ms=args.micro_batch_wait_ms)
+    _apply_batcher_params(endpoints, args)
+    if args.http == "native":
+        from vod_amd.search import native
+
+        native.run(endpoints, host, args.port, max_body=args.max_body_mb << 20, uds=args.uds)
     else:
         from vod_amd.search import fastserver
 
-        fastserver.run(Endpoints(engine, micro_batch_wait_ms=args.micro_batch_wait_ms), host, args.port, workers=args.http_workers,
-                       max_body=args.max_body_mb << 20, uds=args.uds)
+        fastserver.run(endpoints, host, args.port, workers=args.http_workers, max_body=args.max_body_mb << 20, uds=args.uds)
+
+
+def _apply_batcher_params(endpoints, args: argparse.Namespace) -> None:
+    for kv in args.batcher_param:
+        key, _, val = kv.partition("=")
+        if endpoints.batcher is None:
+            raise SystemExit("--batcher-param needs an engine with a fixed query dimension")
+        endpoints.batcher.set_param(key, int(val))
 
 
 def main(argv=None) -> None:
