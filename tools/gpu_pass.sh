@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-4 GPU passes (one gpurun call each; outputs under gpurun_out/r4/<pass>/).  usage: tools/gpu_pass.sh <pass>
+#   serve   GPU tests of the serving path + the boundary under the trainer's load shape (tools/bench_http_load.py, default flags)
+#   serve_ab  the same load cells through round 3's Python shell (asyncio, window 0 / 1 ms) for the A/B
+#   tests   the whole -m gpu suite + smoke
+#   bench   the default bench line
+set -u
+P=${1:-tests}
+OUT=gpurun_out/r4/$P; mkdir -p $OUT
+case $P in
+  tests)
+    python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $OUT/smoke.log 2>&1
+    timeout 1200 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log ;;
+  bench)
+    timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 1500 $OUT/bench_default.json ;;
+  serve)
+    timeout 900 python -m pytest tests/test_server_gpu.py tests/test_fuzz_gpu.py tests/test_node_index_gpu.py -x -q -m gpu > $OUT/pytest_serve.log 2>&1; tail -5 $OUT/pytest_serve.log
+    timeout 1500 python tools/bench_http_load.py --out $OUT/http_load_native.json > $OUT/http_load_native.log 2>&1; tail -25 $OUT/http_load_native.log | cut -c1-400 ;;
+  serve_ab)
+    timeout 900 python tools/bench_http_load.py --http asyncio --micro-batch-ms 0 1 --routes fast --nq 32 64 --out $OUT/http_load_asyncio.json > $OUT/http_load_asyncio.log 2>&1; tail -14 $OUT/http_load_asyncio.log | cut -c1-300 ;;
+  *) echo "unknown pass $P"; exit 2 ;;
+esac
