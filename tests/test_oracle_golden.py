@@ -310,3 +310,77 @@ def test_collate_chain_matches_reference():
         np.testing.assert_array_equal(flat["log_weights"], g[f"flat_logw_{c}"])
         np.testing.assert_array_equal(flat["raw"]["dense"], g[f"flat_dense_{c}"])
         np.testing.assert_array_equal(flat["raw"]["sparse"], g[f"flat_sparse_{c}"])
+
+
+# ---- the C restatement of the reference's numba loops (oracle/collate_ref.c: the CPU figure beside the C5 kernels) must reproduce the
+# ---- same reference-generated fixtures as the NumPy restatements ------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("name", ["merge_3engine_basic"] + [f"merge_random_{i}" for i in range(8)])
+def test_c_collate_restatement_merge_matches_reference(name):
+    from oracle import collate_ref as cref
+
+    g = _load(name)
+    w = MANIFEST[name]["params"]["weights"]
+    idx, scr, lbl, raw = cref.merge_hybrid((g["lookup_idx"], g["lookup_scr"], g["lookup_lbl"]),
+                                           {"dense": (g["dense_idx"], g["dense_scr"]), "sparse": (g["sparse_idx"], g["sparse_scr"])},
+                                           {"dense": w["dense"], "sparse": w["sparse"]})
+    _eq(idx, g["out_idx"])
+    _eq(scr, g["out_scr"])
+    _eq(lbl, g["out_lbl"])
+    _eq(raw["dense"], g["raw_dense"])
+    _eq(raw["sparse"], g["raw_sparse"])
+
+
+def test_c_collate_restatement_chain_matches_reference():
+    from oracle import collate_ref as cref
+
+    g = _load("collate_chain")
+    for c, p in enumerate(MANIFEST["collate_chain"]["params"]["cases"]):
+        lookup = (g[f"l_idx_{c}"], None, g[f"l_lbl_{c}"])
+        m_idx, m_scr, m_lbl, m_raw = cref.merge_hybrid(lookup, {"dense": (g[f"d_idx_{c}"], g[f"d_scr_{c}"]), "sparse": (g[f"s_idx_{c}"], g[f"s_scr_{c}"])},
+                                                       p["weights"])
+        np.testing.assert_array_equal(m_idx, g[f"m_idx_{c}"])
+        np.testing.assert_array_equal(m_scr, g[f"m_scr_{c}"])
+        np.testing.assert_array_equal(m_lbl, g[f"m_lbl_{c}"])
+        out = cref.sample_search_results(m_idx, m_scr, m_lbl, m_raw, g[f"noise_{c}"], p["total"], p["max_pos_sections"], p["temperature"],
+                                         p["max_support_size"])
+        fin = np.isfinite(g[f"smp_logw_{c}"])
+        np.testing.assert_array_equal(out["indices"][fin], g[f"smp_idx_{c}"][fin])
+        np.testing.assert_array_equal(out["labels"], g[f"smp_lbl_{c}"])
+        np.testing.assert_array_equal(out["scores"][fin], g[f"smp_scr_{c}"][fin])
+        np.testing.assert_array_equal(np.isfinite(out["log_weights"]), fin)
+        np.testing.assert_allclose(out["log_weights"][fin], g[f"smp_logw_{c}"][fin], rtol=2e-5, atol=2e-5)
+        for key, ref in (("lse_pos", g[f"smp_lse_pos_{c}"]), ("lse_neg", g[f"smp_lse_neg_{c}"])):
+            both = np.isfinite(ref)
+            np.testing.assert_array_equal(np.isfinite(out[key]), both)
+            np.testing.assert_allclose(out[key][both], ref[both], rtol=2e-5, atol=2e-5)
+        np.testing.assert_array_equal(out["max_sampling_id"], g[f"smp_max_id_{c}"])
+        np.testing.assert_array_equal(out["raw"]["dense"][fin], g[f"smp_dense_{c}"][fin])
+        np.testing.assert_array_equal(out["raw"]["sparse"][fin], g[f"smp_sparse_{c}"][fin])
+        flat = cref.flatten_samples(g[f"smp_idx_{c}"], g[f"smp_scr_{c}"], g[f"smp_lbl_{c}"], g[f"smp_logw_{c}"],
+                                    {"dense": g[f"smp_dense_{c}"], "sparse": g[f"smp_sparse_{c}"]})
+        np.testing.assert_array_equal(flat["indices"], g[f"flat_idx_{c}"])
+        np.testing.assert_array_equal(flat["scores"], g[f"flat_scr_{c}"])
+        np.testing.assert_array_equal(flat["labels"], g[f"flat_lbl_{c}"])
+        np.testing.assert_array_equal(flat["log_weights"], g[f"flat_logw_{c}"])
+        np.testing.assert_array_equal(flat["raw"]["dense"], g[f"flat_dense_{c}"])
+        np.testing.assert_array_equal(flat["raw"]["sparse"], g[f"flat_sparse_{c}"])
+
+
+def test_c_collate_restatement_sampling_matches_reference():
+    from oracle import collate_ref as cref
+
+    g = _load("sampling_fixed_noise")
+    for c, p in enumerate(MANIFEST["sampling_fixed_noise"]["params"]["cases"]):
+        scores, labels, noise = g[f"scores_{c}"], g[f"labels_{c}"], g[f"noise_{c}"]
+        if scores.ndim != 2:
+            continue
+        ids = np.tile(np.arange(scores.shape[1], dtype=np.int64), (scores.shape[0], 1))
+        out = cref.sample_search_results(ids, scores, labels.astype(np.int64), {}, noise, p["k_total"], p["k_positive"], p["temperature"],
+                                         p["max_support_size"] if p["max_support_size"] and p["max_support_size"] > 0 else None)
+        ref_w = g[f"out_logw_{c}"]
+        fin = np.isfinite(ref_w)
+        np.testing.assert_array_equal(out["local"][fin], g[f"out_samples_{c}"][fin])
+        np.testing.assert_array_equal(out["labels"], g[f"out_labels_{c}"])
+        np.testing.assert_allclose(out["log_weights"][fin], ref_w[fin], rtol=2e-5, atol=2e-5)

@@ -45,22 +45,31 @@ def _worker(client, nq, dim, k, seconds, barrier, out_q, seed):
     out_q.put(lat)
 
 
-def run_cell(client, P, nq, dim, k, seconds):
+def run_cell(client, P, nq, dim, k, seconds, stats=lambda: {}):
     ctx = mp.get_context("spawn")
     barrier, out_q = ctx.Barrier(P + 1), ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(client, nq, dim, k, seconds, barrier, out_q, 100 + i)) for i in range(P)]
     for p in procs:
         p.start()
     barrier.wait()
+    s0 = stats()  # the server's counters over the timed window only (not the seconds the client processes take to start)
     t0 = time.perf_counter()
     lats = [out_q.get(timeout=seconds + 120) for _ in range(P)]
     wall = time.perf_counter() - t0
+    s1 = stats()
     for p in procs:
         p.join(timeout=60)
     flat = sorted(x for lat in lats for x in lat)
     n_req = len(flat)
-    return {"clients": P, "nq": nq, "requests": n_req, "qps": n_req * nq / wall, "p50_ms": flat[n_req // 2] * 1e3,
+    cell = {"clients": P, "nq": nq, "requests": n_req, "qps": n_req * nq / wall, "p50_ms": flat[n_req // 2] * 1e3,
             "p99_ms": flat[min(n_req - 1, int(n_req * 0.99))] * 1e3}
+    if s0 and s1 and s1.get("batches", 0) > s0.get("batches", 0):
+        nb = s1["batches"] - s0["batches"]
+        busy, idle = s1["busy_ns"] - s0["busy_ns"], s1["idle_ns"] - s0["idle_ns"]
+        cell["server"] = {"batches": nb, "mean_queries_per_batch": (s1["queries"] - s0["queries"]) / nb,
+                          "mean_requests_per_batch": (s1["requests"] - s0["requests"]) / nb, "engine_idle_fraction": idle / max(1, busy + idle),
+                          "grace_waits": s1["grace_waits"] - s0["grace_waits"], "grace_expired": s1["grace_expired"] - s0["grace_expired"]}
+    return cell
 
 
 def main():
@@ -129,16 +138,7 @@ def main():
                 client = HipMipsClient(host=master.host, port=master.port, binary=binary)
                 for P in a.clients:
                     for nq in a.nq:
-                        s0 = stats()
-                        cell = run_cell(client, P, nq, a.dim, a.k, a.seconds)
-                        s1 = stats()
-                        if s0 and s1 and s1.get("batches", 0) > s0.get("batches", 0):
-                            nb = s1["batches"] - s0["batches"]
-                            busy, idle = s1["busy_ns"] - s0["busy_ns"], s1["idle_ns"] - s0["idle_ns"]
-                            cell["server"] = {"batches": nb, "mean_queries_per_batch": (s1["queries"] - s0["queries"]) / nb,
-                                              "mean_requests_per_batch": (s1["requests"] - s0["requests"]) / nb,
-                                              "engine_idle_fraction": idle / max(1, busy + idle), "grace_waits": s1["grace_waits"] - s0["grace_waits"],
-                                              "grace_expired": s1["grace_expired"] - s0["grace_expired"]}
+                        cell = run_cell(client, P, nq, a.dim, a.k, a.seconds, stats)
                         fused = str(min(2048, P * nq))
                         cell.update(route="/raw-search" if binary else "/fast-search", micro_batch_wait_ms=mb,
                                     device_resident_qps_at_fused_batch=out["device_resident"][fused]["qps"],

@@ -4,6 +4,7 @@
 #   serve_ab  the same load cells through round 3's Python shell (asyncio, window 0 / 1 ms) for the A/B
 #   tests   the whole -m gpu suite + smoke
 #   bench   the default bench line
+#   load / c5 / grid   see the case arms below
 set -u
 P=${1:-tests}
 OUT=gpurun_out/r4/$P; mkdir -p $OUT
@@ -18,5 +19,12 @@ case $P in
     timeout 1500 python tools/bench_http_load.py --out $OUT/http_load_native.json > $OUT/http_load_native.log 2>&1; tail -25 $OUT/http_load_native.log | cut -c1-400 ;;
   serve_ab)
     timeout 900 python tools/bench_http_load.py --http asyncio --micro-batch-ms 0 1 --routes fast --nq 32 64 --out $OUT/http_load_asyncio.json > $OUT/http_load_asyncio.log 2>&1; tail -14 $OUT/http_load_asyncio.log | cut -c1-300 ;;
+  load)   # the load cells only (no tests)
+    timeout 1500 python tools/bench_http_load.py --out $OUT/http_load_native.json > $OUT/http_load_native.log 2>&1; tail -25 $OUT/http_load_native.log | cut -c1-420 ;;
+  c5)     # host-time probe of the retrieval loss + the C5 side entry (with the restated CPU / op-sequence baselines)
+    timeout 600 python tools/probe_h5_host.py > $OUT/probe_h5_host.json 2> $OUT/probe_h5_host.err; cat $OUT/probe_h5_host.json
+    timeout 600 python tools/side_c5.py > $OUT/side_c5.json 2> $OUT/side_c5.err; tail -c 3000 $OUT/side_c5.json ;;
+  grid)   # the reference's published artefact on its own axes
+    timeout 1200 python tools/bench_reference_grid.py --out $OUT/reference_grid.json > $OUT/reference_grid.log 2>&1; tail -15 $OUT/reference_grid.log ;;
   *) echo "unknown pass $P"; exit 2 ;;
 esac

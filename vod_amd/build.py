@@ -36,15 +36,20 @@ def build_oracle(force: bool = False) -> pathlib.Path:
     """gcc the oracle's plain-C restatement (test infrastructure; never linked into the product)."""
     out_dir = ORACLE / "_build"
     out_dir.mkdir(exist_ok=True)
-    target = out_dir / "liboracle_flat_ip.so"
-    src = ORACLE / "flat_ip_ref.c"
-    if target.exists() and not force and target.stat().st_mtime >= src.stat().st_mtime:
-        return target
-    cmd = ["gcc", "-O3", "-fopenmp", "-shared", "-fPIC", str(src), "-o", str(target), "-lm"]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError(f"building the C oracle failed:\n{res.stderr[-4000:]}")
-    return target
+    first = None
+    # flat_ip_ref.c: the H2 restatement (fp32 + heap); collate_ref.c: the reference's numba loops of the collate-side chain
+    for src_name, lib_name in (("flat_ip_ref.c", "liboracle_flat_ip.so"), ("collate_ref.c", "liboracle_collate.so")):
+        target = out_dir / lib_name
+        src = ORACLE / src_name
+        first = first or target
+        if target.exists() and not force and target.stat().st_mtime >= src.stat().st_mtime:
+            continue
+        # (no -ffast-math: the restatement keeps IEEE NaN / inf semantics like NumPy)
+        cmd = ["gcc", "-O3", "-fopenmp", "-shared", "-fPIC", str(src), "-o", str(target), "-lm"]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"building the C oracle ({src_name}) failed:\n{res.stderr[-4000:]}")
+    return first
 
 
 if __name__ == "__main__":

@@ -251,7 +251,7 @@ void slot_free(vodhip_batcher* b, Slot& s) {
 //   * engine idle, no other recently active client is missing            -> now (a lone client never waits: no fixed window)
 //   * engine idle, other clients that searched a moment ago have not come back yet, and the batch still fits one query tile
 //     (<= flat_queries: the scan costs the same with them aboard)          -> wait for them, at most `grace` (a share of a measured
-//                                                                            scan, capped) from the first arrival
+//                                                                            scan, capped) from the first arrival / the engine going idle
 //   * engine busy, pending < flat_queries                                  -> keep collecting until the running batch completes
 //                                                                            (enqueuing early would freeze a small batch that costs
 //                                                                            a whole scan of its own)
@@ -291,7 +291,9 @@ bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
         if (!has) ++missing;
     }
     if (missing == 0) return true;
-    const tp_t deadline = first->t_arrive + std::chrono::nanoseconds((int64_t)grace_ns);
+    // the grace runs from the moment waiting started to cost anything: the first arrival, or - for requests that were collected while a
+    // batch ran - the moment the engine became idle (its callers are turning around right now: they are the company worth waiting for)
+    const tp_t deadline = std::max(first->t_arrive, b->t_idle_since) + std::chrono::nanoseconds((int64_t)grace_ns);
     if (now >= deadline) {
         ++b->n_grace_full;
         return true;
