@@ -620,7 +620,15 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
         sys.path.insert(0, str(ROOT / "tools"))
         import side_c5  # noqa: PLC0415  (tools/side_c5.py: timings + fixture verification of the collate-side chain and the loss)
 
-        out.append(side_c5.measure(rig.dev, cpu_baseline=not args.no_cpu_baseline))
+        c5, ctx = side_c5.measure(rig.dev)
+        out.append(c5)
+        if not args.no_cpu_baseline:
+            try:  # the CPU-baseline leg of C5: the oracle side's restatements, timed beside the kernels and used as the checker
+                from oracle.c5_baseline import measure as c5_baselines  # noqa: PLC0415
+
+                c5.update(c5_baselines(rig.torch, rig.dev, ctx["c5_data"], ctx["loss_inputs"], ctx["kw"]))
+            except Exception as exc:  # noqa: BLE001
+                c5["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     except Exception as exc:  # noqa: BLE001
         out.append({"name": "C5", "error": f"{type(exc).__name__}: {exc}"[:400]})
     return out

@@ -1,5 +1,5 @@
-#!/usr/bin/env python3
-"""The two "restated" baselines reported beside the C5 kernels (bench.py `side` entry C5; never on the product path):
+"""Oracle (test infrastructure; imported only by bench.py's `cpu_baseline` leg): the two "restated" baselines reported beside the C5
+kernels (bench.py `side` entry C5; never on the product path):
 
   cpu_baseline            the reference's numba loops of the collate-side chain (merge.py:71-164, numpy_ops.py:24-143,
                           sample.py:160-352, in_batch_negatives.py:10-52) restated in plain C (oracle/collate_ref.c, gcc -O3 -fopenmp;

@@ -23,7 +23,7 @@ case $P in
     timeout 1500 python tools/bench_http_load.py --out $OUT/http_load_native.json > $OUT/http_load_native.log 2>&1; tail -25 $OUT/http_load_native.log | cut -c1-420 ;;
   c5)     # host-time probe of the retrieval loss + the C5 side entry (with the restated CPU / op-sequence baselines)
     timeout 600 python tools/probe_h5_host.py > $OUT/probe_h5_host.json 2> $OUT/probe_h5_host.err; cat $OUT/probe_h5_host.json
-    timeout 600 python tools/side_c5.py > $OUT/side_c5.json 2> $OUT/side_c5.err; tail -c 3000 $OUT/side_c5.json ;;
+    timeout 600 python tools/side_c5.py > $OUT/side_c5.json 2> $OUT/side_c5.err; tail -c 3000 $OUT/side_c5.json ;;   # (the restated baselines ride on bench.py's cpu_baseline leg)
   grid)   # the reference's published artefact on its own axes
     timeout 1200 python tools/bench_reference_grid.py --out $OUT/reference_grid.json > $OUT/reference_grid.log 2>&1; tail -15 $OUT/reference_grid.log ;;
   *) echo "unknown pass $P"; exit 2 ;;

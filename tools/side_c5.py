@@ -5,10 +5,9 @@ sampling -> in-batch flattening) and the in-batch retrieval loss at B = 64 queri
 
   * `verify`: the same entry points run on the committed REFERENCE-generated fixtures (tests/golden/collate_chain.npz - the reference's
     own merge -> sample -> flatten chain - and the five retrieval_grad_* fixtures) and compared the way the parity tests compare;
-  * `cpu_baseline` (optional): the reference's numba loops restated in plain C (oracle/collate_ref.c, gcc -O3 -fopenmp; checked against
-    the same fixtures by tests/test_oracle_golden.py) timed on the host cores, and `reference_op_sequence`: the reference's H5 op sequence
-    (retrieval.py:153-243) restated in eager torch, timed on the same GPU.  Both are labelled "restated": the reference itself cannot
-    travel to the GPU box.
+  * bench.py's `cpu_baseline` leg adds (oracle/c5_baseline.py - this file never imports the oracle): `cpu_baseline` = the reference's
+    numba loops restated in plain C, timed on the host cores, and `reference_op_sequence` = the reference's H5 op sequence restated in
+    eager torch, timed on the same GPU.  Both are labelled "restated": the reference itself cannot travel to the GPU box.
 
     python tools/side_c5.py            # prints the entry as JSON
 """
@@ -125,7 +124,8 @@ def verify_fixtures(torch, dev) -> dict:
             "tolerance": "ids / labels / merged scores bit-exact; float32 log-weights 2e-5; loss and gradients rtol 2e-4"}
 
 
-def measure(dev, cpu_baseline: bool = True) -> dict:
+def measure(dev) -> tuple[dict, dict]:
+    """(the side entry, the context - inputs and sampling parameters - the baseline leg re-uses)."""
     import torch
 
     import c5_data
@@ -166,17 +166,10 @@ def measure(dev, cpu_baseline: bool = True) -> dict:
 
         fwd = lambda q=q, s=s, batch=batch: grad(batch=batch, query_encoding=q, section_encoding=s)  # noqa: E731
         entry[name] = {"fwd_wall_us": _timeit(torch, fwd), "fwd_bwd_wall_us": _timeit(torch, fwd_bwd), "fwd_bwd_device_us": _device_us(torch, fwd_bwd)}
-    if cpu_baseline:
-        try:
-            import side_c5_baselines  # noqa: PLC0415  (oracle-side restatements: reported baselines, never the product path)
-
-            entry.update(side_c5_baselines.measure(torch, dev, c5_data, loss_inputs, kw))
-        except Exception as exc:  # noqa: BLE001
-            entry["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-    return entry
+    return entry, {"c5_data": c5_data, "loss_inputs": loss_inputs, "kw": kw}
 
 
 if __name__ == "__main__":
     import torch
 
-    print(json.dumps(measure(torch.device("cuda", 0), cpu_baseline="--no-cpu-baseline" not in sys.argv)))
+    print(json.dumps(measure(torch.device("cuda", 0))[0]))

@@ -107,6 +107,7 @@ struct vodhip_index {
     int64_t force_safe = 0;
     int64_t tile = 0;
     int64_t kflags = 0;
+    int64_t ring_single_qtile = 1;    // auto tile choice: FILTER stages of batches of <= 256 queries run on the deep-ring kernel (tile 11)
     int64_t small_chunk_tiles = 256;  // launches with fewer 256x256 tiles than this (less than one per CU) use the 128x128 kernel
     int n_cu = 256;       // compute units of `device` (read once at create; the planner never touches the runtime)
     int64_t profile = 0;  // 1: bracket every filter launch with HIP events (bench / roofline accounting)
@@ -227,7 +228,9 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad,
     }
     const int64_t s_min = std::min(s_max, round_up(std::max<int64_t>(4 * rg * (int64_t)k, 2048), bm));
     int64_t s = std::min(s_max, std::max(s_min, round_up(n / std::max<int64_t>(ix->sample_div, 2), bm)));
+    int64_t round_rows = ROW_ALIGN;  // corpus rows ONE round of the persistent grid covers (one 256 x 256 tile per CU)
     if (filter_tile_is_persistent(gmax_tile)) {
+        round_rows = std::max<int64_t>(1, std::max(1, ix->n_cu) / std::max<int64_t>(1, nq_pad / 256)) * bm;
         // the persistent kernel runs one workgroup per CU: a bootstrap of r.x "rounds" of tiles costs as much as r+1 full ones.
         // Whole rounds only: down when that keeps >= 4k groups (a cheaper bootstrap), up otherwise (a tighter bound for free)
         const int64_t n_cu = std::max(1, ix->n_cu);
@@ -246,7 +249,10 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad,
         st.resize(n_head);
         int64_t b = 0, calibrated = s;
         while (b < n) {
-            const int64_t rows = std::min(rows_safe, round_up((int64_t)((double)calibrated * growth), ROW_ALIGN));
+            int64_t rows = std::min(rows_safe, round_up((int64_t)((double)calibrated * growth), ROW_ALIGN));
+            // whole rounds of the persistent grid: a stage of r.x rounds costs r + 1 (its last round runs on a fraction of the CUs), so
+            // only the LAST stage of a search may end inside a round (round 4; the capacity bound rows_safe only ever rounds DOWN)
+            if (rows > round_rows) rows = rows / round_rows * round_rows;
             int64_t e = std::min(n, b + rows);
             if (n - e < rows / 4 && n - b <= rows_safe) e = n;  // no short tail stage
             st.push_back({ST_FILTER, b, e, 0, 0, 0});
@@ -349,6 +355,11 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
                 // short FILTER stages do not fill the CUs with 256x256 tiles: those launches run on 128x128 tiles, 2 workgroups per CU
                 if (x_tiles * q_tiles < ix->small_chunk_tiles) {
                     tile_c = 1;
+                } else if (q_tiles == 1 && ix->ring_single_qtile) {
+                    // ONE q-tile: every corpus line is read once, from HBM, by one workgroup - the regime where the two-slot loop's
+                    // exposed first-touch wait costs most.  The deep ring (corpus requested two slices ahead, fragments read a k-step
+                    // ahead: kernels_mips_ring.hip) measures 1.6-1.8 % faster there and equal with more q-tiles
+                    tile_c = 11;
                 }
             }
             if (launch_one(tile_c, sg.b, sg.e)) return -1;
@@ -739,6 +750,8 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
         ix->force_safe = value;
     } else if (!strcmp(key, "small_chunk_tiles")) {
         ix->small_chunk_tiles = value;
+    } else if (!strcmp(key, "ring_single_qtile")) {
+        ix->ring_single_qtile = value;
     } else if (!strcmp(key, "kflags")) {
         ix->kflags = value;
     } else if (!strcmp(key, "sample_div")) {
@@ -751,12 +764,12 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
         ix->ingest_threads = value;
     } else if (!strcmp(key, "tile")) {
 #ifdef VODHIP_EXPERIMENTS
-        const bool ring_ok = true;  // tiles 10 / 11 / 12: the FILTER kernels of experiment builds
+        const bool wide_ok = true;  // tile 12: the 384 x 256 FILTER kernel of experiment builds
 #else
-        const bool ring_ok = false;
+        const bool wide_ok = false;
 #endif
-        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 42 && value != 46 && !(ring_ok && value >= 10 && value <= 12))
-            return fail("tile must be 0 (auto) or a filter-kernel variant id: 1, 8, 9, 42, 46 (DESIGN.md 4.1)");
+        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 10 && value != 11 && value != 42 && value != 46 && !(wide_ok && value == 12))
+            return fail("tile must be 0 (auto) or a filter-kernel variant id: 1, 8, 9, 10, 11, 42, 46 (DESIGN.md 4.2)");
         ix->tile = value;
     } else {
         return fail("unknown parameter '%s'", key);

@@ -152,7 +152,17 @@ struct vodhip_batcher {
     bool stop = false;
     std::thread th_sched, th_compl;
     double ema_flat_scan_ns = 0.0;  // duration of batches of <= flat_queries queries that started on an idle engine
+    double ema_tiles_ns[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... and of batches of t query tiles (256 queries each) that started on an idle engine
+    double estimate_ns(int64_t nq) const {  // expected duration of a batch of nq queries: its own bucket, else scaled from the nearest known one
+        const int t = (int)std::min<int64_t>(8, std::max<int64_t>(1, (nq + 255) / 256));
+        if (ema_tiles_ns[t] > 0.0) return ema_tiles_ns[t];
+        for (int d = 1; d < 8; ++d)
+            for (int u : {t - d, t + d})
+                if (u >= 1 && u <= 8 && ema_tiles_ns[u] > 0.0) return ema_tiles_ns[u] * (u == 1 && t > 1 ? (double)t * 0.75 : (double)t / (double)u);
+        return 0.0;
+    }
     tp_t t_idle_since;              // when the engine last became idle (stats)
+    tp_t t_last_completion;         // when the previous batch completed (= when a batch enqueued behind it started to run)
     // stats
     int64_t n_batches = 0, n_requests = 0, n_queries = 0, n_fused_max = 0, n_grace_waits = 0, n_grace_full = 0;
     int64_t idle_ns = 0, busy_ns = 0, last_batch_queries = 0, last_batch_requests = 0;
@@ -272,8 +282,31 @@ bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
     if (pend_q >= b->max_queries) return true;
     const tp_t window_end = first->t_arrive + std::chrono::microseconds(b->window_us);
     if (in_flight > 0) {
-        if (pend_q >= b->flat_queries) return true;
-        return false;  // woken by the completion
+        if (pend_q < b->flat_queries) return false;  // woken by the completion (or by the arrivals that make it a tile's worth)
+        // More than one query tile is waiting: it will be enqueued BEHIND the running batch - but a batch is frozen the moment it is
+        // enqueued, and a scan is cheapest per query when the batch is large and tile-aligned (32 clients x 64 queries: three groups of
+        // ~685 queries ran at 78 % of the device rate with the engine never idle; two groups of 1024 run at 97 %).  So it is enqueued
+        //   - at once when nobody else can join anyway: every recently active client is pending or inside a batch on the device, or
+        //   - just in time: when the oldest running batch is about to complete (its duration is known from earlier batches of its size).
+        int missing = 0;
+        const auto active_window = std::chrono::nanoseconds((int64_t)std::max(5e6, 4.0 * (b->ema_flat_scan_ns + 1e6)));
+        for (const auto& kv : b->clients) {
+            if (now - kv.second > active_window) continue;
+            bool has = false;
+            for (const Request* r : b->pending) has = has || r->client == kv.first;
+            for (const Batch* bt : b->inflight)
+                for (const Request* r : bt->reqs) has = has || r->client == kv.first;
+            if (!has) ++missing;
+        }
+        if (missing == 0) return true;
+        const Batch* oldest = b->inflight.front();
+        const double est = b->estimate_ns(oldest->nq);
+        if (est <= 0.0) return true;  // no estimate yet for a batch of that size: round 3's behaviour (enqueue behind at once)
+        const double lead = std::max(300e3, 0.06 * est) + 0.15e3 * (double)pend_q;  // host-side submission: ~0.15 us per query to stage + copy
+        const tp_t jit = oldest->t_submit + std::chrono::nanoseconds((int64_t)(est - lead));
+        if (now >= jit) return true;
+        *until = jit;
+        return false;
     }
     if (b->window_us > 0 && now < window_end) {
         *until = window_end;
@@ -377,6 +410,13 @@ void complete_locked(vodhip_batcher* b, Batch* bt, tp_t now) {
     const double dur = (double)ns_between(bt->t_submit, now);
     if (bt->rc == 0 && bt->pipeline_was_empty && bt->nq <= b->flat_queries && !bt->subset)
         b->ema_flat_scan_ns = b->ema_flat_scan_ns <= 0.0 ? dur : 0.8 * b->ema_flat_scan_ns + 0.2 * dur;
+    if (bt->rc == 0 && !bt->subset && bt->nq <= 2048) {
+        // a batch that started on an idle engine ran `dur`; one that was enqueued behind another ran from its predecessor's completion
+        const double own = bt->pipeline_was_empty ? dur : (double)ns_between(std::max(bt->t_submit, b->t_last_completion), now);
+        double& e = b->ema_tiles_ns[(int)std::min<int64_t>(8, std::max<int64_t>(1, (bt->nq + 255) / 256))];
+        e = e <= 0.0 ? own : 0.7 * e + 0.3 * own;
+    }
+    b->t_last_completion = now;
     bt->slot->users = (int)bt->reqs.size();
     for (Request* r : bt->reqs) r->done = true;
     if (b->inflight.empty()) {
