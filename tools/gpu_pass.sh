@@ -26,5 +26,16 @@ case $P in
     timeout 600 python tools/side_c5.py > $OUT/side_c5.json 2> $OUT/side_c5.err; tail -c 3000 $OUT/side_c5.json ;;   # (the restated baselines ride on bench.py's cpu_baseline leg)
   grid)   # the reference's published artefact on its own axes
     timeout 1200 python tools/bench_reference_grid.py --out $OUT/reference_grid.json > $OUT/reference_grid.log 2>&1; tail -15 $OUT/reference_grid.log ;;
+  ab_ring)  # same-box interleaved A/B: FILTER stages of one-q-tile batches on the deep ring (tile 11, auto) vs the two-slot kernel (tile 8)
+    for rep in 1 2 3; do
+      for cfg in "c2 --rows 1000000 --nq 256 --steps 300 --warmup 30" "nq256 --nq 256 --steps 60 --warmup 6" "c4shard_nq256 --rows 5000000 --dim 1024 --dtype bf16 --nq 256 --k 200 --steps 60 --warmup 6"; do
+        set -- $cfg; name=$1; shift
+        for v in "ring" "twoslot --param ring_single_qtile=0"; do
+          set -- $v; vn=$1; shift
+          ms=$(timeout 600 python bench.py $(echo $cfg | cut -d" " -f2-) --no-side --no-cpu-baseline --verify-queries 16 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), d['verify']['recall_at_k'], d['verify']['max_abs_score_diff'])")
+          echo "$name $vn rep$rep $ms" | tee -a $OUT/ab_ring.txt
+        done
+      done
+    done ;;
   *) echo "unknown pass $P"; exit 2 ;;
 esac

@@ -28,50 +28,82 @@ class RealmOutput:
     diagnostics: dict[str, typ.Any] = dataclasses.field(default_factory=dict)
 
 
+_ENC = (torch.float16, torch.bfloat16, torch.float32)
+_scratch: dict = {}  # (device index, stream, floats) -> the forward's device scratch (row words + split-K slabs), consumed in stream order
+
+
+def _as(t: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    """`t` itself when it already has the dtype and layout the kernels read (no new tensor object: this sits on a ~100 us host path)."""
+    return t if (t.dtype is dt and t.is_contiguous()) else t.to(dt).contiguous()
+
+
+class _on_device:
+    """`torch.cuda.device(dev)` only when `dev` is not current already (the context manager costs ~5 us per entry)."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev: torch.device):
+        self.ctx = None if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
 class _RetrievalLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, s, score, relevance, sparse, dense, aux_cfg=(0, 0.0, 0.0, 0.0)):  # noqa: ANN001
         lib = _native.load_library()
         if not q.is_cuda:
             raise _native.NativeLibraryError("RetrievalGradients needs device tensors (there is no CPU path)")
-        enc = q.dtype if q.dtype in (torch.float16, torch.bfloat16, torch.float32) else torch.float32
-        as_ = lambda t, dt: t.detach() if (t.dtype is dt and t.is_contiguous()) else t.detach().to(dt).contiguous()  # noqa: E731
-        qc = as_(q, enc)
-        sc = as_(s, enc)
+        enc = q.dtype if q.dtype in _ENC else torch.float32
+        qc, sc = _as(q, enc), _as(s, enc)  # (autograd is off inside `forward`: no detach needed)
         three_d = sc.dim() == 3
         if sc.dim() not in (2, 3):
             raise ValueError(f"Invalid dimension for `section_encoding`: {tuple(sc.shape)}")
         B, H = qc.shape
         D = sc.shape[1] if three_d else sc.shape[0]
-        score_c = as_(score, torch.float32)
-        rel_c = as_(relevance, torch.int64)
+        score_c, rel_c = _as(score, torch.float32), _as(relevance, torch.int64)
         if score_c.shape != (B, D) or rel_c.shape != (B, D):
             raise ValueError(f"section__score / section__relevance must be [{B}, {D}]")
-        sparse_c = None if sparse is None else as_(sparse, torch.float32)
-        dense_c = None if dense is None else as_(dense, torch.float32)
+        sparse_c = None if sparse is None else _as(sparse, torch.float32)
+        dense_c = None if dense is None else _as(dense, torch.float32)
         dev = q.device
-        both = torch.empty((2, B, D), dtype=torch.float32, device=dev)  # retriever scores | dLoss/dScores
-        scores, d_scores = both.unbind(0)
-        # loss [1] | kl [3] | auxiliary terms [3] (the library writes all three: NaN where the weight is 0) | pad | workspace
-        n_work = 16 * B + (4 * B * D if not three_d else 0)  # + room for the split-K slabs of the in-batch contraction
-        small = torch.empty((8 + n_work,), dtype=torch.float32, device=dev)
-        loss, kl, aux, work = small[0], small[1:4], small[4:7], small[8:]
+        stream = _native.current_stream_ptr(dev)
+        # outputs: retriever scores | dLoss/dScores, and loss [1] | kl [3] | auxiliary terms [3] (NaN where the weight is 0) - fresh per
+        # call (the caller keeps them); the kernels' scratch (16 row words per query + the split-K slabs of the in-batch contraction)
+        # is cached per (device, stream, size): the next forward on the stream runs after this one has consumed it
+        both = torch.empty((2, B, D), dtype=torch.float32, device=dev)
+        small = torch.empty((8,), dtype=torch.float32, device=dev)
+        n_work = 16 * B + (4 * B * D if not three_d else 0)
+        key = (dev.index, stream, n_work)
+        work = _scratch.get(key)
+        if work is None:
+            if len(_scratch) > 64:
+                _scratch.clear()
+            work = _scratch[key] = torch.empty((n_work,), dtype=torch.float32, device=dev)
         g_type, w_g, w_ss, w_sd = aux_cfg
-        any_aux = w_g > 0 or w_ss > 0 or w_sd > 0
-        aux_grad = torch.empty((3, B, D), dtype=torch.float32, device=dev) if any_aux else None
-        with torch.cuda.device(dev):
+        aux_grad = torch.empty((3, B, D), dtype=torch.float32, device=dev) if (w_g > 0 or w_ss > 0 or w_sd > 0) else None
+        p_both, p_small = both.data_ptr(), small.data_ptr()
+        with _on_device(dev):
             _native.check(
                 lib.vodhip_retrieval_forward_aux(
                     qc.data_ptr(), sc.data_ptr(), _native.torch_dtype_code(enc), int(three_d), B, D, H,
                     score_c.data_ptr(), rel_c.data_ptr(),
                     None if sparse_c is None else sparse_c.data_ptr(), None if dense_c is None else dense_c.data_ptr(),
                     int(g_type), float(w_g), float(w_ss), float(w_sd),
-                    scores.data_ptr(), d_scores.data_ptr(), loss.data_ptr(), kl.data_ptr(), aux.data_ptr(),
-                    None if aux_grad is None else aux_grad.data_ptr(), work.data_ptr(), n_work, _native.current_stream_ptr(dev),
+                    p_both, p_both + 4 * B * D, p_small, p_small + 4, p_small + 16,
+                    None if aux_grad is None else aux_grad.data_ptr(), work.data_ptr(), n_work, stream,
                 )
             )
+        scores, d_scores = both[0], both[1]
         ctx.save_for_backward(qc, sc, d_scores)
         ctx.meta = (enc, three_d, B, D, H, q.dtype, s.dtype)
+        loss, kl, aux = small[0], small[1:4], small[4:7]
         ctx.mark_non_differentiable(scores, kl, aux)
         return loss, scores, kl, aux
 
@@ -81,12 +113,10 @@ class _RetrievalLoss(torch.autograd.Function):
         qc, sc, d_scores = ctx.saved_tensors
         enc, three_d, B, D, H, q_dt, s_dt = ctx.meta
         dev = qc.device
-        go = g_loss.detach()
-        if go.dtype is not torch.float32 or not go.is_contiguous():
-            go = go.float().contiguous()
+        go = g_loss if (g_loss.dtype is torch.float32 and g_loss.is_contiguous()) else g_loss.float().contiguous()
         dq = torch.empty((B, H), dtype=torch.float32, device=dev)
-        ds = torch.empty(tuple(sc.shape), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        ds = torch.empty(sc.shape, dtype=torch.float32, device=dev)
+        with _on_device(dev):
             _native.check(
                 lib.vodhip_retrieval_backward(
                     qc.data_ptr(), sc.data_ptr(), _native.torch_dtype_code(enc), int(three_d), B, D, H,
