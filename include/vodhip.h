@@ -175,7 +175,12 @@ int vodhip_node_index_reset(vodhip_node_index_t* index);
 int vodhip_node_index_ntotal(const vodhip_node_index_t* index, int64_t* out);
 int vodhip_node_index_n_shards(const vodhip_node_index_t* index);
 int vodhip_node_index_shard(vodhip_node_index_t* index, int g, vodhip_index_t** shard, int64_t* id_base, int* device);
-int vodhip_node_index_set_param(vodhip_node_index_t* index, const char* key, int64_t value);  /* on every shard */
+int vodhip_node_index_set_param(vodhip_node_index_t* index, const char* key, int64_t value);  /* on every shard; plus "host_staging" (below) */
+/* Topology, read once at create (hipDeviceCanAccessPeer both ways; peer access is enabled where possible): out[g] = 2 when shard g lives
+ * on devices[0] itself, 1 when it exchanges with devices[0] by direct peer copies (xGMI), 0 when it goes through pinned host memory
+ * (no peer access, or param "host_staging" = 1: every shard but the first takes that route - bring-up / tests on a 1-GPU box).
+ * Returns the number of shards. */
+int vodhip_node_index_peer_access(const vodhip_node_index_t* index, int* out, int n);
 /* The subset filter of vodhip_index_set_row_labels / _set_query_labels behind the one handle: `labels` = HOST int32 [n_rows] for the
  * global rows 0 .. n_rows-1 (NULL clears); `q_labels` = int32 [nq, n_per_query] of the NEXT searches' batches, host memory or on
  * devices[0] (`location`), caller-owned until cleared with NULL; replicated to every device with the queries. */

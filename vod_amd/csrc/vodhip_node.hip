@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -68,6 +69,18 @@ struct vodhip_node_index {
     const int32_t* q_labels = nullptr;  // the caller's per-query labels for the next searches (host, or devices[0])
     int q_labels_per_query = 0, q_labels_location = VODHIP_HOST;
     bool has_row_labels = false;
+    // topology (read once at create): can devices[0] and shard g's device copy into each other's memory directly?  A shard without
+    // peer access - or every shard but the first with `host_staging` set (bring-up, tests on a 1-GPU box) - exchanges its queries and
+    // its top-k list with devices[0] through pinned host memory instead (two DMA hops over PCIe, no xGMI)
+    std::vector<int> peer_ok;          // 2 = same device as devices[0], 1 = peer access both ways, 0 = none
+    int64_t host_staging = 0;
+    std::vector<void*> pin_res;        // per shard: pinned [scores f32 | ids i64] of its top-k list
+    std::vector<size_t> pin_res_elems;
+    std::vector<hipEvent_t> on_host;   // shard g's list is in pin_res[g]
+    void* pin_q = nullptr;             // the query batch (+ subset labels) staged from devices[0]
+    size_t pin_q_bytes = 0;
+    hipEvent_t q_on_host = nullptr;
+    bool staged(int g) const { return g > 0 && (host_staging != 0 || (device[g] != device[0] && peer_ok[g] == 0)); }
 };
 
 namespace {
@@ -103,6 +116,10 @@ int vodhip_node_index_create(int n_devices, const int* devices, int64_t dim, int
     nx->stream.assign(n_devices, nullptr);
     nx->arrived.assign(n_devices, nullptr);
     nx->buf.resize(n_devices);
+    nx->peer_ok.assign(n_devices, 2);
+    nx->pin_res.assign(n_devices, nullptr);
+    nx->pin_res_elems.assign(n_devices, 0);
+    nx->on_host.assign(n_devices, nullptr);
     auto bail = [&](int rc) {
         const std::string keep = vodhip_last_error();
         vodhip_node_index_destroy(nx);
@@ -119,9 +136,34 @@ int vodhip_node_index_create(int n_devices, const int* devices, int64_t dim, int
     }
     hipError_t e = hipSetDevice(devices[0]);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&nx->ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&nx->q_on_host, hipEventDisableTiming);
     if (e != hipSuccess) return bail(nfail("event creation failed: %s", hipGetErrorString(e)));
+    // topology: direct peer copies where both directions are possible (enabled here; "already enabled" is fine), host staging elsewhere
+    for (int g = 0; g < n_devices; ++g) {
+        if (devices[g] == devices[0]) continue;
+        int to = 0, from = 0;
+        if (hipDeviceCanAccessPeer(&to, devices[0], devices[g]) != hipSuccess) to = 0;
+        if (hipDeviceCanAccessPeer(&from, devices[g], devices[0]) != hipSuccess) from = 0;
+        nx->peer_ok[g] = (to && from) ? 1 : 0;
+        if (nx->peer_ok[g]) {
+            (void)hipSetDevice(devices[0]);
+            hipError_t pe = hipDeviceEnablePeerAccess(devices[g], 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) nx->peer_ok[g] = 0;
+            (void)hipSetDevice(devices[g]);
+            pe = hipDeviceEnablePeerAccess(devices[0], 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) nx->peer_ok[g] = 0;
+            (void)hipGetLastError();
+        }
+    }
+    (void)hipSetDevice(devices[0]);
     *out = nx;
     return 0;
+}
+
+int vodhip_node_index_peer_access(const vodhip_node_index_t* nx, int* out, int n) {
+    if (!nx || !out || n < nx->n) return nfail("invalid arguments");
+    for (int g = 0; g < nx->n; ++g) out[g] = nx->staged(g) ? 0 : nx->peer_ok[g];
+    return nx->n;
 }
 
 int vodhip_node_index_destroy(vodhip_node_index_t* nx) {
@@ -136,8 +178,12 @@ int vodhip_node_index_destroy(vodhip_node_index_t* nx) {
         (void)hipFree(nx->buf[g].ids);
         (void)hipFree(nx->buf[g].q_labels);
         if (nx->arrived[g]) (void)hipEventDestroy(nx->arrived[g]);
+        if (nx->on_host[g]) (void)hipEventDestroy(nx->on_host[g]);
+        if (nx->pin_res[g]) (void)hipHostFree(nx->pin_res[g]);
         if (nx->stream[g]) (void)hipStreamDestroy(nx->stream[g]);
     }
+    if (nx->pin_q) (void)hipHostFree(nx->pin_q);
+    if (nx->q_on_host) (void)hipEventDestroy(nx->q_on_host);
     if (nx->n && nx->shard[0]) (void)hipSetDevice(nx->device[0]);
     (void)hipFree(nx->gathered_scores);
     (void)hipFree(nx->gathered_ids);
@@ -239,6 +285,10 @@ int vodhip_node_index_set_query_labels(vodhip_node_index_t* nx, const int32_t* q
 
 int vodhip_node_index_set_param(vodhip_node_index_t* nx, const char* key, int64_t value) {
     if (!nx) return nfail("index is NULL");
+    if (key && !strcmp(key, "host_staging")) {  // 1: every shard but the first exchanges with devices[0] through pinned host memory
+        nx->host_staging = value;
+        return 0;
+    }
     for (int g = 0; g < nx->n; ++g)
         if (vodhip_index_set_param(nx->shard[g], key, value)) return -1;
     return 0;
@@ -285,10 +335,31 @@ int vodhip_node_index_search(vodhip_node_index_t* nx, const void* queries, int q
     // 1. the query batch reaches every device (replicated: nq * dim * 2-4 bytes), then every shard searches - all enqueued before
     //    anything is waited for, so the devices run side by side
     if (location == VODHIP_DEVICE) NODE_HIP_OK(hipEventRecord(nx->ready, user));  // the caller's stream has produced the queries
+    bool any_staged = false;
+    for (int g = 0; g < G; ++g) any_staged = any_staged || nx->staged(g);
+    const size_t lab_bytes = nx->q_labels ? (size_t)nq * (size_t)nx->q_labels_per_query * sizeof(int32_t) : 0;
+    const bool stage_q = any_staged && location == VODHIP_DEVICE, stage_lab = any_staged && nx->q_labels && nx->q_labels_location == VODHIP_DEVICE;
+    if (stage_q || stage_lab) {
+        // shards without peer access read the batch from pinned host memory: ONE copy down from devices[0], then one copy up per shard
+        const size_t want = q_bytes + lab_bytes + 64;
+        if (nx->pin_q_bytes < want) {
+            if (nx->pin_q) NODE_HIP_OK(hipHostFree(nx->pin_q));
+            nx->pin_q = nullptr;
+            NODE_HIP_OK(hipHostMalloc(&nx->pin_q, want + want / 4, hipHostMallocDefault));
+            nx->pin_q_bytes = want + want / 4;
+        }
+        if (stage_q) NODE_HIP_OK(hipMemcpyAsync(nx->pin_q, queries, q_bytes, hipMemcpyDeviceToHost, user));
+        if (stage_lab) NODE_HIP_OK(hipMemcpyAsync((char*)nx->pin_q + q_bytes, nx->q_labels, lab_bytes, hipMemcpyDeviceToHost, user));
+        NODE_HIP_OK(hipEventRecord(nx->q_on_host, user));
+    }
     for (int g = 0; g < G; ++g) {
         NODE_HIP_OK(hipSetDevice(nx->device[g]));
+        const bool staged = nx->staged(g);
         if (location == VODHIP_HOST) {
             NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q, queries, q_bytes, hipMemcpyHostToDevice, nx->stream[g]));
+        } else if (staged) {
+            NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], nx->q_on_host, 0));
+            NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q, nx->pin_q, q_bytes, hipMemcpyHostToDevice, nx->stream[g]));
         } else {
             NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], nx->ready, 0));
             if (nx->device[g] == dev0) NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q, queries, q_bytes, hipMemcpyDeviceToDevice, nx->stream[g]));
@@ -299,7 +370,10 @@ int vodhip_node_index_search(vodhip_node_index_t* nx, const void* queries, int q
             if (ensure((void**)&nx->buf[g].q_labels, &nx->buf[g].q_label_elems, n_lab, sizeof(int32_t))) return -1;
             if (nx->q_labels_location == VODHIP_HOST)
                 NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q_labels, nx->q_labels, n_lab * sizeof(int32_t), hipMemcpyHostToDevice, nx->stream[g]));
-            else if (nx->device[g] == dev0)
+            else if (staged) {
+                NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], nx->q_on_host, 0));
+                NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q_labels, (char*)nx->pin_q + q_bytes, n_lab * sizeof(int32_t), hipMemcpyHostToDevice, nx->stream[g]));
+            } else if (nx->device[g] == dev0)
                 NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q_labels, nx->q_labels, n_lab * sizeof(int32_t), hipMemcpyDeviceToDevice, nx->stream[g]));
             else
                 NODE_HIP_OK(hipMemcpyPeerAsync(nx->buf[g].q_labels, nx->device[g], nx->q_labels, dev0, n_lab * sizeof(int32_t), nx->stream[g]));
@@ -330,6 +404,26 @@ int vodhip_node_index_search(vodhip_node_index_t* nx, const void* queries, int q
         NODE_HIP_OK(hipSetDevice(nx->device[g]));
         float* ds = nx->gathered_scores + (size_t)g * res;
         int64_t* di = nx->gathered_ids + (size_t)g * res;
+        if (nx->staged(g)) {
+            // no peer access: the list goes down to pinned host memory on the shard's stream and up to devices[0] on the merge stream
+            if (nx->pin_res_elems[g] < res) {
+                if (nx->pin_res[g]) NODE_HIP_OK(hipHostFree(nx->pin_res[g]));
+                nx->pin_res[g] = nullptr;
+                NODE_HIP_OK(hipHostMalloc(&nx->pin_res[g], (res + res / 4 + 64) * 12, hipHostMallocDefault));
+                nx->pin_res_elems[g] = res + res / 4 + 64;
+            }
+            if (!nx->on_host[g]) NODE_HIP_OK(hipEventCreateWithFlags(&nx->on_host[g], hipEventDisableTiming));
+            char* pin = (char*)nx->pin_res[g];
+            NODE_HIP_OK(hipMemcpyAsync(pin, nx->buf[g].scores, res * sizeof(float), hipMemcpyDeviceToHost, nx->stream[g]));
+            NODE_HIP_OK(hipMemcpyAsync(pin + nx->pin_res_elems[g] * 4, nx->buf[g].ids, res * sizeof(int64_t), hipMemcpyDeviceToHost, nx->stream[g]));
+            NODE_HIP_OK(hipEventRecord(nx->on_host[g], nx->stream[g]));
+            NODE_HIP_OK(hipSetDevice(dev0));
+            NODE_HIP_OK(hipStreamWaitEvent(user, nx->on_host[g], 0));
+            NODE_HIP_OK(hipMemcpyAsync(ds, pin, res * sizeof(float), hipMemcpyHostToDevice, user));
+            NODE_HIP_OK(hipMemcpyAsync(di, pin + nx->pin_res_elems[g] * 4, res * sizeof(int64_t), hipMemcpyHostToDevice, user));
+            NODE_HIP_OK(hipEventRecord(nx->arrived[g], user));  // (the merge below runs on `user` anyway: this keeps the wait list uniform)
+            continue;
+        }
         if (nx->device[g] == dev0) {
             NODE_HIP_OK(hipMemcpyAsync(ds, nx->buf[g].scores, res * sizeof(float), hipMemcpyDeviceToDevice, nx->stream[g]));
             NODE_HIP_OK(hipMemcpyAsync(di, nx->buf[g].ids, res * sizeof(int64_t), hipMemcpyDeviceToDevice, nx->stream[g]));

@@ -331,6 +331,13 @@ class HipNodeIndex:
     def set_param(self, key: str, value: int) -> None:
         _native.check(self._lib.vodhip_node_index_set_param(self._h, key.encode(), int(value)))
 
+    def peer_access(self) -> list[int]:
+        """Per shard: 2 = on `devices[0]`, 1 = direct peer copies with it, 0 = staged through pinned host memory (no peer access, or
+        `set_param("host_staging", 1)`)."""
+        out = (ctypes.c_int32 * len(self.devices))()
+        _native.check(min(0, self._lib.vodhip_node_index_peer_access(self._h, out, len(self.devices))))
+        return list(out)
+
     def shard(self, g: int) -> tuple[int, int, int]:
         """(raw `vodhip_index_t*` of shard g, its id offset, its device) - for stats / params of one shard."""
         h, base, dev = ctypes.c_void_p(), ctypes.c_int64(), ctypes.c_int32()
