@@ -314,10 +314,11 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
     const bool abl_corpus_nt = (ex.flags & (16 << 8)) != 0;   // corpus LDS-DMA with the nt cache policy
     const bool abl_corpus_sc0 = (ex.flags & (32 << 8)) != 0;  // corpus LDS-DMA with sc0
     const bool abl_blocked = (ex.flags & (64 << 8)) != 0;     // corpus read AS IF stored [tile][k-slice][256 rows][128 B]: one tile = 384 contiguous KB (timing only)
+    const bool abl_q0 = (ex.flags & (128 << 8)) != 0;         // every q-tile reads the rows of q-tile 0: the query working set of an XCD shrinks from nq to 256 rows (bytes / timing only)
     if (abl_l2hot) tile_step_bytes = 0;
     if (abl_prio && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
 #else
-    constexpr bool abl_l2hot = false, abl_dma_early = false, abl_nosurv = false, abl_blocked = false;
+    constexpr bool abl_l2hot = false, abl_dma_early = false, abl_nosurv = false, abl_blocked = false, abl_q0 = false;
 #endif
 
     const int st_row = lane >> 3, st_slot = lane & 7;
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
 #pragma unroll
     for (int t = 0; t < NBI; ++t) {
         const int r = (wave * NBI + t) * RPI + st_row;
-        b_src[t] = (const char*)Q + ((size_t)(q0 + r) * dim_pad + (st_slot ^ ((r >> 1) & 7)) * 8) * 2;
+        b_src[t] = (const char*)Q + ((size_t)((abl_q0 ? 0 : q0) + r) * dim_pad + (st_slot ^ ((r >> 1) & 7)) * 8) * 2;
     }
     const bool corpus_nt = (ex.flags & FILTER_FLAG_CORPUS_NT) != 0;  // single q-tile: corpus lines are read once (nt cache policy)
     auto stage_part = [&](int slot, int kbyte, int part, int nparts) {
