@@ -1197,13 +1197,13 @@ hipError_t launch_filter(int store_dtype, int tile, int mode, const void* store,
     if (mode == MODE_GMAX && n_sample_tiles <= 0) return hipSuccess;
     const bool subset = ws.extra.row_label != nullptr;
     if (filter_tile_is_persistent(tile) && mode == MODE_DENSE) tile = 1;  // nq_pad is a multiple of 256, which the 128-wide tile divides
-    if (tile >= 10 && tile <= 12) {
+    if (tile >= 10 && tile <= 12) {  // experiment FILTER kernels: `make ABLATION=1 EXPERIMENTS=1` builds only (vodhip_index_set_param refuses the ids otherwise)
 #ifdef VODHIP_EXPERIMENTS
-        if (mode == MODE_FILTER && tile == 12)  // 384 x 256 workgroup tile: `make ABLATION=1 EXPERIMENTS=1` builds only
+        if (mode == MODE_FILTER && tile == 12)  // 384 x 256 workgroup tile
             return launch_filter_wide(store_dtype, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
-#endif
-        if (mode == MODE_FILTER && tile != 12)  // deep ring (10), with fragments read a k-step ahead (11): kernels_mips_ring.hip
+        if (mode == MODE_FILTER)  // deep ring (10), with fragments read a k-step ahead (11)
             return launch_filter_ring(store_dtype, tile == 11, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+#endif
         tile = 8;  // the bootstrap (group maxima of a row sample) runs on the two-slot kernel
     }
     const int bm = filter_tile_rows(tile);

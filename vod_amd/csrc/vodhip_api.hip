@@ -107,7 +107,6 @@ struct vodhip_index {
     int64_t force_safe = 0;
     int64_t tile = 0;
     int64_t kflags = 0;
-    int64_t ring_single_qtile = 1;    // auto tile choice: FILTER stages of batches of <= 256 queries run on the deep-ring kernel (tile 11)
     int64_t small_chunk_tiles = 256;  // launches with fewer 256x256 tiles than this (less than one per CU) use the 128x128 kernel
     int n_cu = 256;       // compute units of `device` (read once at create; the planner never touches the runtime)
     int64_t profile = 0;  // 1: bracket every filter launch with HIP events (bench / roofline accounting)
@@ -355,11 +354,6 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
                 // short FILTER stages do not fill the CUs with 256x256 tiles: those launches run on 128x128 tiles, 2 workgroups per CU
                 if (x_tiles * q_tiles < ix->small_chunk_tiles) {
                     tile_c = 1;
-                } else if (q_tiles == 1 && ix->ring_single_qtile) {
-                    // ONE q-tile: every corpus line is read once, from HBM, by one workgroup - the regime where the two-slot loop's
-                    // exposed first-touch wait costs most.  The deep ring (corpus requested two slices ahead, fragments read a k-step
-                    // ahead: kernels_mips_ring.hip) measures 1.6-1.8 % faster there and equal with more q-tiles
-                    tile_c = 11;
                 }
             }
             if (launch_one(tile_c, sg.b, sg.e)) return -1;
@@ -750,8 +744,6 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
         ix->force_safe = value;
     } else if (!strcmp(key, "small_chunk_tiles")) {
         ix->small_chunk_tiles = value;
-    } else if (!strcmp(key, "ring_single_qtile")) {
-        ix->ring_single_qtile = value;
     } else if (!strcmp(key, "kflags")) {
         ix->kflags = value;
     } else if (!strcmp(key, "sample_div")) {
@@ -764,12 +756,12 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
         ix->ingest_threads = value;
     } else if (!strcmp(key, "tile")) {
 #ifdef VODHIP_EXPERIMENTS
-        const bool wide_ok = true;  // tile 12: the 384 x 256 FILTER kernel of experiment builds
+        const bool ring_ok = true;  // tiles 10 / 11 / 12: the FILTER kernels of experiment builds
 #else
-        const bool wide_ok = false;
+        const bool ring_ok = false;
 #endif
-        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 10 && value != 11 && value != 42 && value != 46 && !(wide_ok && value == 12))
-            return fail("tile must be 0 (auto) or a filter-kernel variant id: 1, 8, 9, 10, 11, 42, 46 (DESIGN.md 4.2)");
+        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 42 && value != 46 && !(ring_ok && value >= 10 && value <= 12))
+            return fail("tile must be 0 (auto) or a filter-kernel variant id: 1, 8, 9, 42, 46 (DESIGN.md 4.1)");
         ix->tile = value;
     } else {
         return fail("unknown parameter '%s'", key);

@@ -303,7 +303,9 @@ bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
         const double est = b->estimate_ns(oldest->nq);
         if (est <= 0.0) return true;  // no estimate yet for a batch of that size: round 3's behaviour (enqueue behind at once)
         const double lead = std::max(300e3, 0.06 * est) + 0.15e3 * (double)pend_q;  // host-side submission: ~0.15 us per query to stage + copy
-        const tp_t jit = oldest->t_submit + std::chrono::nanoseconds((int64_t)(est - lead));
+        // (a batch that was itself enqueued behind another started to RUN when that one completed, not when it was submitted)
+        const tp_t started = oldest->pipeline_was_empty ? oldest->t_submit : std::max(oldest->t_submit, b->t_last_completion);
+        const tp_t jit = started + std::chrono::nanoseconds((int64_t)(est - lead));
         if (now >= jit) return true;
         *until = jit;
         return false;
@@ -351,11 +353,22 @@ Batch* assemble(vodhip_batcher* b) {
     bt->q_dtype = first->q_dtype;
     bt->subset = first->subset != nullptr;
     bt->n_subset = first->n_subset;
+    // A batch enqueued BEHIND a running one is cut to whole query tiles when it spans more than one: the kernels pad a batch to a
+    // multiple of 256 queries, so 11 requests of 64 queries (704 -> 768) or 21 (1344 -> 1536) waste 8-12 % of a scan, while the
+    // requests left behind lose nothing - they ride with the running batch's callers, who are about to come back.  (An idle engine
+    // takes everything: nothing is gained by leaving work behind then.)
+    int64_t budget = b->max_queries;
+    if (!b->inflight.empty() && !first->subset) {
+        int64_t pend_q = 0;
+        for (const Request* r : b->pending) pend_q += r->nq;
+        const int64_t tile = std::max<int64_t>(1, b->flat_queries);
+        if (pend_q > tile && pend_q % tile != 0) budget = std::min(budget, pend_q / tile * tile);
+    }
     // requests are taken in arrival order; one that does not fit this batch (other dtype, subset filter, no room) ends the batch
     while (!b->pending.empty()) {
         Request* r = b->pending.front();
         if (!bt->reqs.empty()) {
-            if (bt->subset || r->subset || r->q_dtype != bt->q_dtype || bt->nq + r->nq > b->max_queries) break;
+            if (bt->subset || r->subset || r->q_dtype != bt->q_dtype || bt->nq + r->nq > budget) break;
         }
         b->pending.pop_front();
         r->batch = bt;
