@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-3 measurement pass on the GPU box: for every workload a bench line, a rocprofv3 kernel trace + stats of the same
-# command, and three separate --pmc passes (never combined with other trace domains).  Results land in gpurun_out/r03/.
-# usage: tools/profile_r3.sh [workload ...]   (default: all)
+# Round-4 measurement pass on the GPU box: for every workload a bench line, a rocprofv3 kernel trace + stats of the same
+# command, and three separate --pmc passes (never combined with other trace domains).  Results land in gpurun_out/r04/.
+# usage: tools/profile_r4.sh [workload ...]   (default: all)
 set -u
 ROOTD=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOTD/gpurun_out/r03; mkdir -p $OUT
+OUT=$ROOTD/gpurun_out/r04; mkdir -p $OUT
 declare -A W
 W[c3]=""
 W[shard]="--rows 1250000"
@@ -13,7 +13,8 @@ W[c4]="--rows 40000000 --dim 1024 --nq 512 --k 200 --dtype bf16"
 W[c3nq256]="--nq 256"
 W[c3clustered]="--data clustered"
 W[shardfc]="--rows 1250000 --force-collective"
-LIST="${@:-c3 shard c2 c4 c3nq256 c3clustered shardfc}"
+W[c4shard]="--rows 5000000 --dim 1024 --nq 512 --k 200 --dtype bf16"
+LIST="${@:-c3 shard c2 c4 c4shard c3nq256 c3clustered shardfc}"
 cd /tmp && export TMPDIR=/tmp
 for w in $LIST; do
   a="${W[$w]}"
@@ -31,4 +32,9 @@ for w in $LIST; do
   find $OUT/${w}_prof $OUT/${w}_pmc_* -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*kernel_trace.csv" -delete 2>/dev/null
   find $OUT/${w}_pmc_* -name "*kernel_trace.csv" -delete 2>/dev/null
 done
+# C5: every kernel of the collate-side chain and of the retrieval loss (what the C5 side entry's launch counts refer to)
+if [[ " $LIST " == *" c3 "* ]]; then
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_prof -- python3 $ROOTD/tools/bench_c5.py > $OUT/c5_latency.json 2> $OUT/c5_prof.log
+  find $OUT/c5_prof -type f ! -name "*kernel_stats.csv" -delete 2>/dev/null
+fi
 ls $OUT | head -80
