@@ -1,7 +1,8 @@
 """Randomised campaign THROUGH the drop-in boundary: one spawned server (optionally with micro-batching, optionally the
 multi-worker group), several client threads firing random requests - `/search` (JSON lists), `/fast-search` (the reference's
 base64-npy codec), `/raw-search`, with and without subset ids, random batch sizes and k - every answer compared bit for bit
-with the fp64 oracle.      python3 tests/fuzz/fuzz_server.py [--requests 400] [--threads 8] [--wait-ms 5] [--group]
+with the fp64 oracle.      python3 tests/fuzz/fuzz_server.py [--requests 400] [--threads 8] [--wait-ms 0] [--group | --node] [--http native]
+(round 4: the server's defaults = libvodhip's native HTTP front + batch-while-busy request fusion; `--wait-ms` adds the optional window)
 """
 import argparse
 import concurrent.futures
@@ -21,8 +22,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--requests", type=int, default=400)
     ap.add_argument("--threads", type=int, default=8)
-    ap.add_argument("--wait-ms", type=float, default=5.0)
+    ap.add_argument("--wait-ms", type=float, default=0.0)
     ap.add_argument("--group", action="store_true", help="serve through the worker group (devices=[0, 0], gloo)")
+    ap.add_argument("--node", action="store_true", help="serve through the one-process node index (devices=[0, 0], group_backend=node)")
+    ap.add_argument("--http", default="native", choices=["native", "asyncio", "uvicorn"])
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
@@ -36,9 +39,10 @@ def main():
 
     class Master(HipMipsMaster):
         def _make_cmd(self):
-            return super()._make_cmd() + ["--subset-ids-path", f"{tmp}/subsets.npy", "--micro-batch-wait-ms", str(a.wait_ms)]
+            return super()._make_cmd() + ["--subset-ids-path", f"{tmp}/subsets.npy"]
 
-    kw = dict(devices=[0, 0], group_backend="gloo") if a.group else {}
+    kw = dict(devices=[0, 0], group_backend="gloo") if a.group else (dict(devices=[0, 0], group_backend="node") if a.node else {})
+    kw.update(http=a.http, micro_batch_wait_ms=a.wait_ms)
     jobs = []
     for j in range(a.requests):
         nq = int(rng.choice([1, 1, 2, 5, 17, 64, 130, 300]))
@@ -84,8 +88,8 @@ def main():
             errs = [e for e in ex.map(run, jobs) if e]
     for e in errs[:20]:
         print("FAIL", e)
-    print(f"fuzz_server: {len(jobs)} requests on {a.threads} threads ({'worker group x2' if a.group else 'single process'}, "
-          f"micro-batch wait {a.wait_ms} ms), {len(errs)} failures, {time.time() - t0:.0f} s")
+    print(f"fuzz_server: {len(jobs)} requests on {a.threads} threads ({'worker group x2' if a.group else ('node index x2' if a.node else 'single process')}, "
+          f"http {a.http}, extra wait window {a.wait_ms} ms, seed {a.seed}), {len(errs)} failures, {time.time() - t0:.0f} s")
     sys.exit(1 if errs else 0)
 
 

@@ -37,5 +37,12 @@ case $P in
         done
       done
     done ;;
+  fuzz)   # randomised campaigns at HEAD: the boundary (native front: single / window / worker group / node index; asyncio shell), search, collate
+    for args in "--requests 800 --threads 16 --seed 41" "--requests 600 --threads 16 --seed 42 --wait-ms 5" "--requests 500 --threads 12 --seed 43 --group" \
+                "--requests 500 --threads 12 --seed 44 --node" "--requests 400 --threads 12 --seed 45 --http asyncio"; do
+      timeout 900 python tests/fuzz/fuzz_server.py $args 2>/dev/null | tail -3 | tee -a $OUT/fuzz_server.txt
+    done
+    timeout 1500 python tests/fuzz/fuzz_search.py --trials 3000 --seed 404 2>/dev/null | tail -3 | tee -a $OUT/fuzz_search.txt
+    timeout 1500 python tests/fuzz/fuzz_collate.py --trials 6000 --seed 405 2>/dev/null | tail -3 | tee -a $OUT/fuzz_collate.txt ;;
   *) echo "unknown pass $P"; exit 2 ;;
 esac
