@@ -1,12 +1,18 @@
 /* A plain C99 consumer of include/vodhip.h: no Python, no torch, no C++.
  * Builds an index from host float32 rows, searches it with device buffers from the HIP runtime's C API, and checks the
  * result against a brute-force loop (integer-valued data: every dot product is exact in fp32; ties -> smaller id); repeats the
- * search through the one-process node index (three shards); then runs
+ * search through the one-process node index (three shards); serves it - request fusion (`vodhip_batcher`) and the native HTTP front
+ * (`vodhip_http`: POST /raw-search over a plain socket, the fallback callback for GET /) - with no interpreter in the process; then runs
  * the collate-side chain (merge -> sampling) through `vodhip_collate` on the SURVEY's hand-written three-engine case.
  * Built and run by tests/test_c_abi.py:  gcc -std=c99 abi_smoke.c -I include -I /opt/rocm/include -lvodhip -lamdhip64 */
 #define __HIP_PLATFORM_AMD__ 1
+#define _POSIX_C_SOURCE 200809L
+#include <arpa/inet.h>
 #include <hip/hip_runtime_api.h>
 #include <math.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -95,6 +101,87 @@ static int collate_case(void) {
     return 0;
 }
 
+/* ---- the serving layer from C: what a non-Python host (C, cgo, JNI) runs instead of the reference's uvicorn process ---- */
+static void fallback(void* user, const char* method, const char* target, const uint8_t* body, int64_t n_body, uint64_t client,
+                     vodhip_http_reply_t* reply) {
+    (void)user; (void)body; (void)n_body; (void)client;
+    if (!strcmp(method, "GET") && !strcmp(target, "/")) {
+        vodhip_http_reply_set(reply, 200, "application/json", (const uint8_t*)"\"OK\"", 4, NULL);
+    } else {
+        const char* msg = "{\"detail\":\"Not Found\"}";
+        vodhip_http_reply_set(reply, 404, "application/json", (const uint8_t*)msg, (int64_t)strlen(msg), NULL);
+    }
+}
+
+static int http_exchange(int port, const char* head, const void* body, size_t n_body, char* out, size_t cap, size_t* n_out) {
+    int fd = socket(AF_INET, SOCK_STREAM, 0);
+    struct sockaddr_in sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sin_family = AF_INET;
+    sa.sin_port = htons((unsigned short)port);
+    sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+    if (fd < 0 || connect(fd, (struct sockaddr*)&sa, sizeof sa) != 0) return -1;
+    if (send(fd, head, strlen(head), 0) < 0 || (n_body && send(fd, body, n_body, 0) < 0)) return -1;
+    size_t got = 0;
+    for (;;) {  /* "connection: close" requests: read until the server closes */
+        ssize_t r = recv(fd, out + got, cap - got, 0);
+        if (r <= 0) break;
+        got += (size_t)r;
+    }
+    close(fd);
+    *n_out = got;
+    return 0;
+}
+
+static int serving_case(vodhip_index_t* ix, const float* q, int64_t nq, int64_t d, int k, const float* want_s, const int64_t* want_i,
+                        int64_t id_base) {
+    vodhip_batcher_t* b = NULL;
+    vodhip_http_t* h = NULL;
+    CHECK(vodhip_batcher_create(ix, NULL, NULL, NULL, d, id_base, &b));
+    float* s = (float*)malloc(sizeof(float) * nq * k);
+    int64_t* id = (int64_t*)malloc(sizeof(int64_t) * nq * k);
+    CHECK(vodhip_batcher_search(b, q, VODHIP_F32, nq, k, NULL, 0, 7u, s, id));  /* host pointers in and out */
+    for (int64_t e = 0; e < nq * k; ++e)
+        if (id[e] != want_i[e] || s[e] != want_s[e]) { fprintf(stderr, "batcher entry %lld differs\n", (long long)e); return 1; }
+    if (vodhip_batcher_search(b, q, VODHIP_F32, nq, 0, NULL, 0, 7u, s, id) == 0) { fprintf(stderr, "batcher accepted k = 0\n"); return 1; }
+    CHECK(vodhip_http_create(b, d, fallback, NULL, 64 << 20, &h));
+    const int port = vodhip_http_listen_tcp(h, "127.0.0.1", 0);
+    if (port <= 0) { fprintf(stderr, "listen: %s\n", vodhip_last_error()); return 1; }
+    CHECK(vodhip_http_start(h));
+    /* POST /raw-search?top_k=K with the .npy bytes of the queries (header from the library's own writer) */
+    uint8_t npy_head[192];
+    const int64_t n_head = vodhip_wire_npy_header(VODHIP_F32, nq, d, npy_head, sizeof npy_head);
+    const size_t n_body = (size_t)n_head + sizeof(float) * (size_t)(nq * d);
+    uint8_t* body = (uint8_t*)malloc(n_body);
+    memcpy(body, npy_head, (size_t)n_head);
+    memcpy(body + n_head, q, sizeof(float) * (size_t)(nq * d));
+    char head[256];
+    snprintf(head, sizeof head, "POST /raw-search?top_k=%d HTTP/1.1\r\nHost: x\r\nConnection: close\r\nContent-Length: %zu\r\n\r\n", k, n_body);
+    const size_t cap = 4096 + (size_t)(nq * k) * 12;
+    char* reply = (char*)malloc(cap);
+    size_t n_reply = 0;
+    if (http_exchange(port, head, body, n_body, reply, cap, &n_reply) != 0) { fprintf(stderr, "http exchange failed\n"); return 1; }
+    if (n_reply < 16 || strncmp(reply, "HTTP/1.1 200", 12) != 0) { fprintf(stderr, "raw-search: %.80s\n", reply); return 1; }
+    const char* payload = NULL;
+    for (size_t i = 0; i + 3 < n_reply; ++i)
+        if (!memcmp(reply + i, "\r\n\r\n", 4)) { payload = reply + i + 4; break; }
+    if (!payload || (size_t)(reply + n_reply - payload) != (size_t)(nq * k) * 12) { fprintf(stderr, "raw-search payload size\n"); return 1; }
+    if (memcmp(payload, want_s, sizeof(float) * (size_t)(nq * k)) != 0 ||
+        memcmp(payload + sizeof(float) * (size_t)(nq * k), want_i, sizeof(int64_t) * (size_t)(nq * k)) != 0) {
+        fprintf(stderr, "raw-search reply differs from the direct search\n");
+        return 1;
+    }
+    if (http_exchange(port, "GET / HTTP/1.1\r\nHost: x\r\nConnection: close\r\n\r\n", NULL, 0, reply, cap, &n_reply) != 0 ||
+        !strstr(reply, "\"OK\"")) { fprintf(stderr, "GET / through the fallback failed\n"); return 1; }
+    int64_t n_native = 0;
+    CHECK(vodhip_http_get_stat(h, "requests_native", &n_native));
+    if (n_native != 1) { fprintf(stderr, "requests_native = %lld\n", (long long)n_native); return 1; }
+    CHECK(vodhip_http_destroy(h));
+    CHECK(vodhip_batcher_destroy(b));
+    free(s); free(id); free(body); free(reply);
+    return 0;
+}
+
 int main(void) {
     const int64_t n = 30000, d = 96, nq = 37;
     const int k = 12;
@@ -149,6 +236,7 @@ int main(void) {
         fprintf(stderr, "k = 0 was not rejected\n");
         return 1;
     }
+    if (serving_case(ix, q, nq, d, k, hs, hi, 1000) != 0) return 1;
     CHECK(vodhip_index_destroy(ix));
     /* the same rows behind the one-process node index, three shards (all on device 0 here), host buffers in and out: must give
      * the single index's answer (ids without the +1000 offset) */

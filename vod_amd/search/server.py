@@ -383,6 +383,7 @@ class NodeHipEngine:
             for rows in synthetic_rows(torch, torch.device("cuda", devices[0]), 0, n, d, int(seed or 0)):
                 self.index.add(rows.to(torch.float16).cpu().numpy())
             self.n_store = n
+            self._log_topology()
             return
         vectors = store.open_vectors(vectors_path)
         n, d = vectors.shape
@@ -403,6 +404,14 @@ class NodeHipEngine:
             uniq, codes = np.unique(ids.astype(str), return_inverse=True)
             self.vocab = {str(u): i for i, u in enumerate(uniq)}
             self.index.set_row_labels(codes.astype(np.int32))
+        self._log_topology()
+
+    def _log_topology(self) -> None:
+        import logging
+
+        how = {2: "on the merge device", 1: "direct peer copies", 0: "staged through pinned host memory (no peer access)"}
+        for g, (dev, p) in enumerate(zip(self.index.devices, self.index.peer_access())):
+            logging.getLogger(__name__).info("node index: shard %d on device %d: %s", g, dev, how.get(p, p))
 
     @property
     def ntotal(self) -> int:
