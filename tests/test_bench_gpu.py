@@ -170,6 +170,11 @@ def test_bench_default_line_carries_the_side_workloads():
     assert c5["collate_merge_sample"]["host_syncs"] == 0 and c5["collate_merge_sample_flatten"]["host_syncs"] == 0
     assert 0 < c5["collate_merge_sample"]["device_us"] < c5["collate_merge_sample"]["wall_us"] < 2000
     assert c5["retrieval_loss_inbatch_64x2048"]["fwd_bwd_wall_us"] > 0
+    # the tier's "CPU path timed beside it", for C5: the reference's numba loops restated in C on the host cores (and used as the checker of
+    # the device chain on the same inputs), and the reference's H5 op sequence restated in eager torch on the same GPU
+    assert c5["cpu_baseline"]["value"] > 0 and c5["cpu_baseline"]["kind"] == "port" and c5["cpu_baseline"]["device_chain_equals_cpu_restatement"] is True
+    for shape in ("retrieval_loss_3d_64x32", "retrieval_loss_inbatch_64x2048"):
+        assert c5["reference_op_sequence"][shape]["fwd_bwd_wall_us"] > 0 and c5["reference_op_sequence"][shape]["fused_equals_op_sequence"] is True
     assert rec["comm"]["world_size"] == 1 and rec["comm"]["ranks_in_first_all_reduce"] == 1  # (the exchange side line brought RCCL up)
     assert {"bound", "mfma_frac_of_2.5PF", "hbm_frac_at_8TBps", "frac", "achieved", "peak", "traffic"} <= set(rec["roofline"])
     assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["threads"] >= 1 and rec["cpu_baseline"]["cores"] >= 1
