@@ -959,3 +959,93 @@ def test_native_wire_pieces_match_numpy_and_the_python_codec():
         out = ctypes.create_string_buffer(need)
         assert lib.vodhip_wire_fast_search_reply(scores.ctypes.data, ids.ctypes.data, nq, k, out, need) == need
         assert out.raw == want
+
+
+def test_native_http_front_survives_malformed_and_hostile_requests():
+    """The native front parses untrusted bytes in C++: random mutations of valid requests, truncated heads and bodies, lying
+    Content-Lengths, binary junk, oversized heads - every connection must end in a well-formed HTTP reply or a clean close, never a
+    crash or a hang, and a valid request must still be answered bit-exactly afterwards (and between the attacks)."""
+    import socket as _socket
+
+    from oracle.flat_ip import flat_ip_topk
+
+    rng = np.random.default_rng(99)
+    x = rng.integers(-4, 5, size=(300, 8)).astype(np.float32)
+    q = rng.integers(-4, 5, size=(4, 8)).astype(np.float32)
+    port, stop = _serve_in_thread(_OracleEngine(x), shell="native")
+    try:
+        good_fast = bytes(vio.json_body_with_arrays({"vectors": q}, {"top_k": 5}))
+        buf = __import__("io").BytesIO()
+        np.save(buf, q)
+        good_raw = buf.getvalue()
+
+        def head(path, n, extra=b""):
+            return b"POST " + path + b" HTTP/1.1\r\nHost: x\r\n" + extra + b"Content-Length: " + str(n).encode() + b"\r\n\r\n"
+
+        def exchange(payload: bytes, wait=0.5) -> bytes:
+            s = _socket.create_connection(("127.0.0.1", port), timeout=5)
+            s.settimeout(wait)
+            got = b""
+            try:
+                s.sendall(payload)
+                try:
+                    s.shutdown(_socket.SHUT_WR)
+                except OSError:
+                    pass
+                while True:
+                    chunk = s.recv(65536)
+                    if not chunk:
+                        break
+                    got += chunk
+            except (OSError, _socket.timeout):
+                pass
+            finally:
+                s.close()
+            return got
+
+        def check_alive():
+            c = vclient.HipMipsClient("http://127.0.0.1", port)
+            res = c.search(vector=q, top_k=5)
+            rs, ri = flat_ip_topk(q, x, 5)
+            np.testing.assert_array_equal(res.indices, ri)
+            np.testing.assert_array_equal(res.scores, rs)
+
+        attacks = [
+            b"", b"\r\n\r\n", b"GET", b"POST /fast-search HTTP/1.1\r\n\r\n", b"\x00" * 5000, bytes(rng.integers(0, 256, size=3000, dtype=np.uint8)),
+            head(b"/fast-search", len(good_fast) + 50) + good_fast,                       # body shorter than announced, then EOF
+            head(b"/fast-search", 10) + good_fast,                                         # body longer than announced (rest parsed as a request)
+            head(b"/fast-search", 2 ** 62),                                                # absurd length -> 413
+            b"POST /fast-search HTTP/1.1\r\nContent-Length: -5\r\n\r\n", b"POST /fast-search HTTP/1.1\r\nContent-Length: 1e3\r\n\r\n",
+            b"POST /fast-search HTTP/1.1\r\n" + b"X-Pad: " + b"a" * 70000 + b"\r\n\r\n",    # 64 KB of headers -> 431
+            head(b"/fast-search", 9) + b'{"vectors',                                       # truncated JSON
+            head(b"/fast-search", 2) + b"{}", head(b"/fast-search", 4) + b"null", head(b"/fast-search", 27) + b'{"vectors": "", "top_k": 3}',
+            head(b"/fast-search", 34) + b'{"vectors": "!!!!####", "top_k": 3}',
+            head(b"/raw-search?top_k=5", 20) + b"\x93NUMPY\x01\x00\xff\xff" + b"x" * 10,        # header length beyond the body
+            head(b"/raw-search?top_k=5", len(good_raw) - 7) + good_raw[:-7],                    # truncated data
+            head(b"/raw-search?top_k=99999999999999999999", len(good_raw)) + good_raw,
+            head(b"/raw-search?top_k=5&x=" + b"y" * 3000, len(good_raw)) + good_raw,
+        ]
+        for a in attacks:
+            reply = exchange(a)
+            assert reply == b"" or reply.startswith(b"HTTP/1.1 "), reply[:80]
+        check_alive()
+        # random mutations of the two valid requests: flip / delete / insert bytes anywhere (head and body)
+        for trial in range(300):
+            base = bytearray((head(b"/fast-search", len(good_fast)) + good_fast) if trial % 2 else (head(b"/raw-search?top_k=5", len(good_raw)) + good_raw))
+            for _ in range(int(rng.integers(1, 6))):
+                pos = int(rng.integers(0, len(base)))
+                op = int(rng.integers(0, 3))
+                if op == 0:
+                    base[pos] = int(rng.integers(0, 256))
+                elif op == 1:
+                    del base[pos : pos + int(rng.integers(1, 9))]
+                else:
+                    base[pos:pos] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 9)), dtype=np.uint8))
+            reply = exchange(bytes(base), wait=0.3)
+            assert reply == b"" or reply.startswith(b"HTTP/1.1 "), (trial, reply[:80])
+            if trial % 60 == 59:
+                check_alive()
+        check_alive()
+        assert stop.front.get_stat("open_connections") <= 2  # nothing leaked: the attack connections are gone
+    finally:
+        stop()

@@ -181,3 +181,42 @@ def test_no_peer_access_route_staged_through_pinned_host_memory(location):
         s, i = nx.search(q, k, subset=sub)
         np.testing.assert_array_equal(i, mi)
         np.testing.assert_array_equal(s, ms)
+
+
+def test_row_labels_set_on_a_non_blocking_stream_survive_the_initial_fill():
+    """Found by the round-4 campaign (fuzz_search seed 404, trial 1051): the FIRST `set_row_labels` of an index allocated the label array,
+    filled it with -1 on the NULL stream and copied the labels on the caller's stream - the node index's shard streams are non-blocking, so
+    the fill could land after the copy and every restricted query came back empty.  Run in a fresh process (the race needs the first,
+    slow, memset of a process) several times: every restricted row must match the masked oracle."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = f"""
+import sys
+import numpy as np
+sys.path.insert(0, {str(ROOT)!r})
+from oracle.flat_ip import topk_desc_tiebreak
+from vod_amd.index import HipNodeIndex
+rng = np.random.default_rng(3)
+n, d, nq, k = 9000, 65, 300, 128
+x = rng.integers(-8, 9, size=(n, d)).astype(np.float32)
+q = rng.integers(-8, 9, size=(nq, d)).astype(np.float32)
+labels = rng.integers(0, 6, size=n).astype(np.int32)
+sub = np.full((nq, 2), -1, dtype=np.int32)
+sub[::2] = [5, 2]
+nx = HipNodeIndex(d, n, [0])
+nx.add(x)
+nx.set_row_labels(labels)
+s, i = nx.search(q, k, subset=sub)
+full = q.astype(np.float64) @ x.astype(np.float64).T
+for r in range(0, nq, 2):
+    full[r, ~np.isin(labels, [5, 2])] = np.nan
+rs, ri = topk_desc_tiebreak(full, k)
+assert np.array_equal(i, ri) and np.array_equal(s, rs), int((i != ri).any(axis=1).sum())
+print("ok")
+"""
+    for _ in range(3):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:] + out.stdout[-300:]

@@ -410,6 +410,9 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
         return fail("hipMalloc of the %zu-byte vector store failed: %s", bytes, hipGetErrorString(e));
     }
     e = hipMemset(ix->data, 0, bytes);
+    // hipMemset of device memory returns before the fill has run; rows are ingested (and searched) on streams that do not order
+    // themselves behind the null stream (the batcher's and the node index's are non-blocking): the fill must be over before any of that
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->ovf_q, MAX_IN_FLIGHT * OVF_ROWS * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc((void**)&ix->q_map, MAX_IN_FLIGHT * OVF_ROWS * sizeof(int));
     if (e == hipSuccess) e = hipHostMalloc((void**)&ix->overflow_host, MAX_IN_FLIGHT * sizeof(unsigned int), hipHostMallocDefault);
@@ -572,11 +575,15 @@ int vodhip_index_set_row_labels(vodhip_index_t* ix, const int32_t* labels, int64
         return 0;
     }
     if (n_rows < 0 || n_rows > ix->capacity) return fail("n_rows=%lld out of range", (long long)n_rows);
+    hipStream_t stream = (hipStream_t)stream_;
     if (!ix->row_label) {
         HIP_OK(hipMalloc((void**)&ix->row_label, (size_t)ix->capacity_pad * sizeof(int)));
-        HIP_OK(hipMemset(ix->row_label, 0xFF, (size_t)ix->capacity_pad * sizeof(int)));  // -1: matches no query label
+        // -1: matches no query label.  On the SAME stream as the copy below: a null-stream hipMemset is not ordered before work on a
+        // non-blocking stream (the node index's shard streams), and the late fill wiped the labels just copied - every restricted query
+        // of the FIRST filtered search of a process came back empty (round 4, fuzz_search seed 404 trial 1051: found, fixed, pinned by
+        // tests/test_node_index_gpu.py::test_row_labels_set_on_a_non_blocking_stream_survive_the_initial_fill)
+        HIP_OK(hipMemsetAsync(ix->row_label, 0xFF, (size_t)ix->capacity_pad * sizeof(int), stream));
     }
-    hipStream_t stream = (hipStream_t)stream_;
     HIP_OK(hipMemcpyAsync(ix->row_label, labels, (size_t)n_rows * sizeof(int),
                           location == VODHIP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
     HIP_OK(hipStreamSynchronize(stream));
