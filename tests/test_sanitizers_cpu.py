@@ -1,0 +1,39 @@
+"""The native serving layer (vod_amd/csrc/vodhip_serve.hip: scheduler / completion threads, caller hand-off, one thread per HTTP
+connection, the wire parsers, the shutdown paths) under ThreadSanitizer and AddressSanitizer.  GPU sanitizers are not available on the
+pool, so the file is compiled as HOST C++ and driven by tests/sanitize/serve_stress.cpp with a callback engine (exact brute force on the
+host): 12 threads x 40 requests through `vodhip_batcher_search` and through real sockets, engine failures, non-`.npy` bodies through the
+fallback, and a shutdown with clients still connected.  Any sanitizer report fails the test."""
+import pathlib
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address"])
+def test_serving_layer_is_clean_under(sanitizer, tmp_path):
+    if not pathlib.Path(CLANG).exists() or not pathlib.Path("/opt/rocm/include/hip/hip_runtime.h").exists():
+        pytest.skip("ROCm clang++ / HIP headers not available")
+    from vod_amd.build import build_native
+
+    build_native()  # the harness links the (uninstrumented) library for the index entry points the batcher references
+    exe = tmp_path / f"serve_stress_{sanitizer}"
+    libdir = ROOT / "vod_amd" / "csrc"
+    cmd = [CLANG, "-std=c++17", "-g", "-O1", f"-fsanitize={sanitizer}", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-x", "c++",
+           str(libdir / "vodhip_serve.hip"), str(ROOT / "tests" / "sanitize" / "serve_stress.cpp"), "-I", str(ROOT / "include"), "-I", str(libdir),
+           "-I", "/opt/rocm/include", "-L", str(libdir), "-lvodhip", "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}",
+           "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", str(exe)]
+    built = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if built.returncode != 0 and "sanitizer" in built.stderr.lower() and "unsupported" in built.stderr.lower():
+        pytest.skip(f"-fsanitize={sanitizer} is not supported by this toolchain")
+    assert built.returncode == 0, built.stderr[-3000:]
+    assert shutil.which("true")
+    env = {"TSAN_OPTIONS": "halt_on_error=0 exitcode=66", "ASAN_OPTIONS": "detect_leaks=1 exitcode=66", "PATH": "/usr/bin:/bin"}
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900, env=env)
+    text = out.stdout + out.stderr
+    assert "Sanitizer" not in text, text[-4000:]
+    assert out.returncode == 0 and "0 errors" in out.stdout, text[-2000:]
