@@ -152,6 +152,18 @@ def test_bench_two_ranks_only_one_shard_overflows_stays_collective_safe():
     assert rec["verify"]["max_abs_score_diff"] < 1e-3
 
 
+def test_bench_eight_ranks_sharing_the_gpu_headline_shape():
+    """The driver's widest launch, `python bench.py --gpus 8`, end to end on real kernels: eight fresh ranks (gloo, sharing the box's one
+    GPU - RCCL refuses that), the headline's generation-chunk sharding (2 M rows = 8 chunks of 250 k), one packed all-gather + 8-way merge
+    per step, the fp64 verification merged over the ranks, and the `comm` record of the line."""
+    rec = _run_bench("--gpus", "8", "--backend", "gloo", "--rows", "2000000", "--dim", "128", "--nq", "512", "--k", "100", "--steps", "3",
+                     "--warmup", "1", "--no-cpu-baseline", "--verify-queries", "32", timeout=1200)
+    assert rec["n_gpus"] == 8 and rec["config"]["rows_per_gpu"] == 250_000 and rec["scaling"] == "strong"
+    assert rec["comm"]["world_size"] == 8 and rec["comm"]["ranks_in_first_all_reduce"] == 8 and rec["comm"]["backend"] == "gloo"
+    assert rec["verify"]["recall_at_k"] == 1.0 and rec["verify"]["max_abs_score_diff"] < 1e-3
+    assert "all-gather" in rec["config"]["parallelism"]
+
+
 def test_bench_default_line_carries_the_side_workloads():
     """The default 1-GPU run appends C2, nq = 256, clustered C3 and the 1.25 M-row shard with the exchange as `side`
     (small row counts here: the plumbing, not the numbers)."""
