@@ -29,7 +29,7 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def _worker(client, nq, dim, k, seconds, barrier, out_q, seed):
+def _worker(client, nq, dim, k, seconds, barrier, out_q, seed, think_ms=0.0):
     rng = np.random.default_rng(seed)
     q = rng.standard_normal((nq, dim), dtype=np.float32)
     for _ in range(3):
@@ -41,14 +41,16 @@ def _worker(client, nq, dim, k, seconds, barrier, out_q, seed):
         t0 = time.perf_counter()
         res = client.search(vector=q, top_k=k)
         lat.append(time.perf_counter() - t0)
+        if think_ms > 0:  # an open-ish loop: the worker "tokenises its next batch" for an Exp(think_ms) time before it searches again
+            time.sleep(float(rng.exponential(think_ms)) / 1e3)
     assert res.indices.shape == (nq, k)
     out_q.put(lat)
 
 
-def run_cell(client, P, nq, dim, k, seconds, stats=lambda: {}):
+def run_cell(client, P, nq, dim, k, seconds, stats=lambda: {}, think_ms=0.0):
     ctx = mp.get_context("spawn")
     barrier, out_q = ctx.Barrier(P + 1), ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(client, nq, dim, k, seconds, barrier, out_q, 100 + i)) for i in range(P)]
+    procs = [ctx.Process(target=_worker, args=(client, nq, dim, k, seconds, barrier, out_q, 100 + i, think_ms)) for i in range(P)]
     for p in procs:
         p.start()
     barrier.wait()
@@ -84,6 +86,9 @@ def main():
     ap.add_argument("--http", default="native", choices=["native", "asyncio", "uvicorn"])
     ap.add_argument("--routes", nargs="+", default=["fast", "raw"], choices=["fast", "raw"])
     ap.add_argument("--batcher-param", action="append", default=[], metavar="KEY=VALUE")
+    ap.add_argument("--think-ms", type=float, nargs="+", default=[0.0],
+                    help="mean of an exponential pause between a worker's requests (0 = closed loop, the default cells); > 0 shows what the "
+                         "fusion policy costs / gives when arrivals are not synchronised by the server itself")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import torch
@@ -136,9 +141,10 @@ def main():
 
             for binary in [r == "raw" for r in a.routes]:
                 client = HipMipsClient(host=master.host, port=master.port, binary=binary)
-                for P in a.clients:
-                    for nq in a.nq:
-                        cell = run_cell(client, P, nq, a.dim, a.k, a.seconds, stats)
+                for P, nq, think in [(P, nq, th) for th in a.think_ms for P in a.clients for nq in a.nq]:
+                    if True:
+                        cell = run_cell(client, P, nq, a.dim, a.k, a.seconds, stats, think)
+                        cell["think_ms"] = think
                         fused = str(min(2048, P * nq))
                         cell.update(route="/raw-search" if binary else "/fast-search", micro_batch_wait_ms=mb,
                                     device_resident_qps_at_fused_batch=out["device_resident"][fused]["qps"],

@@ -44,5 +44,8 @@ case $P in
     done
     timeout 1500 python tests/fuzz/fuzz_search.py --trials 3000 --seed 404 2>/dev/null | tail -3 | tee -a $OUT/fuzz_search.txt
     timeout 1500 python tests/fuzz/fuzz_collate.py --trials 6000 --seed 405 2>/dev/null | tail -3 | tee -a $OUT/fuzz_collate.txt ;;
+  openloop)  # arrivals NOT synchronised by the server: workers pause Exp(think) between requests; default policy vs never waiting for company
+    timeout 900 python tools/bench_http_load.py --routes fast --clients 8 32 --nq 32 --think-ms 2 10 --out $OUT/http_openloop_default.json > $OUT/openloop_default.log 2>&1; tail -5 $OUT/openloop_default.log | cut -c1-330
+    timeout 900 python tools/bench_http_load.py --routes fast --clients 8 32 --nq 32 --think-ms 2 10 --batcher-param grace_us=0 --out $OUT/http_openloop_nograce.json > $OUT/openloop_nograce.log 2>&1; tail -5 $OUT/openloop_nograce.log | cut -c1-330 ;;
   *) echo "unknown pass $P"; exit 2 ;;
 esac
