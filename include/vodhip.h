@@ -113,7 +113,10 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
  *   scored densely, default 2048), "sample_div" (the threshold bootstrap scores ~ntotal / sample_div sampled rows, default 96),
  *   "growth" (x100: a filter stage covers growth x the rows its threshold was calibrated on, default 800),
  *   "force_safe" (1 = exhaustive schedule: dense chunks of <= cand_cap rows), "tile" (0 = auto; 1 = 128x128, 42 / 46 = small-batch
- *   rings, 8 / 9 = persistent 256x256 without / with the wave stagger), "small_chunk_tiles", "profile" (1 = HIP events around
+ *   rings, 8 / 9 = persistent 256x256 without / with the wave stagger), "small_chunk_tiles", "no_prepare" (default 1: a search whose
+ *   queries have the store dtype, a 64-aligned dimension, whole query tiles and 16-byte alignment reads them IN PLACE and starts without
+ *   the prepare launch when the previous search on the handle had the same padded batch and k bucket - its final select left the state
+ *   empty; 0 = always prepare), "profile" (1 = HIP events around
  *   every filter launch), "ingest_threads" (CPU threads staging pageable host rows, 0 = auto), "kflags" (timing knobs of
  *   diagnostic builds).
  * stats (of the search completed by the last vodhip_index_search_finish): "last_overflow" (a candidate list overflowed),
@@ -394,7 +397,8 @@ int64_t vodhip_b64url_decode(const char* src, int64_t n, uint8_t* out);
  *     runs with k = max(k_i) and a prefix of a top-k' list is the top-k.
  *   policy (no fixed wait window): a request that finds the engine idle runs at once, unless other clients that searched a moment
  *     ago have nothing pending yet and the batch still fits one query tile ("flat_queries", 256: the scan costs the same with them
- *     aboard) - then it waits for them at most min("grace_us", "grace_pct" % of a measured scan); requests that arrive while a batch
+ *     aboard) and are DUE (their usual come-back time after an answer, an EMA per client, ends before the grace does) - then it waits for
+ *     them at most min("grace_us", "grace_pct" % of a measured scan); requests that arrive while a batch
  *     is on the device are fused, and enqueued behind it once they exceed one query tile (time is linear from there) or when it
  *     completes.  params: "max_queries" (2048), "flat_queries", "grace_us" (1000; 0 = never wait), "grace_pct" (35), "window_us"
  *     (0; > 0 = additionally wait this long for company, round 3's --micro-batch-wait-ms), "depth" (2).

@@ -847,21 +847,23 @@ def test_native_batcher_waits_for_expected_company_only():
     eng = Timed(x)
     mb = NativeBatcher(engine=eng, dim=8, grace_us=30_000, grace_pct=60)   # grace = min(30 ms, 60 % of the measured scan) = 24 ms
     q = rng.integers(-4, 5, size=(2, 8)).astype(np.float32)
-    t0 = time.monotonic()
+    lone = []
     for _ in range(3):
+        t0 = time.monotonic()
         mb.search(q, 3, client=1)                       # a lone client: three scans, no waiting (also measures the scan)
-    lone = (time.monotonic() - t0) / 3
-    assert lone < 0.04 + 0.015, lone
+        lone.append(time.monotonic() - t0)
+    assert min(lone) < 0.04 + 0.015 and sorted(lone)[1] < 0.04 + 0.02, lone   # (min / median: the VM's timers hiccup now and then)
     assert mb.get_stat("flat_scan_ns") > 30e6
 
-    # four closed-loop clients whose turn-around (5-15 ms) is shorter than the grace: every round must be ONE batch of all four
+    # four closed-loop clients whose come-back time (5-15 ms) is shorter than the grace: once the batcher has learnt each client's rhythm
+    # (two returns), every round must be ONE batch of all four
     eng.sizes.clear()
-    rounds = 5
+    rounds = 8
 
-    def loop(c):
-        for _ in range(rounds):
+    def loop(c, n=rounds, pause=None):
+        for _ in range(n):
             mb.search(q, 3, client=10 + c)
-            time.sleep(0.005 + 0.003 * c)
+            time.sleep(0.005 + 0.003 * c if pause is None else pause)
 
     threads = [threading.Thread(target=loop, args=(c,)) for c in range(4)]
     for t in threads:
@@ -869,14 +871,40 @@ def test_native_batcher_waits_for_expected_company_only():
     for t in threads:
         t.join(timeout=60)
     full = sum(1 for n in eng.sizes if n == 8)
-    assert full >= rounds - 1, eng.sizes                # (the very first round may split before every client is known)
-    assert mb.get_stat("grace_waits") >= rounds - 1
+    assert full >= rounds - 3, eng.sizes
+    assert mb.get_stat("grace_waits") >= rounds - 3
+    # ... while a client that pauses LONGER than the grace between its requests (a worker tokenising its next batch: 70 ms here, grace
+    # 24 ms) is not waited for: the closed-loop client next to it keeps the latency of a plain scan
+    lat = []
+
+    def fast():
+        for _ in range(6):
+            t0 = time.monotonic()
+            mb.search(q, 3, client=31)
+            lat.append(time.monotonic() - t0)
+            time.sleep(0.004)
+
+    slow = threading.Thread(target=loop, args=(20, 5, 0.07))
+    fastt = threading.Thread(target=fast)
+    slow.start()
+    time.sleep(0.2)  # the slow client's rhythm is known by now
+    fastt.start()
+    fastt.join(timeout=60)
+    slow.join(timeout=60)
+    # most of its requests cost one plain scan; the others queued behind the slow client's scan or were fused with it when it WAS due
+    # within the grace (70 ms after its last answer) - never "every request + the whole grace", which is what waiting for any recently
+    # seen client gave
+    plain = sum(1 for v in lat if v < 0.04 + 0.012)
+    assert plain >= 3, lat
     # a client that went away is not waited for once it is forgotten
-    for c in range(1, 4):
-        mb.forget_client(10 + c)
-    t0 = time.monotonic()
-    mb.search(q, 3, client=10)
-    assert time.monotonic() - t0 < 0.04 + 0.015
+    for c in (11, 12, 13, 30, 31):   # (the HTTP front forgets a client when its connection closes)
+        mb.forget_client(c)
+    after = []
+    for _ in range(3):
+        t0 = time.monotonic()
+        mb.search(q, 3, client=10)
+        after.append(time.monotonic() - t0)
+    assert min(after) < 0.04 + 0.015 and sorted(after)[1] < 0.04 + 0.02, after
     mb.close()
 
 
