@@ -113,10 +113,7 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
  *   scored densely, default 2048), "sample_div" (the threshold bootstrap scores ~ntotal / sample_div sampled rows, default 96),
  *   "growth" (x100: a filter stage covers growth x the rows its threshold was calibrated on, default 800),
  *   "force_safe" (1 = exhaustive schedule: dense chunks of <= cand_cap rows), "tile" (0 = auto; 1 = 128x128, 42 / 46 = small-batch
- *   rings, 8 / 9 = persistent 256x256 without / with the wave stagger), "small_chunk_tiles", "no_prepare" (default 1: a search whose
- *   queries have the store dtype, a 64-aligned dimension, whole query tiles and 16-byte alignment reads them IN PLACE and starts without
- *   the prepare launch when the previous search on the handle had the same padded batch and k bucket - its final select left the state
- *   empty; 0 = always prepare), "profile" (1 = HIP events around
+ *   rings, 8 / 9 = persistent 256x256 without / with the wave stagger), "small_chunk_tiles", "profile" (1 = HIP events around
  *   every filter launch), "ingest_threads" (CPU threads staging pageable host rows, 0 = auto), "kflags" (timing knobs of
  *   diagnostic builds).
  * stats (of the search completed by the last vodhip_index_search_finish): "last_overflow" (a candidate list overflowed),

@@ -757,77 +757,3 @@ def test_merge_of_more_than_8192_entries_runs_in_levels():
         rs, ri = merge_shard_topk(list(scores), list(ids), k_out)
         np.testing.assert_array_equal(gi.cpu().numpy(), ri)
         np.testing.assert_array_equal(gs.cpu().numpy(), rs)
-
-
-def test_prepare_free_search_sequences_stay_exact():
-    """Round 4: a search whose queries have the store dtype, a 64-aligned dimension and whole query tiles starts WITHOUT the prepare launch
-    when the previous search left the state empty for the same shape (the final select resets it) and reads its queries in place.  Mixed
-    sequences on one handle - same shape repeated with NEW queries, other batch sizes / k buckets / float32 queries in between, a subset
-    search, pipelined depth 3, a store whose ties overflow tiny candidate lists (recovery passes re-prepare) - must reproduce the oracle bit
-    for bit every time, and equal what the same handle answers with the shortcut switched off."""
-    from oracle.flat_ip import flat_ip_topk, topk_desc_tiebreak
-
-    rng = np.random.default_rng(2024)
-    n, d = 70_000, 128
-    x = rng.integers(-8, 9, size=(n, d)).astype(np.float16)
-    x[n - 20_000 :] = x[n - 20_000]  # 20 k copies of one row: queries aimed at it overflow a 256-entry candidate list
-    labels = rng.integers(0, 5, size=n).astype(np.int32)
-    with _index(x) as ix:
-        ix.set_row_labels(labels)
-
-        def check(q, k, subset=None, **kw):
-            s, i = ix.search(torch.from_numpy(q).cuda(), k, subset=subset, **kw)
-            full = q.astype(np.float64) @ x.astype(np.float64).T
-            if subset is not None:
-                for r in range(len(q)):
-                    allowed = subset[r][subset[r] >= 0]
-                    if allowed.size:
-                        full[r, ~np.isin(labels, allowed)] = np.nan
-            rs, ri = topk_desc_tiebreak(full, k)
-            np.testing.assert_array_equal(i.cpu().numpy(), ri)
-            np.testing.assert_array_equal(s.cpu().numpy(), rs)
-
-        def fresh(nq, dtype=np.float16):
-            return rng.integers(-8, 9, size=(nq, d)).astype(dtype)
-
-        for _ in range(4):                      # the steady state: same shape, new queries every time (2nd.. start without prepare)
-            check(fresh(256), 100)
-        check(fresh(256), 300)                  # another k bucket (kp 512): prepares, then ...
-        check(fresh(256), 300)                  # ... runs prepare-free in the new shape
-        check(fresh(256, np.float32), 100)      # float32 queries are converted: always prepared
-        check(fresh(256), 100)                  # back: the float32 search's final select left the state empty for nq_pad 256, kp 128
-        check(fresh(200), 100)                  # not whole tiles: prepared (pad rows)
-        check(fresh(256), 100)
-        sub = np.full((256, 2), -1, dtype=np.int32)
-        sub[::3] = [1, 4]
-        check(fresh(256), 100, subset=sub)      # subset search (geometric schedule) in place
-        check(fresh(256), 100)
-        check(fresh(512), 64)                   # two q-tiles
-        check(fresh(512), 64)
-        check(fresh(64), 10)                    # small-batch kernels (tile 42): 64 = one whole tile there
-        check(fresh(64), 10)
-        # pipelined: three searches of one shape in flight, each with its own queries
-        qs = [fresh(256) for _ in range(3)]
-        outs = [ix.search_async(torch.from_numpy(q).cuda(), 100) for q in qs]
-        for _ in qs:
-            ix.finish()
-        for q, (s, i) in zip(qs, outs):
-            rs, ri = flat_ip_topk(q.astype(np.float32), x.astype(np.float32), 100)
-            np.testing.assert_array_equal(i.cpu().numpy(), ri)
-            np.testing.assert_array_equal(s.cpu().numpy(), rs)
-        # overflow in the middle of a steady sequence: the recovery passes re-prepare, the next search must not trust the state
-        ix.set_param("cand_cap", 256)
-        hot = (np.sign(x[n - 1].astype(np.float32))[None, :] * rng.integers(1, 4, size=(256, d))).astype(np.float16)
-        check(fresh(256), 100)
-        check(hot, 100)
-        assert ix.get_stat("last_safe_reruns") >= 1
-        check(fresh(256), 100)
-        check(hot, 100)
-        check(hot, 100)
-        check(fresh(256), 100)
-        # and the shortcut switched off gives the same answers
-        q = fresh(256)
-        a = ix.search(torch.from_numpy(q).cuda(), 100)
-        ix.set_param("no_prepare", 0)
-        b = ix.search(torch.from_numpy(q).cuda(), 100)
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

@@ -47,16 +47,5 @@ case $P in
   openloop)  # arrivals NOT synchronised by the server: workers pause Exp(think) between requests; default policy vs never waiting for company
     timeout 900 python tools/bench_http_load.py --routes fast --clients 8 32 --nq 32 --think-ms 2 10 --out $OUT/http_openloop_default.json > $OUT/openloop_default.log 2>&1; tail -5 $OUT/openloop_default.log | cut -c1-330
     timeout 900 python tools/bench_http_load.py --routes fast --clients 8 32 --nq 32 --think-ms 2 10 --batcher-param grace_us=0 --out $OUT/http_openloop_nograce.json > $OUT/openloop_nograce.log 2>&1; tail -5 $OUT/openloop_nograce.log | cut -c1-330 ;;
-  ab_noprep)  # same-box interleaved A/B of the prepare-free search start (device-resident fp16 queries, whole tiles) vs always preparing
-    for rep in 1 2 3; do
-      for cfg in "c2 --rows 1000000 --nq 256 --steps 300 --warmup 30" "shard --rows 1250000 --steps 150 --warmup 15" "nq256 --nq 256 --steps 60 --warmup 6" "c3 --steps 20 --warmup 3"; do
-        name=$(echo $cfg | cut -d" " -f1)
-        for v in "inplace" "prepare --param no_prepare=0"; do
-          vn=$(echo $v | cut -d" " -f1); extra=$(echo "$v" | cut -s -d" " -f2-)
-          ms=$(timeout 600 python bench.py $(echo $cfg | cut -d" " -f2-) --no-side --no-cpu-baseline --verify-queries 16 $extra 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), d['verify']['recall_at_k'], d['verify']['rows_with_identical_id_order'], d['verify']['max_abs_score_diff'])")
-          echo "$name $vn rep$rep $ms" | tee -a $OUT/ab_noprep.txt
-        done
-      done
-    done ;;
   *) echo "unknown pass $P"; exit 2 ;;
 esac

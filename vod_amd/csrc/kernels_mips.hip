@@ -829,7 +829,7 @@ __device__ __forceinline__ void sort_front_desc(key_t64* keys, int kp, int tid) 
 // SELECT_THRESHOLD_ONLY (after a GMAX stage): the candidates are group maxima, not rows - only the threshold leaves.
 // The threshold never decreases: a stage whose candidates do not fill the top-k keeps the bound it was given.
 // LDS: the histogram words + `front`, kp keys: where a round's survivors are gathered (and sorted, and read by the next round).
-enum : int { SELECT_FINAL = 1, SELECT_THRESHOLD_ONLY = 2, SELECT_RESET = 4 };
+enum : int { SELECT_FINAL = 1, SELECT_THRESHOLD_ONLY = 2 };
 #define SEL_PROBE(i) VODHIP_PROBE(g_probe_select, pb + (i))
 template <int KPT>
 __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ topk, int kp, int k,
@@ -922,11 +922,8 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
         kth = front[k - 1];
     }
     SEL_PROBE(4);
-    // SELECT_RESET (with SELECT_FINAL): this is the search's last launch - leave the query's search state as a prepare launch would
-    // (empty running top-k, no threshold, counter 0), so that the NEXT search of the same shape can start without one (round 4)
-    const bool reset = (flags & SELECT_RESET) != 0;
     if (!thr_only)
-        for (int i = tid; i < kp; i += 256) topk[(size_t)q * kp + i] = reset ? 0ull : front[i];
+        for (int i = tid; i < kp; i += 256) topk[(size_t)q * kp + i] = front[i];
     if (out_scores != nullptr) {  // last select of a search: the sorted keys leave as (float32 score, int64 id) rows
         const size_t qo = q_map ? (size_t)q_map[q] : (size_t)q;
         for (int c = tid; c < k; c += 256) {
@@ -939,10 +936,7 @@ __global__ __launch_bounds__(256) void mips_select_kernel(key_t64* __restrict__ 
         // a group maximum stands for "some row with this score": every row with the score must pass `key > thr_key`
         if (thr_only) kth &= 0xFFFFFFFF00000000ull;
         const key_t64 old = thr_key[q];
-        if (reset) {
-            thr_key[q] = 0ull;
-            thr_s[q] = -__builtin_inff();
-        } else if (kth > old) {
+        if (kth > old) {
             thr_key[q] = kth;
             thr_s[q] = unflip_f32((unsigned)(kth >> 32));
         }

@@ -95,11 +95,6 @@ struct vodhip_index {
     unsigned int* overflow_host = nullptr;  // pinned, one word per in-flight slot
     unsigned int* ovf_q = nullptr;          // device [MAX_IN_FLIGHT][OVF_ROWS]: which queries of a slot's search overflowed
     int* q_map = nullptr;                   // device [MAX_IN_FLIGHT][OVF_ROWS]: the rows a slot's recovery pass re-searches
-    unsigned int* overflow_words = nullptr; // device [MAX_IN_FLIGHT]: "a candidate list overflowed", one word per in-flight slot (zero between searches)
-    // The search state (running top-k, thresholds, counters) is left EMPTY by the final select of a search (SELECT_RESET): when the next
-    // search has the same padded batch and k bucket, queries of the store dtype, a 64-aligned dimension and whole query tiles, it starts
-    // without a prepare launch and reads its queries in place (one launch and one dependent kernel boundary fewer: ~11 us of C2's 463)
-    int64_t ws_ready_nq_pad = 0, ws_ready_kp = 0;
     hipEvent_t done[MAX_IN_FLIGHT] = {};    // recorded after a search's overflow word is copied back
     std::deque<PendingSearch> inflight;     // oldest first
     int unfinished = 0;                     // searches popped by a vodhip_index_search_finish that is still waiting for their event
@@ -112,7 +107,6 @@ struct vodhip_index {
     int64_t force_safe = 0;
     int64_t tile = 0;
     int64_t kflags = 0;
-    int64_t no_prepare = 1;           // 1: skip the prepare launch when the state is known empty and the queries can be read in place ("no_prepare" param)
     int64_t small_chunk_tiles = 256;  // launches with fewer 256x256 tiles than this (less than one per CU) use the 128x128 kernel
     int n_cu = 256;       // compute units of `device` (read once at create; the planner never touches the runtime)
     int64_t profile = 0;  // 1: bracket every filter launch with HIP events (bench / roofline accounting)
@@ -140,10 +134,10 @@ int free_workspace(vodhip_index* ix) {
     (void)hipFree(w.cnt);
     (void)hipFree(w.thr_s);
     (void)hipFree(w.thr_key);
+    (void)hipFree(w.overflow);
     const int n_cu = w.n_cu;
     w = SearchWorkspace();
     w.n_cu = n_cu;
-    ix->ws_ready_nq_pad = 0;
     return 0;
 }
 
@@ -158,10 +152,10 @@ int ensure_workspace(vodhip_index* ix, int64_t nq_pad, int64_t cap, int64_t kp) 
     HIP_OK(hipMalloc((void**)&w.cnt, (size_t)nq_cap * CNT_STRIDE * sizeof(unsigned int)));
     HIP_OK(hipMalloc((void**)&w.thr_s, (size_t)nq_cap * sizeof(float)));
     HIP_OK(hipMalloc((void**)&w.thr_key, (size_t)nq_cap * sizeof(key_t64)));
+    HIP_OK(hipMalloc((void**)&w.overflow, sizeof(unsigned int)));
     w.nq_cap = nq_cap;
     w.cap = cap;
     w.kp = kp;
-    ix->ws_ready_nq_pad = 0;  // fresh buffers: the next search initialises them with a prepare launch
     return 0;
 }
 
@@ -314,14 +308,6 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
         ix->last_chunks = (int64_t)stages.size();
     }
     const SearchWorkspace& ws = ix->ws;
-    ix->ws.overflow = ix->overflow_words + ps.slot;  // this search's own "a list overflowed" word (zero between searches)
-    // No prepare launch when the previous search left the state empty for exactly this shape (its final select ran with SELECT_RESET)
-    // and the queries can be read where they lie: store dtype, 64-aligned dimension, whole query tiles, 16-byte aligned, no query map
-    const int64_t nq_pad_all = round_up(std::min(MAX_NQ_PER_PASS, ps.nq), bn);
-    const bool in_place = recovery == 0 && !ps.q_map && ps.nq <= MAX_NQ_PER_PASS && ps.nq == nq_pad_all && ps.q_dtype == ix->dtype &&
-                          ix->dim == ix->dim_pad && ((uintptr_t)ps.queries & 15) == 0 && !stages.empty() && ix->no_prepare &&
-                          ix->ws_ready_nq_pad == nq_pad_all && ix->ws_ready_kp == kp;
-    ix->ws_ready_nq_pad = 0;  // until this enqueue has ended with a resetting final select
     for (int64_t qb = 0; qb < ps.nq; qb += MAX_NQ_PER_PASS) {
         const int64_t nq = std::min(MAX_NQ_PER_PASS, ps.nq - qb);
         const int64_t nq_pad = round_up(nq, bn);
@@ -331,14 +317,9 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
         const int* q_map = ps.q_map ? ps.q_map + qb : nullptr;
         const int64_t row0 = ps.q_map ? 0 : qb;
         ix->ws.ovf_q = track_ovf ? ix->ovf_q + (size_t)ps.slot * OVF_ROWS + qb : nullptr;
-        const void* q_rows = ws.q_pad;  // what the filter launches read: the staged copy, or the caller's rows in place
-        if (in_place) {
-            q_rows = ps.queries;
-        } else {
-            HIP_OK(launch_search_prepare(ws, (const char*)ps.queries + (size_t)row0 * ix->dim * q_es, ps.q_dtype, nq, ix->dim,
-                                         ix->dtype, nq_pad, ix->dim_pad, qb == 0, recovery > 0 ? ps.out_scores + row0 * k : nullptr,
-                                         recovery > 0 ? ps.out_ids + row0 * k : nullptr, k, q_map, stream));
-        }
+        HIP_OK(launch_search_prepare(ws, (const char*)ps.queries + (size_t)row0 * ix->dim * q_es, ps.q_dtype, nq, ix->dim,
+                                     ix->dtype, nq_pad, ix->dim_pad, qb == 0, recovery > 0 ? ps.out_scores + row0 * k : nullptr,
+                                     recovery > 0 ? ps.out_ids + row0 * k : nullptr, k, q_map, stream));
         ix->ws.extra.q_label = ps.q_label ? ps.q_label + (size_t)row0 * ps.n_qlab : nullptr;
         ix->ws.extra.q_map = q_map;
         for (size_t c = 0; c < stages.size(); ++c) {
@@ -361,7 +342,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
                 // are split between the head and the tail of the store
                 ix->ws.extra.sample_offset = sg.kind == ST_GMAX ? (int)(((ix->ntotal - 1) - (sg.n_tiles * filter_tile_rows(tile_c) - 1) * sg.rstride) / 2) : 0;
                 ix->ws.extra.sample_groups = (int)sg.n_groups;
-                HIP_OK(launch_filter(ix->dtype, tile_c, sg.kind, ix->data, q_rows, ix->dim_pad, b, e, sg.n_tiles, nq, nq_pad, ws, stream));
+                HIP_OK(launch_filter(ix->dtype, tile_c, sg.kind, ix->data, ws.q_pad, ix->dim_pad, b, e, sg.n_tiles, nq, nq_pad, ws, stream));
                 if (ix->profile) HIP_OK(hipEventRecord(ev1, stream));
                 return 0;
             };
@@ -377,7 +358,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
             }
             if (launch_one(tile_c, sg.b, sg.e)) return -1;
             int64_t dense_n = -1;
-            int flags = last ? (1 | 4) : 0;  // SELECT_FINAL | SELECT_RESET: the last select leaves the state empty for the next search
+            int flags = last ? 1 : 0;
             if (sg.kind == ST_DENSE) dense_n = sg.e - sg.b;
             if (sg.kind == ST_GMAX) {
                 dense_n = sg.n_groups;
@@ -390,12 +371,6 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
     }
     HIP_OK(hipMemcpyAsync(ix->overflow_host + ps.slot, ws.overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipEventRecord(ix->done[ps.slot], stream));
-    // the state is empty again for this shape - as long as it was ONE pass over whole query tiles (rows beyond nq were initialised by
-    // the prepare launch that set the shape up and are never written) and nothing overflows (then the recovery passes re-prepare)
-    if (recovery == 0 && ps.nq <= MAX_NQ_PER_PASS && !stages.empty()) {
-        ix->ws_ready_nq_pad = nq_pad_all;
-        ix->ws_ready_kp = kp;
-    }
     return 0;
 }
 
@@ -440,10 +415,6 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->ovf_q, MAX_IN_FLIGHT * OVF_ROWS * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc((void**)&ix->q_map, MAX_IN_FLIGHT * OVF_ROWS * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void**)&ix->overflow_words, MAX_IN_FLIGHT * sizeof(unsigned int));
-    if (e == hipSuccess) e = hipMemset(ix->overflow_words, 0, MAX_IN_FLIGHT * sizeof(unsigned int));
-    if (e == hipSuccess) e = hipMemset(ix->ovf_q, 0, MAX_IN_FLIGHT * OVF_ROWS * sizeof(unsigned int));
-    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ix->overflow_host, MAX_IN_FLIGHT * sizeof(unsigned int), hipHostMallocDefault);
     for (int i = 0; i < MAX_IN_FLIGHT && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ix->done[i], hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -473,7 +444,6 @@ int vodhip_index_destroy(vodhip_index_t* ix) {
     (void)hipFree(ix->row_label);
     (void)hipFree(ix->ovf_q);
     (void)hipFree(ix->q_map);
-    (void)hipFree(ix->overflow_words);
     (void)hipHostFree(ix->overflow_host);
     delete ix;
     return 0;
@@ -701,9 +671,6 @@ int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
                 // clustered in the store): only they are searched again, as a small batch on the small-batch kernels
                 std::vector<unsigned int> flags((size_t)ps.nq);
                 HIP_OK(hipMemcpy(flags.data(), ix->ovf_q + (size_t)ps.slot * OVF_ROWS, (size_t)ps.nq * sizeof(unsigned int), hipMemcpyDeviceToHost));
-                // read: clear them for the slot's next search (which may start without a prepare launch); the recovery passes below
-                // index the slot's flags by THEIR workspace rows
-                HIP_OK(hipMemsetAsync(ix->ovf_q + (size_t)ps.slot * OVF_ROWS, 0, (size_t)ps.nq * sizeof(unsigned int), stream));
                 std::vector<int> rows;
                 for (int64_t q = 0; q < ps.nq; ++q)
                     if (flags[(size_t)q]) rows.push_back((int)q);
@@ -716,7 +683,6 @@ int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
                 }
             }
             const size_t ev_first = ix->ev_used;  // behind the events of every younger search in flight
-            ix->ws_ready_nq_pad = 0;  // the recovery pass re-initialises the workspace for ITS batch: the next search prepares again
             if (enqueue_search(ix, rs, false, pass, stream)) return -1;
             HIP_OK(hipStreamSynchronize(stream));
             // the recovery launches are accounted separately ("last_recovery_ns"): the time they take is real
@@ -785,9 +751,6 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
         ix->force_safe = value;
     } else if (!strcmp(key, "small_chunk_tiles")) {
         ix->small_chunk_tiles = value;
-    } else if (!strcmp(key, "no_prepare")) {
-        ix->no_prepare = value;
-        ix->ws_ready_nq_pad = 0;
     } else if (!strcmp(key, "kflags")) {
         ix->kflags = value;
     } else if (!strcmp(key, "sample_div")) {
