@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <mutex>
 #include <set>
 #include <string>
@@ -1388,7 +1389,14 @@ void accept_main(vodhip_http* h) {
                 ++h->n_conn_threads;
             }
             h->n_connections.fetch_add(1, std::memory_order_relaxed);
-            std::thread(conn_main, h, fd, client).detach();
+            try {
+                std::thread(conn_main, h, fd, client).detach();
+            } catch (const std::exception&) {  // no thread to be had (process limits): refuse this connection, keep serving the others
+                std::lock_guard<std::mutex> lk(h->mu);
+                h->conn_fds.erase(fd);
+                --h->n_conn_threads;
+                close(fd);
+            }
         }
     }
 }
