@@ -112,9 +112,9 @@ class HipMipsClient(base.SearchClient):
 
         loc = self._local
         if getattr(loc, "conn", None) is None or loc.conn_pid != os.getpid():  # a forked / unpickled worker opens its own socket
-            if self.uds:
+            if self.uds and os.path.exists(self.uds):
                 loc.conn = _UnixHTTPConnection(self.uds, timeout=timeout)
-            else:
+            else:  # (no socket file on THIS host - a client on another machine, a server without --uds: the TCP address still works)
                 u = urllib.parse.urlsplit(self.host if "://" in self.host else "http://" + self.host)
                 cls = http.client.HTTPSConnection if u.scheme == "https" else http.client.HTTPConnection
                 loc.conn = cls(u.hostname, self.port, timeout=timeout)
