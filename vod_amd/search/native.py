@@ -10,9 +10,10 @@ serialises `faiss_index.search` calls; see DESIGN.md 6b for the policy and the m
 """
 from __future__ import annotations
 
+import collections
 import ctypes
+import re
 import threading
-import traceback
 import urllib.parse
 
 import numpy as np
@@ -36,7 +37,10 @@ class NativeBatcher:
         elif engine is not None:
             self._cb = _native.SEARCH_FN(self._call_engine)
             self._engine = engine
-            self._engine_error: BaseException | None = None
+            # a failing engine call fails its whole fused batch: every caller of that batch re-raises the engine's OWN exception, found by
+            # the status number the callback returned (it travels through the library's error message)
+            self._failures: "collections.OrderedDict[int, BaseException]" = collections.OrderedDict()
+            self._failure_seq = 0
         else:
             raise ValueError("one of index / node / engine is required")
         handle = ctypes.c_void_p()
@@ -62,9 +66,11 @@ class NativeBatcher:
             np.ctypeslib.as_array(ctypes.cast(out_i, ctypes.POINTER(ctypes.c_int64)), shape=(nq, k))[:] = ids
             return 0
         except BaseException as exc:  # noqa: BLE001 - nothing may propagate into the C thread
-            self._engine_error = exc
-            self._engine_trace = traceback.format_exc()
-            return 1
+            self._failure_seq = self._failure_seq % 1_000_000 + 1
+            self._failures[self._failure_seq] = exc
+            while len(self._failures) > 64:
+                self._failures.popitem(last=False)
+            return self._failure_seq
 
     # -- API ---------------------------------------------------------------------------------------------------------------------
     def set_param(self, key: str, value: int) -> None:
@@ -101,11 +107,11 @@ class NativeBatcher:
         rc = self._lib.vodhip_batcher_search(self._h, q.ctypes.data, _native.numpy_dtype_code(q.dtype), nq, k, sub_ptr, n_sub, int(client),
                                              scores.ctypes.data, ids.ctypes.data)  # (ctypes releases the GIL for the whole wait)
         if rc != 0:
-            err = getattr(self, "_engine_error", None)
-            if err is not None and self._cb is not None:
-                self._engine_error = None
-                raise err  # the engine's own exception (ValueError from a bad argument, ...) - what a direct call would raise
-            _native.check(rc)
+            msg = (self._lib.vodhip_last_error() or b"").decode("utf-8", "replace")
+            found = re.search(r"search callback failed \(status (\d+)\)", msg) if self._cb is not None else None
+            if found and int(found.group(1)) in self._failures:
+                raise self._failures[int(found.group(1))]  # the engine's own exception (ValueError from a bad argument, ...): what a direct call would raise
+            raise _native.NativeLibraryError(msg or f"native call failed with status {rc}")
         return scores, ids
 
     def close(self) -> None:
