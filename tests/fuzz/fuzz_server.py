@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--group", action="store_true", help="serve through the worker group (devices=[0, 0], gloo)")
     ap.add_argument("--node", action="store_true", help="serve through the one-process node index (devices=[0, 0], group_backend=node)")
     ap.add_argument("--http", default="native", choices=["native", "asyncio", "uvicorn"])
+    ap.add_argument("--churn", action="store_true", help="a NEW client object (new connections) every 25 requests per route: connection churn for soak runs")
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
@@ -70,8 +71,20 @@ def main():
             "json": HipMipsClient(host=m.host, port=m.port),
         }
 
+        def server_stats():
+            try:
+                import requests
+
+                return requests.get(f"{m.host}:{m.port}/stats", timeout=10).json()
+            except Exception:  # noqa: BLE001
+                return {}
+
+        stats0 = server_stats()
+
         def run(job):
             j, route, q, k, subset = job
+            if a.churn and j % 25 == 24:  # drop this route's client: its threads' connections close, new ones open
+                clients[route] = HipMipsClient(host=m.host, port=m.port, forward_subset_ids=(route == "fast"), binary=(route == "raw"))
             try:
                 if route == "json":
                     res = clients["json"].search_py(q, top_k=k)
@@ -86,6 +99,10 @@ def main():
 
         with concurrent.futures.ThreadPoolExecutor(a.threads) as ex:
             errs = [e for e in ex.map(run, jobs) if e]
+        stats1 = server_stats()
+        if stats0 and stats1:
+            print(f"server: rss {stats0.get('rss_kb')} -> {stats1.get('rss_kb')} kB, connections {stats1.get('connections')} (open now {stats1.get('open_connections')}), "
+                  f"native {stats1.get('requests_native')} / fallback {stats1.get('requests_fallback')} requests, batches {stats1.get('batches')}")
     for e in errs[:20]:
         print("FAIL", e)
     print(f"fuzz_server: {len(jobs)} requests on {a.threads} threads ({'worker group x2' if a.group else ('node index x2' if a.node else 'single process')}, "

@@ -1160,8 +1160,20 @@ std::string stats_json(vodhip_http* h) {
         snprintf(tmp, sizeof(tmp), "\"%s\": %lld, ", k, (long long)v);
         out += tmp;
     }
-    snprintf(tmp, sizeof(tmp), "\"requests_native\": %lld, \"requests_fallback\": %lld, \"connections\": %lld}", (long long)h->n_native.load(),
-             (long long)h->n_fallback.load(), (long long)h->n_connections.load());
+    long rss_pages = 0;  // resident set of the server process (a soak run reads it before and after: tests/fuzz/fuzz_server.py)
+    if (FILE* f = fopen("/proc/self/statm", "r")) {
+        long size = 0;
+        if (fscanf(f, "%ld %ld", &size, &rss_pages) != 2) rss_pages = 0;
+        fclose(f);
+    }
+    int open_now = 0;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        open_now = h->n_conn_threads;
+    }
+    snprintf(tmp, sizeof(tmp), "\"requests_native\": %lld, \"requests_fallback\": %lld, \"connections\": %lld, \"open_connections\": %d, \"rss_kb\": %ld}",
+             (long long)h->n_native.load(), (long long)h->n_fallback.load(), (long long)h->n_connections.load(), open_now,
+             rss_pages * (sysconf(_SC_PAGESIZE) / 1024));
     out += tmp;
     return out;
 }
