@@ -1153,7 +1153,7 @@ std::string stats_json(vodhip_http* h) {
     static const char* keys[] = {"batches", "requests", "queries", "fused_requests_max", "grace_waits", "grace_expired", "idle_ns", "busy_ns",
                                  "last_batch_queries", "last_batch_requests", "flat_scan_ns", "in_flight", "pending", "active_clients"};
     std::string out = "{";
-    char tmp[96];
+    char tmp[320];
     for (const char* k : keys) {
         int64_t v = 0;
         (void)vodhip_batcher_get_stat(h->batcher, k, &v);
