@@ -83,6 +83,9 @@ def main():
 
         def run(job):
             j, route, q, k, subset = job
+            if a.churn and j % 1000 == 999:
+                st = server_stats()
+                print(f"  after ~{j + 1} requests: rss {st.get('rss_kb')} kB, connections {st.get('connections')}, open {st.get('open_connections')}", flush=True)
             if a.churn and j % 25 == 24:  # drop this route's client: its threads' connections close, new ones open
                 clients[route] = HipMipsClient(host=m.host, port=m.port, forward_subset_ids=(route == "fast"), binary=(route == "raw"))
             try:
