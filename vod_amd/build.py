@@ -14,7 +14,7 @@ ORACLE = ROOT / "oracle"
 def build_native(force: bool = False, verbose: bool = False) -> pathlib.Path:
     """hipcc --offload-arch=gfx950 over vod_amd/csrc/*.hip -> vod_amd/csrc/libvodhip.so."""
     target = CSRC / "libvodhip.so"
-    srcs = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + [ROOT / "include" / "vodhip.h"]
+    srcs = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.cpp")) + list(CSRC.glob("*.h")) + [ROOT / "include" / "vodhip.h"]
     if target.exists() and not force and all(target.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return target
     if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):

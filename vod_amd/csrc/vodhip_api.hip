@@ -1155,110 +1155,7 @@ int vodhip_debug_read_probe(int which, int64_t* out, int n) {
     return 0;
 }
 
-// ---- wire codec helper (host only) ----
-// Table-driven: the encoder maps 12 input bits to two output characters per lookup (8 KB table, L1-resident), the decoder ORs four
-// pre-shifted 256-entry tables and checks validity once per quantum - ~3x the byte-at-a-time loops of round 1 on a 4 MB batch,
-// which is what a 1024 x 768 float32 query batch weighs in the reference's base64-in-JSON wire format.
-static const char kB64Url[65] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789-_";
-
-extern "C++" {
-namespace {
-struct B64Tables {
-    uint16_t enc12[4096];      // 12 bits -> two characters (little endian: first character in the low byte)
-    uint32_t dec[4][256];      // character at position i of a quantum -> its 6 bits, shifted into place; bit 31 = invalid
-    B64Tables() {
-        for (int v = 0; v < 4096; ++v) enc12[v] = (uint16_t)((unsigned char)kB64Url[v >> 6] | ((unsigned char)kB64Url[v & 63] << 8));
-        for (int i = 0; i < 4; ++i)
-            for (int c = 0; c < 256; ++c) dec[i][c] = 0x80000000u;
-        auto put = [&](unsigned char c, uint32_t v) {
-            for (int i = 0; i < 4; ++i) dec[i][c] = v << (18 - 6 * i);
-        };
-        for (uint32_t v = 0; v < 64; ++v) put((unsigned char)kB64Url[v], v);
-        put('+', 62);
-        put('/', 63);
-    }
-};
-const B64Tables& b64_tables() {
-    static const B64Tables t;  // thread-safe initialisation (C++11 magic static)
-    return t;
-}
-}  // namespace
-}  // extern "C++"
-
-int64_t vodhip_b64url_encode(const uint8_t* head, int64_t n_head, const uint8_t* data, int64_t n_data, char* out) {
-    if (n_head < 0 || n_data < 0 || !out || (n_head && !head) || (n_data && !data)) return -1;
-    const B64Tables& T = b64_tables();
-    const int64_t n = n_head + n_data;
-    auto at = [&](int64_t i) -> uint32_t { return i < n_head ? head[i] : data[i - n_head]; };
-    char* o = out;
-    int64_t i = 0;
-    // the head and the triple that straddles the head / data seam go through the generic accessor
-    const int64_t seam_end = n_head == 0 ? 0 : ((n_head + 2) / 3) * 3;
-    for (; i + 2 < n && i < seam_end; i += 3) {
-        const uint32_t v = (at(i) << 16) | (at(i + 1) << 8) | at(i + 2);
-        const uint16_t a = T.enc12[v >> 12], b = T.enc12[v & 4095];
-        memcpy(o, &a, 2);
-        memcpy(o + 2, &b, 2);
-        o += 4;
-    }
-    if (i + 2 < n) {
-        const uint8_t* p = data + (i - n_head);  // i >= n_head here
-        for (; i + 5 < n; i += 6, p += 6, o += 8) {  // two quanta per iteration
-            const uint32_t v0 = ((uint32_t)p[0] << 16) | ((uint32_t)p[1] << 8) | p[2];
-            const uint32_t v1 = ((uint32_t)p[3] << 16) | ((uint32_t)p[4] << 8) | p[5];
-            const uint64_t w = (uint64_t)T.enc12[v0 >> 12] | ((uint64_t)T.enc12[v0 & 4095] << 16) | ((uint64_t)T.enc12[v1 >> 12] << 32) |
-                               ((uint64_t)T.enc12[v1 & 4095] << 48);
-            memcpy(o, &w, 8);
-        }
-        for (; i + 2 < n; i += 3, p += 3, o += 4) {
-            const uint32_t v = ((uint32_t)p[0] << 16) | ((uint32_t)p[1] << 8) | p[2];
-            const uint32_t w = (uint32_t)T.enc12[v >> 12] | ((uint32_t)T.enc12[v & 4095] << 16);
-            memcpy(o, &w, 4);
-        }
-    }
-    if (i < n) {
-        const uint32_t b0 = at(i), b1 = i + 1 < n ? at(i + 1) : 0;
-        *o++ = kB64Url[b0 >> 2];
-        *o++ = kB64Url[((b0 & 3) << 4) | (b1 >> 4)];
-        *o++ = i + 1 < n ? kB64Url[(b1 & 15) << 2] : '=';
-        *o++ = '=';
-    }
-    return (int64_t)(o - out);
-}
-
-int64_t vodhip_b64url_decode(const char* src, int64_t n, uint8_t* out) {
-    if (n < 0 || (n && (!src || !out))) return -1;
-    const B64Tables& T = b64_tables();
-    const unsigned char* s = (const unsigned char*)src;
-    while (n > 0 && s[n - 1] == '=') --n;
-    uint8_t* o = out;
-    int64_t i = 0;
-    uint32_t bad = 0;
-    // the 4-byte store of a quantum spills one byte past its 3: safe while at least one more quantum (or the tail) follows
-    for (; i + 7 < n; i += 4, o += 3) {
-        const uint32_t v = T.dec[0][s[i]] | T.dec[1][s[i + 1]] | T.dec[2][s[i + 2]] | T.dec[3][s[i + 3]];
-        bad |= v;
-        const uint32_t be = __builtin_bswap32(v << 8);  // bytes v[23:16], v[15:8], v[7:0], 0 in memory order
-        memcpy(o, &be, 4);
-    }
-    if (bad & 0x80000000u) return -1;
-    for (; i + 3 < n; i += 4, o += 3) {
-        const uint32_t v = T.dec[0][s[i]] | T.dec[1][s[i + 1]] | T.dec[2][s[i + 2]] | T.dec[3][s[i + 3]];
-        if (v & 0x80000000u) return -1;
-        o[0] = (uint8_t)(v >> 16);
-        o[1] = (uint8_t)(v >> 8);
-        o[2] = (uint8_t)v;
-    }
-    const int64_t rem = n - i;
-    if (rem == 1) return -1;
-    if (rem >= 2) {
-        const uint32_t v = T.dec[0][s[i]] | T.dec[1][s[i + 1]] | (rem == 3 ? T.dec[2][s[i + 2]] : 0u);
-        if (v & 0x80000000u) return -1;
-        *o++ = (uint8_t)(v >> 16);
-        if (rem == 3) *o++ = (uint8_t)(v >> 8);
-    }
-    return (int64_t)(o - out);
-}
+// (the wire codec - vodhip_b64url_encode / vodhip_b64url_decode - lives in wire_codec.cpp: host C++ with AVX2 paths)
 
 }  // extern "C"
 
