@@ -1116,7 +1116,7 @@ bool try_native(vodhip_http* h, int fd, uint64_t client, bool raw, int64_t raw_t
     int dtype = 0;
     int64_t rows = 0, cols = 0, off = 0;
     if (parse_npy_2d(npy, npy_n, &dtype, &rows, &cols, &off)) return false;
-    if (cols != h->dim || rows < 1 || top_k < 1 || top_k > VODHIP_MAX_K) return false;  // the host raises the reference's errors
+    if (cols != h->dim || rows < 1 || rows > 65536 || top_k < 1 || top_k > VODHIP_MAX_K) return false;  // the host raises the reference's errors (and takes the oversized batches)
     const int k = (int)top_k;
     cs.scores.resize((size_t)rows * k);
     cs.ids.resize((size_t)rows * k);
