@@ -495,8 +495,8 @@ def parse_args(argv=None) -> argparse.Namespace:
                    help="HTTP shell: libvodhip's native front (default: the hot routes never enter the interpreter), the in-tree asyncio "
                         "server, or uvicorn + FastAPI")
     p.add_argument("--http-workers", type=int, default=64, help="handler threads = requests that may be in flight at once")
-    p.add_argument("--max-body-mb", type=int, default=512, help="largest request body the asyncio shell accepts (413 above it)")
-    p.add_argument("--uds", type=str, default=None, help="also serve on this Unix-domain socket path (asyncio shell; clients on the same host)")
+    p.add_argument("--max-body-mb", type=int, default=512, help="largest request body the native / asyncio shells accept (413 above it)")
+    p.add_argument("--uds", type=str, default=None, help="also serve on this Unix-domain socket path (native / asyncio shells; clients on the same host)")
     p.add_argument("--micro-batch-wait-ms", type=float, default=0.0,
                    help="> 0: every batch additionally waits this long for company.  Not needed: concurrent requests are fused by default "
                         "(batch-while-busy, no fixed window: vodhip_batcher in include/vodhip.h)")
