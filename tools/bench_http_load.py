@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--http", default="native", choices=["native", "asyncio", "uvicorn"])
     ap.add_argument("--routes", nargs="+", default=["fast", "raw"], choices=["fast", "raw"])
     ap.add_argument("--batcher-param", action="append", default=[], metavar="KEY=VALUE")
+    ap.add_argument("--devices", type=int, nargs="+", default=None, help="serve the store row-sharded over these GPUs (a device may repeat)")
+    ap.add_argument("--group-backend", default="node", choices=["node", "nccl", "gloo"])
     ap.add_argument("--think-ms", type=float, nargs="+", default=[0.0],
                     help="mean of an exponential pause between a worker's requests (0 = closed loop, the default cells); > 0 shows what the "
                          "fusion policy costs / gives when arrivals are not synchronised by the server itself")
@@ -103,7 +105,8 @@ def main():
 
     out = {"store": f"{a.rows} x {a.dim} fp16 (synthetic N(0,1), generated on the device)", "k": a.k, "http": a.http, "seconds_per_cell": a.seconds,
            "host_cpus_visible": len(os.sched_getaffinity(0)), "host_cpus_usable": usable_cpus(), "batcher_params": a.batcher_param,
-           "note": "client processes and the server share the usable host CPUs", "device_resident": {}, "cells": []}
+           "note": "client processes and the server share the usable host CPUs", "device_resident": {}, "cells": [],
+           "server_shape": "single process, one device" if a.devices is None else f"devices={a.devices}, group_backend={a.group_backend}"}
     # device-resident reference: the same store in this process, one fused batch of B queries resident in HBM
     dev = torch.device("cuda", 0)
     ix = HipFlatIndex(a.dim, a.rows, dtype=torch.float16, device=0)
@@ -130,7 +133,8 @@ def main():
     torch.cuda.empty_cache()
     for mb in a.micro_batch_ms:
         bparams = {kv.partition("=")[0]: int(kv.partition("=")[2]) for kv in a.batcher_param}
-        with HipMipsMaster(spec, port=-1, logging_level="warning", micro_batch_wait_ms=mb, http=a.http, batcher_params=bparams) as master:
+        multi = {} if a.devices is None else dict(devices=a.devices, group_backend=a.group_backend)
+        with HipMipsMaster(spec, port=-1, logging_level="warning", micro_batch_wait_ms=mb, http=a.http, batcher_params=bparams, **multi) as master:
             import requests
 
             def stats():
