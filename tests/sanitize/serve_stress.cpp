@@ -1,4 +1,4 @@
-// Sanitizer harness for the native serving layer (vod_amd/csrc/vodhip_serve.hip compiled as HOST C++ with -fsanitize=thread / address;
+// Sanitizer harness for the native serving layer (vod_amd/csrc/vodhip_serve.hip + vodhip_http.hip compiled as HOST C++ with -fsanitize=thread / address;
 // GPU sanitizers are not available on the pool, so the threading and the parsers are checked on the CPU build).  A callback engine (exact
 // brute force on the host) stands in for the GPU: the batcher's scheduler / completion logic, the caller hand-off, the HTTP front's
 // connection threads, the wire parsers and the shutdown paths are exactly the product's.  Built and run by tests/test_sanitizers_cpu.py.

@@ -96,7 +96,7 @@ SIGNATURES: dict[str, tuple] = {
     "vodhip_gather_by_id": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vodhip_b64url_encode": (_i64, [_vp, _i64, _vp, _i64, _vp]),
     "vodhip_b64url_decode": (_i64, [_vp, _i64, _vp]),
-    # H6 serving (vodhip_serve.hip)
+    # H6 serving (vodhip_serve.hip, vodhip_http.hip)
     "vodhip_batcher_create": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _c.POINTER(_vp)]),
     "vodhip_batcher_destroy": (_i32, [_vp]),
     "vodhip_batcher_set_param": (_i32, [_vp, _c.c_char_p, _i64]),
