@@ -2,7 +2,7 @@
 // urlsafe base64 of `head || data` and back, byte-identical to Python's base64.urlsafe_b64encode / urlsafe_b64decode
 // (/root/reference/src/vod_search/io.py:17-32).  Declared in include/vodhip.h.
 //
-// Two implementations behind one entry point each, chosen once per process (cpuid):
+// Three implementations behind one entry point each, chosen once per process (cpuid): AVX-512 VBMI (below), and
 //   * AVX2 (Mula / Lemire style): 24 input bytes -> 32 characters per iteration (two multiplies split the 6-bit fields, one byte shuffle
 //     maps them to the alphabet); 32 characters -> 24 bytes (nibble look-ups translate and validate, two multiply-adds pack).
 //     Round 4: a 1024 x 768 float32 query batch is 4.2 MB of base64 - at the table-driven loops' ~2 GB/s that was ~2 ms per direction
@@ -43,6 +43,61 @@ const B64Tables& tables() {
 bool have_avx2() {
     static const bool yes = __builtin_cpu_supports("avx2");
     return yes;
+}
+bool have_vbmi() {
+    static const bool yes = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi");
+    return yes;
+}
+
+// ---- AVX-512 VBMI (Zen 4 / Zen 5, Ice Lake+): one byte permute gathers the triples, one multishift extracts the four 6-bit fields, one
+// byte permute looks the characters up: 48 bytes -> 64 characters; decoding is a 128-entry two-table permute + the two multiply-adds.
+#define VBMI __attribute__((target("avx512f,avx512bw,avx512vbmi")))
+VBMI int64_t encode_vbmi(const uint8_t* p, int64_t n, char* o) {
+    alignas(64) uint8_t gather[64];
+    for (int i = 0; i < 16; ++i) {
+        gather[4 * i + 0] = (uint8_t)(3 * i + 1);
+        gather[4 * i + 1] = (uint8_t)(3 * i + 0);
+        gather[4 * i + 2] = (uint8_t)(3 * i + 2);
+        gather[4 * i + 3] = (uint8_t)(3 * i + 1);
+    }
+    const __m512i idx = _mm512_load_si512(gather);
+    const __m512i shifts = _mm512_set1_epi64(0x3036242a1016040aLL);
+    const __m512i lut = _mm512_loadu_si512(kB64Url);
+    int64_t i = 0;
+    for (; i + 64 <= n; i += 48, o += 64) {  // (reads 64 bytes, consumes 48)
+        const __m512i in = _mm512_permutexvar_epi8(idx, _mm512_loadu_si512(p + i));
+        const __m512i six = _mm512_multishift_epi64_epi8(shifts, in);
+        _mm512_storeu_si512(o, _mm512_permutexvar_epi8(six, lut));  // (vpermb looks at the low 6 bits of each index only)
+    }
+    return i;
+}
+
+// both alphabets at once ('+' = '-' = 62, '/' = '_' = 63); anything else (padding, whitespace, junk, bytes >= 0x80) stops the vector loop
+VBMI int64_t decode_vbmi(const unsigned char* s, int64_t n, uint8_t* o) {
+    alignas(64) uint8_t table[128];
+    memset(table, 0x80, sizeof(table));
+    for (int v = 0; v < 64; ++v) table[(unsigned char)kB64Url[v]] = (uint8_t)v;
+    table[(unsigned char)'+'] = 62;
+    table[(unsigned char)'/'] = 63;
+    const __m512i lut_lo = _mm512_load_si512(table), lut_hi = _mm512_load_si512(table + 64);
+    alignas(64) uint8_t pack[64];
+    memset(pack, 0, sizeof(pack));
+    for (int j = 0; j < 16; ++j) {
+        pack[3 * j + 0] = (uint8_t)(4 * j + 2);
+        pack[3 * j + 1] = (uint8_t)(4 * j + 1);
+        pack[3 * j + 2] = (uint8_t)(4 * j + 0);
+    }
+    const __m512i pack_idx = _mm512_load_si512(pack);
+    int64_t i = 0;
+    for (; i + 64 <= n; i += 64, o += 48) {
+        const __m512i src = _mm512_loadu_si512(s + i);
+        const __m512i v = _mm512_permutex2var_epi8(lut_lo, src, lut_hi);  // 7-bit index; bit 7 of a byte >= 0x80 is checked below
+        if (_mm512_movepi8_mask(_mm512_or_si512(v, src)) != 0) break;
+        const __m512i ab = _mm512_maddubs_epi16(v, _mm512_set1_epi32(0x01400140));
+        const __m512i packed = _mm512_madd_epi16(ab, _mm512_set1_epi32(0x00011000));
+        _mm512_mask_storeu_epi8(o, 0x0000FFFFFFFFFFFFull, _mm512_permutexvar_epi8(pack_idx, packed));
+    }
+    return i;
 }
 
 // ---- AVX2 -------------------------------------------------------------------------------------------------------------------------
@@ -126,6 +181,12 @@ int64_t vodhip_b64url_encode(const uint8_t* head, int64_t n_head, const uint8_t*
     }
     if (i + 2 < n) {
         const uint8_t* p = data + (i - n_head);  // i >= n_head here
+        if (have_vbmi()) {
+            const int64_t done = encode_vbmi(p, n - i, o);
+            i += done;
+            p += done;
+            o += done / 3 * 4;
+        }
         if (have_avx2()) {
             const int64_t done = encode_avx2(p, n - i, o);
             i += done;
@@ -162,11 +223,16 @@ int64_t vodhip_b64url_decode(const char* src, int64_t n, uint8_t* out) {
     while (n > 0 && s[n - 1] == '=') --n;
     uint8_t* o = out;
     int64_t i = 0;
-    if (have_avx2() && n >= 64) {
-        // (the vector loop writes exactly 24 bytes per 32 characters; it leaves the last group to the scalar loops, whose 4-byte store of a
-        // quantum needs one more quantum behind it)
-        i = decode_avx2(s, n - 32, o);
+    if (have_vbmi() && n >= 128) {
+        i = decode_vbmi(s, n - 64, o);
         o += i / 4 * 3;
+    }
+    if (have_avx2() && n - i >= 64) {
+        // (the vector loops write exactly 3 bytes per 4 characters; they leave the last group to the scalar loops, whose 4-byte store of a
+        // quantum needs one more quantum behind it)
+        const int64_t done = decode_avx2(s + i, n - i - 32, o);
+        i += done;
+        o += done / 4 * 3;
     }
     uint32_t bad = 0;
     // the 4-byte store of a quantum spills one byte past its 3: safe while at least one more quantum (or the tail) follows
