@@ -80,12 +80,16 @@ class _RetrievalLoss(torch.autograd.Function):
         both = torch.empty((2, B, D), dtype=torch.float32, device=dev)
         small = torch.empty((8,), dtype=torch.float32, device=dev)
         n_work = 16 * B + (4 * B * D if not three_d else 0)
-        key = (dev.index, stream, n_work)
-        work = _scratch.get(key)
-        if work is None:
-            if len(_scratch) > 64:
-                _scratch.clear()
-            work = _scratch[key] = torch.empty((n_work,), dtype=torch.float32, device=dev)
+        if torch.cuda.is_current_stream_capturing():
+            # under hipGraph capture the scratch must come from the graph's own pool (and must not leak into the cache)
+            work = torch.empty((n_work,), dtype=torch.float32, device=dev)
+        else:
+            key = (dev.index, stream, n_work)
+            work = _scratch.get(key)
+            if work is None:
+                if len(_scratch) > 64:
+                    _scratch.clear()
+                work = _scratch[key] = torch.empty((n_work,), dtype=torch.float32, device=dev)
         g_type, w_g, w_ss, w_sd = aux_cfg
         aux_grad = torch.empty((3, B, D), dtype=torch.float32, device=dev) if (w_g > 0 or w_ss > 0 or w_sd > 0) else None
         p_both, p_small = both.data_ptr(), small.data_ptr()
