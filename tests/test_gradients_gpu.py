@@ -188,3 +188,37 @@ def test_plain_entry_point_matches_the_autograd_wrapper_in_batch(adjacent):
     np.testing.assert_allclose(scores.cpu().numpy(), out.retriever_scores.cpu().numpy(), rtol=2e-4, atol=2e-4)  # fp32 sums of 768 products in 1 / 2 / 4 slabs
     np.testing.assert_allclose(small[0].item(), out.loss.item(), rtol=1e-5)
     np.testing.assert_allclose(small[1].item(), out.diagnostics["kl_score"].item(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("three_d,D", [(True, 32), (False, 2048)])
+def test_graphed_step_replays_the_eager_step_bit_for_bit(three_d, D):
+    """`GraphedRetrievalStep`: forward + autograd backward captured as ONE hipGraph (the kernels are enqueued on torch's capturing stream
+    through the C-ABI).  Replays on fresh inputs - copied into the static buffers - must equal the eager step bit for bit: loss, scores,
+    diagnostics, dq, ds; with the auxiliary losses on; and the padded / no-positive rows of the fixtures' kind."""
+    from vod_amd.gradients import GraphedRetrievalStep, RetrievalGradients
+
+    B, H = 64, 768
+    rng = torch.Generator(device="cuda").manual_seed(11)
+    for cfg in ({}, {"guidance": "sparse", "guidance_weight": 0.3, "self_supervision_weight": 0.2, "score_decay": 0.01}):
+        grad = RetrievalGradients(**cfg)
+        step = GraphedRetrievalStep(grad, batch_size=B, n_sections=D, hidden=H, sections_3d=three_d, device=0)
+        for trial in range(3):
+            q = torch.randn((B, H), device="cuda", generator=rng)
+            s = torch.randn(((B, D, H) if three_d else (D, H)), device="cuda", generator=rng)
+            score = torch.randn((B, D), device="cuda", generator=rng)
+            score[torch.rand((B, D), device="cuda", generator=rng) < 0.1] = float("-inf")
+            score[:, 0] = 0.5
+            rel = (torch.rand((B, D), device="cuda", generator=rng) < 0.05).long()
+            rel[:, 0] = 1
+            rel[B // 2] = 0
+            batch = {"section__score": score, "section__relevance": rel, "section__sparse": torch.randn((B, D), device="cuda", generator=rng),
+                     "section__dense": torch.randn((B, D), device="cuda", generator=rng)}
+            out, dq, ds = step(batch=batch, query_encoding=q, section_encoding=s)
+            qe, se = q.clone().requires_grad_(), s.clone().requires_grad_()
+            ref = grad(batch=batch, query_encoding=qe, section_encoding=se)
+            ref.loss.backward()
+            assert torch.equal(out.loss, ref.loss) and torch.equal(out.retriever_scores, ref.retriever_scores)
+            assert list(out.diagnostics) == list(ref.diagnostics)
+            for key in ref.diagnostics:
+                assert torch.equal(out.diagnostics[key], ref.diagnostics[key]) or (torch.isnan(out.diagnostics[key]) and torch.isnan(ref.diagnostics[key]))
+            assert torch.equal(dq, qe.grad) and torch.equal(ds, se.grad), trial

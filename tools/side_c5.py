@@ -166,6 +166,20 @@ def measure(dev) -> tuple[dict, dict]:
 
         fwd = lambda q=q, s=s, batch=batch: grad(batch=batch, query_encoding=q, section_encoding=s)  # noqa: E731
         entry[name] = {"fwd_wall_us": _timeit(torch, fwd), "fwd_bwd_wall_us": _timeit(torch, fwd_bwd), "fwd_bwd_device_us": _device_us(torch, fwd_bwd)}
+        # the same step captured as ONE hipGraph (vod_amd.gradients.GraphedRetrievalStep): one host call per step, bit-identical results
+        try:
+            from vod_amd.gradients import GraphedRetrievalStep  # noqa: PLC0415
+
+            step = GraphedRetrievalStep(grad, batch_size=B, n_sections=D, hidden=H, sections_3d=three_d, device=dev)
+            step.load(batch=batch, query_encoding=q.detach(), section_encoding=s.detach())
+            out_g = step.replay()
+            q.grad = s.grad = None
+            out_e = grad(batch=batch, query_encoding=q, section_encoding=s)
+            out_e.loss.backward()
+            entry[name]["graphed_fwd_bwd_wall_us"] = _timeit(torch, step.replay)
+            entry[name]["graphed_equals_eager"] = bool(torch.equal(out_g.loss, out_e.loss) and torch.equal(step.dq, q.grad) and torch.equal(step.ds, s.grad))
+        except Exception as exc:  # noqa: BLE001
+            entry[name]["graphed_error"] = f"{type(exc).__name__}: {exc}"[:300]
     return entry, {"c5_data": c5_data, "loss_inputs": loss_inputs, "kw": kw}
 
 
