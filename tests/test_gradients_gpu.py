@@ -210,7 +210,8 @@ def test_graphed_step_replays_the_eager_step_bit_for_bit(three_d, D):
             score[:, 0] = 0.5
             rel = (torch.rand((B, D), device="cuda", generator=rng) < 0.05).long()
             rel[:, 0] = 1
-            rel[B // 2] = 0
+            if not cfg:
+                rel[B // 2] = 0  # a row without positives (with the self-supervision term on, the reference's loss is NaN for such a row)
             batch = {"section__score": score, "section__relevance": rel, "section__sparse": torch.randn((B, D), device="cuda", generator=rng),
                      "section__dense": torch.randn((B, D), device="cuda", generator=rng)}
             out, dq, ds = step(batch=batch, query_encoding=q, section_encoding=s)
