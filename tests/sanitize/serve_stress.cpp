@@ -156,6 +156,41 @@ int main() {
     const int rc_stop = vodhip_http_destroy(h);
     late.join();
     const int rc_b = vodhip_batcher_destroy(b);
+    // destroy with callers INSIDE the batcher (one batch in the engine, the rest queued behind it): everyone returns - its rows or the
+    // shut-down error - and the handle is freed only after the last caller has left (ASan / TSan see a use-after-free otherwise)
+    int inside_bad = 0;
+    for (int round = 0; round < 8; ++round) {
+        vodhip_batcher_t* b2 = nullptr;
+        if (vodhip_batcher_create(nullptr, nullptr, engine, nullptr, D, 0, &b2)) return 1;
+        vodhip_batcher_set_param(b2, "grace_us", 0);
+        std::atomic<int> returned{0}, wrong{0};
+        std::vector<std::thread> in;
+        for (int t = 0; t < 6; ++t)
+            in.emplace_back([&, t] {
+                std::vector<float> q((size_t)(2 * D), (float)(t + 1)), s2(2 * 3), rs(2 * 3);
+                std::vector<int64_t> id(2 * 3), rid(2 * 3);
+                std::this_thread::sleep_for(std::chrono::microseconds(40 * t));
+                const int rc = vodhip_batcher_search(b2, q.data(), VODHIP_F32, 2, 3, nullptr, 0, (uint64_t)(t + 1), s2.data(), id.data());
+                if (rc == 0) {
+                    brute(q.data(), 2, 3, rs.data(), rid.data());
+                    if (memcmp(id.data(), rid.data(), sizeof(int64_t) * id.size())) ++wrong;
+                } else if (!strstr(vodhip_last_error(), "shut")) {
+                    ++wrong;
+                }
+                ++returned;
+            });
+        for (;;) {  // until all six are inside (assembled into a batch, or queued): a call on a freed handle would be the harness's bug
+            int64_t assembled = 0, queued = 0;
+            vodhip_batcher_get_stat(b2, "requests", &assembled);
+            vodhip_batcher_get_stat(b2, "pending", &queued);
+            if (assembled + queued == 6) break;
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        if (vodhip_batcher_destroy(b2)) ++inside_bad;
+        for (auto& t : in) t.join();
+        if (returned.load() != 6 || wrong.load()) ++inside_bad;
+    }
+    if (inside_bad) { fprintf(stderr, "destroy with callers inside: %d bad rounds\n", inside_bad); return 1; }
     printf("serve_stress: %d engine calls, %lld batches for %lld requests, %lld native http requests, %d errors (%d result mismatches), stop %d / %d\n", g_calls.load(),
            (long long)batches, (long long)requests, (long long)native, g_errors.load(), g_mismatch.load(), rc_stop, rc_b);
     return (g_errors.load() == 0 && rc_stop == 0 && rc_b == 0 && batches < requests) ? 0 : 1;

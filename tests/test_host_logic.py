@@ -1,5 +1,6 @@
 """CPU tests: host-side mirror of the reference interface (containers, codec, routing, server contract),
 and the C-ABI library's exported symbols.  No compute call touches a GPU here."""
+import ctypes
 import json
 import pickle
 import re
@@ -1118,3 +1119,105 @@ def test_wire_codec_vector_paths_equal_pythons_base64():
                 broken = bytearray(ref)
                 broken[int(rng.integers(0, len(body)))] = int(rng.choice(list(b"!@# \n*~\x80\xff")))
                 assert dec(bytes(broken)) is None, (nh, nd)
+
+
+def test_native_batcher_can_be_closed_while_callers_are_inside():
+    """Shutdown with searches in every state.  (1) `vodhip_batcher_destroy` itself: one request running in the engine, five queued
+    behind it - each caller returns (its rows, or the "shut down" error), none hangs, the handle is freed after the last one left.
+    (2) `NativeBatcher.close()` racing threads that search in a loop: the calls already counted finish normally, later ones are refused
+    by the wrapper and never reach the freed handle."""
+    import threading
+    import time
+
+    from vod_amd.search.native import NativeBatcher
+
+    rng = np.random.default_rng(5)
+    x = rng.integers(-4, 5, size=(200, 8)).astype(np.float32)
+
+    class Slow(_OracleEngine):
+        def search(self, q, k):
+            time.sleep(0.08)
+            return super().search(q, k)
+
+    # (1) the library
+    mb = NativeBatcher(engine=Slow(x), dim=8, grace_us=0)
+    outcomes: list = []
+
+    def once(i):
+        q = rng.integers(-4, 5, size=(2, 8)).astype(np.float32)
+        time.sleep(0.005 * i)  # the first request starts a batch of its own, the others queue behind it
+        try:
+            s, ids = mb.search(q, 3, client=i + 1)
+            outcomes.append(ids.shape == (2, 3))
+        except _native_error() as exc:
+            outcomes.append("shut" in str(exc))
+
+    threads = [threading.Thread(target=once, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    time.sleep(0.05)
+    assert mb.get_stat("pending") + mb.get_stat("in_flight") >= 2
+    h, mb._h = mb._h, None
+    assert mb._lib.vodhip_batcher_destroy(h) == 0
+    for t in threads:
+        t.join(timeout=20)
+    assert not any(t.is_alive() for t in threads) and len(outcomes) == 6 and all(outcomes)
+    assert any(o is True for o in outcomes)
+
+    # (2) the wrapper
+    mb = NativeBatcher(engine=Slow(x), dim=8)
+    outcomes = []
+
+    def loop(i):
+        q = rng.integers(-4, 5, size=(2, 8)).astype(np.float32)
+        try:
+            while True:
+                s, ids = mb.search(q, 3, client=i + 1)
+                outcomes.append(ids.shape == (2, 3))
+        except RuntimeError as exc:
+            outcomes.append("closed" in str(exc))
+
+    threads = [threading.Thread(target=loop, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    time.sleep(0.2)
+    mb.close()
+    for t in threads:
+        t.join(timeout=20)
+    assert not any(t.is_alive() for t in threads) and len(outcomes) >= 12 and all(outcomes)
+
+
+def test_native_wire_parser_refuses_shapes_that_overflow():
+    from vod_amd import _native
+
+    lib = _native.load_library()
+    for shape in ("(99999999999, 99999999999)", "(4611686018427387904, 8)", "(3, 4611686018427387904)"):
+        head = ("{'descr': '<f4', 'fortran_order': False, 'shape': %s, }" % shape).ljust(117) + "\n"
+        blob = b"\x93NUMPY\x01\x00" + len(head).to_bytes(2, "little") + head.encode() + b"\0" * 64
+        dt, rows, cols, off = ctypes.c_int(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        assert lib.vodhip_wire_parse_npy(blob, len(blob), ctypes.byref(dt), ctypes.byref(rows), ctypes.byref(cols), ctypes.byref(off)) == -1
+
+
+def test_native_http_front_sends_any_content_type_the_fallback_chooses():
+    import http.client
+
+    from vod_amd.search.native import NativeBatcher, NativeHttpFront
+
+    class Ends:
+        def handle(self, method, path, query, body, client=0):
+            return 200, "text/" + "x" * 900, b"ok", {"x-long": "y" * 2000}
+
+    mb = NativeBatcher(engine=_OracleEngine(np.zeros((4, 8), np.float32)), dim=8)
+    front = NativeHttpFront(mb, Ends())
+    port = front.listen("127.0.0.1", 0)
+    front.start()
+    try:
+        c = http.client.HTTPConnection("127.0.0.1", port, timeout=5)
+        c.request("GET", "/anything")
+        r = c.getresponse()
+        assert r.status == 200 and r.read() == b"ok"
+        assert r.getheader("content-type") == "text/" + "x" * 900 and r.getheader("x-long") == "y" * 2000
+        c.close()
+    finally:
+        front.close()
+        mb.close()

@@ -7,6 +7,7 @@
 #include "../../include/vodhip.h"
 
 #include <arpa/inet.h>
+#include <fcntl.h>
 #include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -140,7 +141,9 @@ int parse_npy_2d(const uint8_t* data, int64_t n, int* dtype, int64_t* rows, int6
     }
     if (i >= vn || v[i] != ')') return -1;
     const int64_t es = *dtype == VODHIP_F32 ? 4 : 2;
-    if (10 + hlen + dims[0] * dims[1] * es > n) return -1;
+    int64_t payload = 0;
+    if (__builtin_mul_overflow(dims[0], dims[1], &payload) || __builtin_mul_overflow(payload, es, &payload)) return -1;
+    if (payload > n - 10 - hlen) return -1;
     *rows = dims[0];
     *cols = dims[1];
     *offset = 10 + hlen;
@@ -379,10 +382,12 @@ bool send_all(int fd, const void* a, size_t na, const void* b2, size_t nb) {
 }
 
 bool send_reply(int fd, int status, const char* ctype, const std::string& extra, const void* payload, size_t n, bool keep) {
-    char head[512];
-    const int hn = snprintf(head, sizeof(head), "HTTP/1.1 %d %s\r\ncontent-type: %s\r\ncontent-length: %zu\r\nconnection: %s\r\n", status,
-                            reason_of(status), ctype, n, keep ? "keep-alive" : "close");
+    char head[160];
+    int hn = snprintf(head, sizeof(head), "HTTP/1.1 %d %s\r\ncontent-type: ", status, reason_of(status));
     std::string h(head, (size_t)hn);
+    h += ctype;  // (the host's fallback chooses it: any length)
+    hn = snprintf(head, sizeof(head), "\r\ncontent-length: %zu\r\nconnection: %s\r\n", n, keep ? "keep-alive" : "close");
+    h.append(head, (size_t)hn);
     h += extra;
     h += "\r\n";
     return send_all(fd, h.data(), h.size(), payload, n);
@@ -675,6 +680,18 @@ void conn_main(vodhip_http* h, int fd, uint64_t client) {
                 ok = send_reply(fd, reply.status, reply.ctype.c_str(), reply.extra, reply.payload.data(), reply.payload.size(), keep);
             }
             if (!ok || !keep) goto done;
+            // a kept-alive connection does not hold on to the buffers of one unusually large request
+            constexpr size_t KEEP_BYTES = 64u << 20;
+            for (Buf* bf : {&cs.body, &cs.decoded, &cs.reply})
+                if (bf->cap > KEEP_BYTES) {
+                    free(bf->p);
+                    bf->p = nullptr;
+                    bf->cap = 0;
+                }
+            if (cs.ids.capacity() * sizeof(int64_t) > KEEP_BYTES) {
+                std::vector<float>().swap(cs.scores);
+                std::vector<int64_t>().swap(cs.ids);
+            }
         }
     }
 done:
@@ -690,7 +707,10 @@ done:
 
 void accept_main(vodhip_http* h) {
     std::vector<struct pollfd> pfds;
-    for (int fd : h->listen_fds) pfds.push_back({fd, POLLIN, 0});
+    for (int fd : h->listen_fds) {
+        (void)fcntl(fd, F_SETFL, fcntl(fd, F_GETFL, 0) | O_NONBLOCK);  // (accepted sockets do not inherit it on Linux)
+        pfds.push_back({fd, POLLIN, 0});
+    }
     pfds.push_back({h->wake_pipe[0], POLLIN, 0});
     while (!h->stop.load()) {
         const int r = poll(pfds.data(), pfds.size(), -1);
@@ -701,8 +721,12 @@ void accept_main(vodhip_http* h) {
         if (h->stop.load()) break;
         for (size_t i = 0; i + 1 < pfds.size(); ++i) {
             if (!(pfds[i].revents & POLLIN)) continue;
-            const int fd = accept(pfds[i].fd, nullptr, nullptr);
-            if (fd < 0) continue;
+            const int fd = accept(pfds[i].fd, nullptr, nullptr);  // (the listeners are non-blocking: a connection reset between poll and accept)
+            if (fd < 0) {
+                if (errno == EMFILE || errno == ENFILE || errno == ENOBUFS || errno == ENOMEM)  // out of descriptors: the backlog stays
+                    std::this_thread::sleep_for(std::chrono::milliseconds(20));                 // readable - do not spin on it
+                continue;
+            }
             int one = 1;
             (void)setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));  // (fails harmlessly on a Unix-domain socket)
             const uint64_t client = h->client_base + h->next_client.fetch_add(1);

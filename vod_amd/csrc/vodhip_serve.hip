@@ -155,6 +155,8 @@ struct vodhip_batcher {
     };
     std::unordered_map<uint64_t, Client> clients;  // client tag -> what is known about its rhythm
     bool stop = false;
+    bool closing = false;  // destroy has begun: new searches are refused, the ones already inside are drained
+    int callers = 0;       // threads inside vodhip_batcher_search (destroy waits for them before it frees the handle)
     std::thread th_sched, th_compl;
     double ema_flat_scan_ns = 0.0;  // duration of batches of <= flat_queries queries that started on an idle engine
     double ema_tiles_ns[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... and of batches of t query tiles (256 queries each) that started on an idle engine
@@ -589,6 +591,7 @@ int vodhip_batcher_destroy(vodhip_batcher_t* b) {
     if (!b) return 0;
     {
         std::unique_lock<std::mutex> lk(b->mu);
+        b->closing = true;  // (a search that arrives from now on is refused: nothing may join `pending` behind the scheduler's back)
         // requests that were never assembled fail; batches on the device are completed first
         for (Request* r : b->pending) {
             r->batch = nullptr;
@@ -605,8 +608,8 @@ int vodhip_batcher_destroy(vodhip_batcher_t* b) {
     if (b->th_compl.joinable()) b->th_compl.join();
     {
         std::unique_lock<std::mutex> lk(b->mu);
-        for (;;) {  // callers still copying their rows out
-            bool used = false;
+        for (;;) {  // callers still copying their rows out / on their way out of vodhip_batcher_search (they touch the handle's mutex last)
+            bool used = b->callers > 0;
             for (const Slot& s : b->slots) used = used || s.busy;
             if (!used) break;
             b->cv_sched.wait_for(lk, std::chrono::milliseconds(5));
@@ -691,7 +694,16 @@ int vodhip_batcher_search(vodhip_batcher_t* b, const void* queries, int q_dtype,
     r.out_s = out_scores;
     r.out_i = out_ids;
     std::unique_lock<std::mutex> lk(b->mu);
-    if (b->stop) return sfail("the batcher is shutting down");
+    if (b->stop || b->closing) return sfail("the batcher is shutting down");
+    ++b->callers;
+    struct Leave {  // runs before `lk` unlocks on every way out: the handle stays alive until the count is back to zero
+        vodhip_batcher* b;
+        std::unique_lock<std::mutex>& lk;
+        ~Leave() {
+            if (!lk.owns_lock()) lk.lock();
+            --b->callers;
+        }
+    } leave{b, lk};
     r.t_arrive = clock_t_::now();
     if (client) {
         vodhip_batcher::Client& c = b->clients[client];
@@ -728,7 +740,6 @@ int vodhip_batcher_search(vodhip_batcher_t* b, const void* queries, int q_dtype,
         delete bt;
         b->cv_sched.notify_all();
     }
-    lk.unlock();
     if (rc) {
         vodhip::set_last_error(err.c_str());
         return -1;

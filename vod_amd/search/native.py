@@ -46,6 +46,12 @@ class NativeBatcher:
         handle = ctypes.c_void_p()
         _native.check(self._lib.vodhip_batcher_create(h_index, h_node, self._cb, None, self.dim, int(id_base), ctypes.byref(handle)))
         self._h = handle
+        # `close` may race with searches on other threads: a call is counted from before it reads the handle until it has returned, `close`
+        # refuses new calls, lets the counted ones finish normally and only then destroys the handle (the library drains its own callers
+        # too - vodhip_batcher_destroy - but cannot protect a Python thread that has read the handle and not yet entered the library)
+        self._gate = threading.Condition()
+        self._active = 0
+        self._closed = False
         for key, value in params.items():
             self.set_param(key, value)
 
@@ -104,10 +110,20 @@ class NativeBatcher:
             sub_ptr, n_sub = sub.ctypes.data, int(sub.shape[1])
         scores = np.empty((nq, max(k, 0)), dtype=np.float32)
         ids = np.empty((nq, max(k, 0)), dtype=np.int64)
-        rc = self._lib.vodhip_batcher_search(self._h, q.ctypes.data, _native.numpy_dtype_code(q.dtype), nq, k, sub_ptr, n_sub, int(client),
-                                             scores.ctypes.data, ids.ctypes.data)  # (ctypes releases the GIL for the whole wait)
+        with self._gate:
+            if self._closed:
+                raise RuntimeError("the batcher is closed")
+            self._active += 1
+        try:
+            rc = self._lib.vodhip_batcher_search(self._h, q.ctypes.data, _native.numpy_dtype_code(q.dtype), nq, k, sub_ptr, n_sub, int(client),
+                                                 scores.ctypes.data, ids.ctypes.data)  # (ctypes releases the GIL for the whole wait)
+            msg = (self._lib.vodhip_last_error() or b"").decode("utf-8", "replace") if rc != 0 else ""
+        finally:
+            with self._gate:
+                self._active -= 1
+                if self._active == 0:
+                    self._gate.notify_all()
         if rc != 0:
-            msg = (self._lib.vodhip_last_error() or b"").decode("utf-8", "replace")
             found = re.search(r"search callback failed \(status (\d+)\)", msg) if self._cb is not None else None
             if found and int(found.group(1)) in self._failures:
                 raise self._failures[int(found.group(1))]  # the engine's own exception (ValueError from a bad argument, ...): what a direct call would raise
@@ -115,9 +131,14 @@ class NativeBatcher:
         return scores, ids
 
     def close(self) -> None:
-        if getattr(self, "_h", None):
-            self._lib.vodhip_batcher_destroy(self._h)
-            self._h = None
+        if not getattr(self, "_h", None):
+            return
+        with self._gate:
+            self._closed = True
+            self._gate.wait_for(lambda: self._active == 0, timeout=60.0)
+            h, self._h = self._h, None
+        if h:
+            self._lib.vodhip_batcher_destroy(h)
 
     def __del__(self):  # pragma: no cover - best effort
         try:
