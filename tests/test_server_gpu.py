@@ -439,6 +439,52 @@ def test_concurrent_callers_while_every_search_overflows(tmp_path):
     engine.close()
 
 
+def test_engine_can_be_closed_while_searches_are_in_flight(tmp_path):
+    """`HipEngine.close()` with caller threads inside the batcher and batches on the device: searches already counted finish with
+    their exact rows, later ones are refused (`RuntimeError: ... closed`), nothing hangs and nothing touches the freed handles."""
+    import threading
+
+    from oracle.flat_ip import flat_ip_topk
+    from vod_amd import store
+    from vod_amd.search.server import HipEngine
+
+    rng = np.random.default_rng(13)
+    n, d = 200_000, 64
+    x = rng.integers(-8, 9, size=(n, d)).astype(np.float32)
+    store.save_vectors(tmp_path / "v.npy", x, dtype=np.float16)
+    for trial in range(3):
+        engine = HipEngine(str(tmp_path / "v.npy"))
+        answered, refused, wrong = [], [], []
+
+        def loop(i):
+            r = np.random.default_rng(100 * trial + i)
+            try:
+                while True:
+                    q = r.integers(-8, 9, size=(int(r.integers(1, 300)), d)).astype(np.float32)
+                    s, ids = engine.batcher.search(q, 20, client=i + 1)
+                    answered.append((q, s, ids))
+            except RuntimeError as exc:
+                (refused if "closed" in str(exc) else wrong).append(str(exc))
+            except Exception as exc:  # noqa: BLE001
+                wrong.append(repr(exc))
+
+        threads = [threading.Thread(target=loop, args=(i,)) for i in range(10)]
+        for t in threads:
+            t.start()
+        time.sleep(0.15 + 0.1 * trial)
+        batcher = engine.batcher
+        batcher.close()          # drains the counted calls, refuses the rest, then frees the library handle
+        for t in threads:
+            t.join(timeout=60)
+        assert not any(t.is_alive() for t in threads)
+        engine.close()
+        assert not wrong and len(refused) == 10 and len(answered) > 10
+        for q, s, ids in answered[-12:]:
+            rs, ri = flat_ip_topk(q, x, 20)
+            np.testing.assert_array_equal(ids, ri)
+            np.testing.assert_array_equal(s, rs)
+
+
 def test_master_with_a_unix_domain_socket(tmp_path):
     """`HipMipsMaster(uds=True)`: the spawned server also listens on a Unix-domain socket, `get_client()` searches through it
     (SURVEY 8f-4's transport item), results equal the oracle; the socket file goes away with the server."""
