@@ -47,5 +47,13 @@ case $P in
   openloop)  # arrivals NOT synchronised by the server: workers pause Exp(think) between requests; default policy vs never waiting for company
     timeout 900 python tools/bench_http_load.py --routes fast --clients 8 32 --nq 32 --think-ms 2 10 --out $OUT/http_openloop_default.json > $OUT/openloop_default.log 2>&1; tail -5 $OUT/openloop_default.log | cut -c1-330
     timeout 900 python tools/bench_http_load.py --routes fast --clients 8 32 --nq 32 --think-ms 2 10 --batcher-param grace_us=0 --out $OUT/http_openloop_nograce.json > $OUT/openloop_nograce.log 2>&1; tail -5 $OUT/openloop_nograce.log | cut -c1-330 ;;
+  final)  # at the round's last HEAD: serving tests, the randomised campaigns on fresh seeds, the default-flag load cells
+    timeout 900 python -m pytest tests/test_server_gpu.py tests/test_node_index_gpu.py -x -q -m gpu > $OUT/pytest_serve.log 2>&1; tail -3 $OUT/pytest_serve.log
+    for args in "--requests 800 --threads 16 --seed 51" "--requests 500 --threads 12 --seed 53 --group" "--requests 500 --threads 12 --seed 54 --node" "--requests 400 --threads 16 --seed 56 --churn"; do
+      timeout 900 python tests/fuzz/fuzz_server.py $args 2>/dev/null | tail -2 | tee -a $OUT/fuzz_server.txt
+    done
+    timeout 1200 python tests/fuzz/fuzz_search.py --trials 2500 --seed 504 2>/dev/null | tail -2 | tee -a $OUT/fuzz_search.txt
+    timeout 900 python tests/fuzz/fuzz_collate.py --trials 4000 --seed 505 2>/dev/null | tail -2 | tee -a $OUT/fuzz_collate.txt
+    timeout 1200 python tools/bench_http_load.py --routes fast --out $OUT/http_load_native.json > $OUT/http_load_native.log 2>&1; tail -12 $OUT/http_load_native.log | cut -c1-420 ;;
   *) echo "unknown pass $P"; exit 2 ;;
 esac
