@@ -165,6 +165,8 @@ int vodhip_merge_topk_strided(const float* scores, int64_t shard_stride_scores, 
  *           location = VODHIP_DEVICE: they live on devices[0]; the queries must be complete on `stream` and the outputs are complete
  *           on `stream` when the call returns (the exactness check of every shard has already been done on the host).
  *   shard   the per-device handle (for params, stats, subset labels, persistence), its id offset and its device.
+ * Calls on one handle are serialised by the library (a mutex per handle); a search that fails half-way leaves no shard with a search
+ * in flight.  `set_query_labels` + `search` are two calls: callers that filter from several threads go through a vodhip_batcher.
  * ------------------------------------------------------------------------------------------- */
 typedef struct vodhip_node_index vodhip_node_index_t;
 int vodhip_node_index_create(int n_devices, const int* devices, int64_t dim, int store_dtype, int64_t capacity_rows,

@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -80,6 +81,10 @@ struct vodhip_node_index {
     void* pin_q = nullptr;             // the query batch (+ subset labels) staged from devices[0]
     size_t pin_q_bytes = 0;
     hipEvent_t q_on_host = nullptr;
+    // add / reset / label changes / searches on one handle are serialised (the staging buffers and the shards' FIFOs are shared); a
+    // `set_query_labels` + `search` pair is two calls: callers that filter from several threads go through a vodhip_batcher
+    std::mutex mu;
+    std::vector<char> enqueued;        // shard g has a search of the CURRENT call in its FIFO (drained if the call fails half-way)
     bool staged(int g) const { return g > 0 && (host_staging != 0 || (device[g] != device[0] && peer_ok[g] == 0)); }
 };
 
@@ -197,6 +202,7 @@ int vodhip_node_index_destroy(vodhip_node_index_t* nx) {
 
 int vodhip_node_index_add(vodhip_node_index_t* nx, const void* rows, int64_t n_rows, int src_dtype) {
     if (!nx) return nfail("index is NULL");
+    std::lock_guard<std::mutex> guard(nx->mu);
     if (n_rows < 0 || (n_rows > 0 && !rows)) return nfail("invalid rows");
     if (src_dtype < 0 || src_dtype > 2) return nfail("invalid src_dtype %d", src_dtype);
     if (nx->ntotal + n_rows > nx->capacity)
@@ -233,6 +239,7 @@ int vodhip_node_index_add(vodhip_node_index_t* nx, const void* rows, int64_t n_r
 
 int vodhip_node_index_reset(vodhip_node_index_t* nx) {
     if (!nx) return nfail("index is NULL");
+    std::lock_guard<std::mutex> guard(nx->mu);
     for (int g = 0; g < nx->n; ++g)
         if (vodhip_index_reset(nx->shard[g])) return -1;
     nx->ntotal = 0;
@@ -259,6 +266,7 @@ int vodhip_node_index_shard(vodhip_node_index_t* nx, int g, vodhip_index_t** sha
 int vodhip_node_index_set_row_labels(vodhip_node_index_t* nx, const int32_t* labels, int64_t n_rows) {
     if (!nx) return nfail("index is NULL");
     if (labels && (n_rows < 0 || n_rows > nx->capacity)) return nfail("n_rows=%lld out of range", (long long)n_rows);
+    std::lock_guard<std::mutex> guard(nx->mu);
     for (int g = 0; g < nx->n; ++g) {
         const int64_t lo = std::min<int64_t>(n_rows, g * nx->rows_per_shard), hi = std::min<int64_t>(n_rows, lo + nx->rows_per_shard);
         if (!labels) {
@@ -277,6 +285,7 @@ int vodhip_node_index_set_query_labels(vodhip_node_index_t* nx, const int32_t* q
     if (q_labels && (n_per_query < 1 || n_per_query > 64)) return nfail("n_per_query must be in [1, 64]");
     if (q_labels && !nx->has_row_labels) return nfail("set the row labels first (vodhip_node_index_set_row_labels)");
     if (location != VODHIP_HOST && location != VODHIP_DEVICE) return nfail("invalid location %d", location);
+    std::lock_guard<std::mutex> guard(nx->mu);
     nx->q_labels = q_labels;
     nx->q_labels_per_query = q_labels ? n_per_query : 0;
     nx->q_labels_location = location;
@@ -285,6 +294,7 @@ int vodhip_node_index_set_query_labels(vodhip_node_index_t* nx, const int32_t* q
 
 int vodhip_node_index_set_param(vodhip_node_index_t* nx, const char* key, int64_t value) {
     if (!nx) return nfail("index is NULL");
+    std::lock_guard<std::mutex> guard(nx->mu);
     if (key && !strcmp(key, "host_staging")) {  // 1: every shard but the first exchanges with devices[0] through pinned host memory
         nx->host_staging = value;
         return 0;
@@ -294,9 +304,12 @@ int vodhip_node_index_set_param(vodhip_node_index_t* nx, const char* key, int64_
     return 0;
 }
 
-int vodhip_node_index_search(vodhip_node_index_t* nx, const void* queries, int q_dtype, int64_t nq, int k, int location,
-                             float* out_scores, int64_t* out_ids, void* stream_) {
-    if (!nx) return nfail("index is NULL");
+}  // extern "C"
+
+namespace {
+
+int node_search_locked(vodhip_node_index* nx, const void* queries, int q_dtype, int64_t nq, int k, int location, float* out_scores,
+                       int64_t* out_ids, void* stream_) {
     if (k < 1 || k > VODHIP_MAX_K) return nfail("k=%d out of range [1, %d]", k, VODHIP_MAX_K);
     if (nq < 0 || (nq > 0 && (!queries || !out_scores || !out_ids))) return nfail("invalid query / output pointers");
     if (q_dtype < 0 || q_dtype > 2) return nfail("invalid q_dtype %d", q_dtype);
@@ -386,15 +399,16 @@ int vodhip_node_index_search(vodhip_node_index_t* nx, const void* queries, int q
         int64_t* i_out = G == 1 ? final_ids : nx->buf[g].ids;
         if (vodhip_index_search_async(nx->shard[g], nx->buf[g].q, q_dtype, nq, k, g * nx->rows_per_shard, s_out, i_out, nx->stream[g])) {
             const std::string keep = vodhip_last_error();
-            for (int h = 0; h < g; ++h) (void)vodhip_index_search_finish(nx->shard[h], nx->stream[h]);  // nothing stays in flight
             return nfail("shard %d: %s", g, keep.c_str());
         }
+        nx->enqueued[g] = 1;
     }
     // 2. exactness check of every shard (host side; a shard that needs a recovery pass runs it on its own stream), then its list
     //    travels to devices[0]
     int rc = 0;
     std::string first_error;
     for (int g = 0; g < G; ++g) {
+        nx->enqueued[g] = 0;
         if (vodhip_index_search_finish(nx->shard[g], nx->stream[g])) {
             if (!rc) first_error = std::string("shard ") + std::to_string(g) + ": " + vodhip_last_error();
             rc = -1;
@@ -458,6 +472,28 @@ int vodhip_node_index_search(vodhip_node_index_t* nx, const void* queries, int q
         NODE_HIP_OK(hipSetDevice(dev0));
     }
     return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vodhip_node_index_search(vodhip_node_index_t* nx, const void* queries, int q_dtype, int64_t nq, int k, int location,
+                             float* out_scores, int64_t* out_ids, void* stream_) {
+    if (!nx) return nfail("index is NULL");
+    std::lock_guard<std::mutex> guard(nx->mu);
+    nx->enqueued.assign((size_t)nx->n, 0);
+    const int rc = node_search_locked(nx, queries, q_dtype, nq, k, location, out_scores, out_ids, stream_);
+    if (rc) {
+        // whatever failed (a copy, an allocation, one shard's search): no shard keeps a search of this call in its FIFO - the next
+        // call's `finish` must meet the next call's search
+        const std::string keep = vodhip_last_error();
+        for (int g = 0; g < nx->n; ++g)
+            if (nx->enqueued[(size_t)g]) (void)vodhip_index_search_finish(nx->shard[g], nx->stream[g]);
+        (void)hipGetLastError();
+        vodhip::set_last_error(keep.c_str());
+    }
+    return rc;
 }
 
 }  // extern "C"
