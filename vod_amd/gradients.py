@@ -225,6 +225,8 @@ class GraphedRetrievalStep:
             self.section_encoding.copy_(section_encoding)
             for key, dst in self.batch.items():
                 if dst is None:
+                    if get(key) is not None:
+                        raise ValueError(f"the step was captured without `{key}`: the set of optional fields is fixed at capture")
                     continue
                 src = get(key)
                 if src is None:
