@@ -263,8 +263,13 @@ int vodhip_retrieval_backward(const void* q, const void* s, int enc_dtype, int s
  * Outputs: samples int64 [nq, k_total] = column index into the row (-1 padded), log_weights float32
  * [nq, k_total] (-inf padded), out_labels uint8 [nq, k_total], lse float32 [nq, 2] (positives, negatives).
  * Reference quirks kept: support truncation masks entries >= the
- * `max_support_size`-th largest; ties in the priority keys are broken by the smaller column.
+ * `max_support_size`-th largest - it REMOVES the best entries of each class (src/vod_dataloaders/core/sample.py:176-178); ties in
+ * the priority keys are broken by the smaller column.  `normalized` is a flag word: bit 0 = log-softmax the selected weights
+ * (the reference's `normalized`), bit 1 = VODHIP_SAMPLE_KEEP_TOP_SUPPORT: the corrected truncation - KEEP the `max_support_size`
+ * best entries of each class, mask the rest (what the parameter's name and the shipped `support_size: 100` intend).  Off by
+ * default everywhere: bit parity with the reference is the default.
  * ------------------------------------------------------------------------------------------- */
+#define VODHIP_SAMPLE_KEEP_TOP_SUPPORT 2
 int vodhip_priority_sample(const float* scores, const uint8_t* labels, const float* noise, int64_t nq, int width,
                            int k_positive, int k_total, float temperature, int max_support_size, int normalized,
                            int64_t* out_samples, float* out_log_weights, uint8_t* out_labels, float* out_lse,
@@ -336,7 +341,7 @@ typedef struct vodhip_collate_args {
     /* sampling parameters (sample_search_results' arguments) */
     int32_t k_positive, k_total, max_support_size, in_batch_negatives;
     float temperature;
-    int32_t reserved;
+    int32_t flags;                                    /* 0, or VODHIP_SAMPLE_KEEP_TOP_SUPPORT */
     /* workspace: the merged rows at full stride (also an output: what _merge_search_results returns, uncut) */
     int64_t* merged_idx;                              /* [nq, stride] */
     int64_t* merged_lbl;                              /* [nq, stride] */

@@ -37,14 +37,17 @@ def _log_softmax_1d(x: np.ndarray) -> np.ndarray:
     return x
 
 
-def priority_sampling_1d(scores: np.ndarray, noise: np.ndarray, k: int, temperature: float = 1.0, max_support_size: int = -1):
+def priority_sampling_1d(scores: np.ndarray, noise: np.ndarray, k: int, temperature: float = 1.0, max_support_size: int = -1, keep_top: bool = False):
     dt = scores.dtype.type
     with np.errstate(all="ignore"):
         t_inv = dt(temperature if temperature > 0 else 1.0)
         log_p = (scores * t_inv).astype(scores.dtype)
         if max_support_size > 0 and len(log_p) > max_support_size:
             thr = np.sort(log_p)[-max_support_size]
-            log_p[log_p >= thr] = dt(-np.inf)  # Q8: removes the top entries
+            if keep_top:  # the CORRECTED truncation (no reference counterpart: what `max_support_size` is named for) - keep the best entries
+                log_p[log_p < thr] = dt(-np.inf)
+            else:
+                log_p[log_p >= thr] = dt(-np.inf)  # Q8: removes the top entries
         log_p = _log_softmax_1d(log_p)
         log_norm = np.log(np.sum(np.exp(log_p)))
         log_u = np.log(noise)
@@ -64,7 +67,7 @@ def priority_sampling_1d(scores: np.ndarray, noise: np.ndarray, k: int, temperat
     return sorted_ids, log_w.astype(scores.dtype), log_norm
 
 
-def labeled_priority_sampling_2d(scores, labels, noise, k_positive, k_total, normalized=True, temperature=1.0, max_support_size=-1):
+def labeled_priority_sampling_2d(scores, labels, noise, k_positive, k_total, normalized=True, temperature=1.0, max_support_size=-1, keep_top=False):
     nq, n = scores.shape
     out_samples = np.full((nq, k_total), -1, dtype=np.int64)
     out_logw = np.full((nq, k_total), -np.inf, dtype=scores.dtype)
@@ -80,11 +83,11 @@ def labeled_priority_sampling_2d(scores, labels, noise, k_positive, k_total, nor
         kp = k_positive
         if n_neg_finite < kt - kp:
             kp = kt - n_neg_finite
-        ps, pw, plse = priority_sampling_1d(scores[r][lab], noise[r][lab], kp, temperature, max_support_size)
+        ps, pw, plse = priority_sampling_1d(scores[r][lab], noise[r][lab], kp, temperature, max_support_size, keep_top)
         pos = idx[lab][ps]
         if normalized and len(pos) > 0:
             pw = _log_softmax_1d(pw)
-        ns, nw, nlse = priority_sampling_1d(scores[r][nlab], noise[r][nlab], kt - len(ps), temperature, max_support_size)
+        ns, nw, nlse = priority_sampling_1d(scores[r][nlab], noise[r][nlab], kt - len(ps), temperature, max_support_size, keep_top)
         neg = idx[nlab][ns]
         if normalized and len(neg) > 0:
             nw = _log_softmax_1d(nw)
@@ -116,7 +119,7 @@ def flatten_samples(indices, scores, labels, log_weights, raw_scores: dict, padd
     }
 
 
-def sample_search_results(indices, scores, labels, raw_scores: dict, noise, total, max_pos_sections, temperature=1.0, max_support_size=None):
+def sample_search_results(indices, scores, labels, raw_scores: dict, noise, total, max_pos_sections, temperature=1.0, max_support_size=None, keep_top=False):
     """sample.py:22-84 with the noise of sample.py:398 passed in.  Returns a dict of the `PrioritySampledSections` fields."""
     total = total or scores.shape[-1]
     max_pos_sections = max_pos_sections or total
@@ -126,7 +129,7 @@ def sample_search_results(indices, scores, labels, raw_scores: dict, noise, tota
         max_support_size = max(max_support_size, total)
     with np.errstate(all="ignore"):
         local, logw, lab, lse = labeled_priority_sampling_2d(scores, labels_ref, noise, max_pos_sections, total, True, temperature,
-                                                             max_support_size)
+                                                             max_support_size, keep_top)
     take = lambda a: np.take_along_axis(a, local, axis=-1)  # noqa: E731  (-1 pads take the LAST column, as NumPy indexes)
     smp_scores = take(scores)
     min_neg = np.amin(np.where((lab <= 0) & np.isfinite(smp_scores), smp_scores, np.inf), axis=-1, keepdims=True)

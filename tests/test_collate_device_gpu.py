@@ -164,6 +164,7 @@ def _random_engines(rng, nq, kl, ks, pool, pad_frac, dup_frac):
     return (l_idx, l_lbl), [eng(k) for k in ks]
 
 
+@pytest.mark.parametrize("mode", ["reference", "keep_top"])  # Q8's support truncation as the reference has it / corrected
 @pytest.mark.parametrize("nq,kl,ks,pool,pad,dup,total,kpos,temp,support", [
     (64, 128, (128, 128), 1_000_000, 0.1, 0.0, 32, 8, 1.0, 100),      # C5: B = 64, K = 128 per engine, 32 sampled sections
     (64, 128, (128, 128), 600, 0.1, 0.0, 32, 8, 1.0, None),            # heavy overlap between the engines
@@ -172,7 +173,9 @@ def _random_engines(rng, nq, kl, ks, pool, pad_frac, dup_frac):
     (7, 3, (2,), 4, 0.5, 0.5, 16, 4, 1.0, None),                       # tiny lists, fewer candidates than `total`
     (6, 0, (33, 20, 7, 11), 40, 0.2, 0.3, 8, 2, 0.0, None),            # empty lookup list, four engines, deterministic top-k
 ])
-def test_device_pipeline_matches_the_oracle_random(nq, kl, ks, pool, pad, dup, total, kpos, temp, support):
+def test_device_pipeline_matches_the_oracle_random(nq, kl, ks, pool, pad, dup, total, kpos, temp, support, mode):
+    if mode == "keep_top" and support is None:
+        pytest.skip("no support truncation in this case: the two modes are the same code path")
     from oracle import sampling as osmp
     from oracle.hybrid import merge_hybrid
     from vod_amd.core.collate import collate_on_device, sample_merged_on_device
@@ -197,12 +200,12 @@ def test_device_pipeline_matches_the_oracle_random(nq, kl, ks, pool, pad, dup, t
     # everything beyond the cut is padding, as the merge kernel leaves it
     w = m_idx.shape[1]
     assert bool((merged.indices[:, w:] == -1).all()) and bool(torch.isneginf(merged.scores[:, w:]).all())
-    ref = osmp.sample_search_results(m_idx, m_scr, m_lbl, m_raw, noise[:, :w], total, kpos, temp, support)
-    out = sample_merged_on_device(merged, _t(noise), total=total, max_pos_sections=kpos, temperature=temp, max_support_size=support)
+    ref = osmp.sample_search_results(m_idx, m_scr, m_lbl, m_raw, noise[:, :w], total, kpos, temp, support, keep_top=mode == "keep_top")
+    out = sample_merged_on_device(merged, _t(noise), total=total, max_pos_sections=kpos, temperature=temp, max_support_size=support, support=mode)
     _check_sampled(out, ref, names, TOL_RANDOM)
     if nq * total <= 8192:
         flat = collate_on_device(_t(l_idx), _t(l_lbl), engines, weights, _t(noise), total=total, max_pos_sections=kpos, temperature=temp,
-                                 max_support_size=support, in_batch_negatives=True)
+                                 max_support_size=support, in_batch_negatives=True, support=mode)
         o = out
         rf = osmp.flatten_samples(o.indices.cpu().numpy(), o.scores.cpu().numpy(), o.labels.cpu().numpy(), o.log_weights.cpu().numpy(),
                                   {n: v.cpu().numpy() for n, v in o.raw_scores.items()})

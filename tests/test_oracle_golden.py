@@ -118,6 +118,29 @@ def test_sampling_matches_reference():
         np.testing.assert_allclose(lse, g[f"out_lse_{c}"], rtol=2e-6, atol=2e-6, equal_nan=True)
 
 
+def test_sampling_corrected_support_mode_of_the_oracle():
+    """`keep_top=True` (SURVEY 9 Q8's corrected truncation; no reference counterpart) differs from the reference mode only in which side
+    of the support threshold is masked: with a support that covers a whole class the two agree, otherwise the corrected mode samples
+    from the best `support` candidates and the reference mode from the rest."""
+    rng = np.random.default_rng(3)
+    scores = rng.normal(size=(6, 60)).astype(np.float32)
+    labels = rng.uniform(size=scores.shape) < 0.4
+    noise = rng.exponential(size=scores.shape).astype(np.float32)
+    a = osmp.labeled_priority_sampling_2d(scores, labels, noise, 4, 12, True, 1.0, 60, keep_top=True)
+    b = osmp.labeled_priority_sampling_2d(scores, labels, noise, 4, 12, True, 1.0, 60)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)                          # support >= class size: no truncation either way
+    smp, logw, lab, _ = osmp.labeled_priority_sampling_2d(scores, labels, noise, 4, 12, True, 1.0, 12, keep_top=True)
+    smp_r, _, lab_r, _ = osmp.labeled_priority_sampling_2d(scores, labels, noise, 4, 12, True, 1.0, 12)
+    for r in range(len(scores)):
+        neg = np.flatnonzero(~labels[r])
+        thr = np.sort(scores[r][neg])[-12]
+        picked = smp[r][(smp[r] >= 0) & ~lab[r] & np.isfinite(logw[r])]
+        assert len(picked) and np.all(scores[r][picked] >= thr)      # corrected: from the 12 best negatives
+        picked_r = smp_r[r][(smp_r[r] >= 0) & ~lab_r[r]]
+        assert np.all(scores[r][picked_r] < thr)                     # reference (Q8): from everything BUT them
+
+
 def test_flatten_matches_reference():
     g = _load("flatten_inbatch")
     out = osmp.flatten_samples(g["idx"], g["scr"], g["lbl"], g["logw"], {"dense": g["raw_dense"], "sparse": g["raw_sparse"]})

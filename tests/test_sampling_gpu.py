@@ -16,13 +16,13 @@ pytestmark = pytest.mark.gpu
 TOL = dict(rtol=2e-5, atol=2e-5)
 
 
-def _run(scores, labels, noise, p):
+def _run(scores, labels, noise, p, support="reference"):
     from vod_amd.core.sample import labeled_priority_sampling_tensors
 
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
     out = labeled_priority_sampling_tensors(
         t(scores), t(labels), t(noise), p["k_positive"], p["k_total"], normalized=True, temperature=p["temperature"],
-        max_support_size=p["max_support_size"],
+        max_support_size=p["max_support_size"], support=support,
     )
     return [o.cpu().numpy() for o in out]
 
@@ -73,6 +73,41 @@ def test_matches_oracle_random(nq, n, k_pos, k_tot, support, temp):
     sup = max(support, k_tot) if support >= 0 else -1
     ref = labeled_priority_sampling_2d(scores, labels, noise, k_pos, k_tot, True, temp, sup)
     _compare(got, ref)
+
+
+@pytest.mark.parametrize("nq,n,k_pos,k_tot,support,temp", [
+    (64, 385, 8, 32, 100, 1.0),   # shipped training shape
+    (16, 1000, 16, 64, 200, 0.0),
+    (5, 4096, 32, 128, 2000, 0.5),
+    (8, 300, 4, 16, 16, 1.0),     # support = k_total: the sample is the support
+])
+def test_corrected_support_mode_keeps_the_best_candidates(nq, n, k_pos, k_tot, support, temp):
+    """the reference's truncation REMOVES each class's `max_support_size` best candidates; `support="keep_top"` keeps
+    them instead.  Against the oracle's restatement of that mode (the same code with the comparison turned around), and by its
+    defining property: every sampled column ranks among its class's `support` best scores."""
+    from oracle.sampling import labeled_priority_sampling_2d
+
+    rng = np.random.default_rng(7 * nq + n)
+    scores = (rng.normal(size=(nq, n)) * 3).astype(np.float32)
+    scores[rng.uniform(size=scores.shape) < 0.1] = -np.inf
+    labels = rng.uniform(size=scores.shape) < 0.3
+    noise = rng.exponential(size=scores.shape).astype(np.float32)
+    p = {"k_positive": k_pos, "k_total": k_tot, "temperature": temp, "max_support_size": support}
+    got = _run(scores, labels, noise, p, support="keep_top")
+    sup = max(support, k_tot)
+    _compare(got, labeled_priority_sampling_2d(scores, labels, noise, k_pos, k_tot, True, temp, sup, keep_top=True))
+    smp, logw, lab, _ = got
+    for r in range(nq):
+        for cls in (True, False):
+            members = np.flatnonzero(labels[r] == cls)
+            if len(members) <= sup:
+                continue
+            thr = np.sort(scores[r][members])[-sup]
+            picked = smp[r][(smp[r] >= 0) & (lab[r] == cls) & np.isfinite(logw[r])]
+            assert np.all(scores[r][picked] >= thr)
+    # and the reference mode on the same inputs picks from the OTHER end (the quirk, kept as the default)
+    ref_mode = _run(scores, labels, noise, p)
+    assert not np.array_equal(ref_mode[0], smp)
 
 
 def test_sample_search_results_wrapper_contract():

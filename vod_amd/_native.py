@@ -133,7 +133,7 @@ class CollateArgs(ctypes.Structure):
         ("nq", _i64),
         ("noise", _vp), ("noise_stride", _i64),
         ("k_positive", _c.c_int32), ("k_total", _c.c_int32), ("max_support_size", _c.c_int32), ("in_batch_negatives", _c.c_int32),
-        ("temperature", _c.c_float), ("reserved", _c.c_int32),
+        ("temperature", _c.c_float), ("flags", _c.c_int32),
         ("merged_idx", _vp), ("merged_lbl", _vp), ("merged_scr", _vp), ("merged_raw", _vp * MAX_ENGINES), ("row_cursor", _vp),
         ("out_local", _vp), ("out_ids", _vp), ("out_scores", _vp), ("out_log_weights", _vp), ("out_labels", _vp),
         ("out_raw", _vp * MAX_ENGINES), ("out_lse_pos", _vp), ("out_lse_neg", _vp), ("out_max_sampling_id", _vp),

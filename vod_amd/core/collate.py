@@ -25,6 +25,7 @@ import torch
 
 from vod_amd import _native
 from vod_amd.core.merge import MergedOnDevice, merge_hybrid_device
+from vod_amd.core.sample import support_flag
 
 
 @dataclasses.dataclass
@@ -74,6 +75,7 @@ def sample_merged_on_device(
     temperature: float = 1.0,
     max_support_size: int | None = None,
     width: int | None = None,
+    support: str = "reference",
 ) -> DeviceSampledSections:
     """`sample_search_results` (sample.py:22-84) on the merge's device outputs: ONE launch, no host sync.
 
@@ -114,7 +116,7 @@ def sample_merged_on_device(
                 nz.data_ptr(), int(nz.stride(0)), nq, stride,
                 -1 if width is None else int(width), None if merged.stage_max is None else merged.stage_max.data_ptr(),
                 None if merged.row_cursor is None else merged.row_cursor.data_ptr(), merged.k_lookup, len(merged.engine_k), eng_k,
-                k_pos, total, float(temperature), max_support, 1,
+                k_pos, total, float(temperature), max_support, 1 | support_flag(support),
                 samples.data_ptr(), out_ids.data_ptr(), out_scores.data_ptr(), out_logw.data_ptr(), out_lab.data_ptr(),
                 _ptr_array(out_raw), lse.data_ptr(), max_id.data_ptr(), _native.current_stream_ptr(dev),
             )
@@ -173,6 +175,7 @@ def collate_on_device(
     max_support_size: int | None = None,
     in_batch_negatives: bool = False,
     generator: torch.Generator | None = None,
+    support: str = "reference",
 ) -> DeviceSampledSections:
     """merge -> sample -> (flatten) without leaving the GPU: ONE call into libvodhip (`vodhip_collate`) that enqueues the 2 (3)
     launches back to back on the current stream, zero host syncs.
@@ -188,7 +191,7 @@ def collate_on_device(
         if noise is None:
             noise = torch.empty((merged.indices.shape[0], merged.stride), dtype=torch.float32, device=merged.indices.device).exponential_(generator=generator)
         out = sample_merged_on_device(merged, noise, total=total, max_pos_sections=max_pos_sections, temperature=temperature,
-                                      max_support_size=max_support_size)
+                                      max_support_size=max_support_size, support=support)
         return flatten_on_device(out) if in_batch_negatives else out
     lib = _native.load_library()
     dev = lookup_idx.device
@@ -245,6 +248,7 @@ def collate_on_device(
     a.noise, a.noise_stride = noise.data_ptr(), noise.stride(0)
     a.k_positive, a.k_total, a.max_support_size, a.in_batch_negatives = int(max_pos_sections or total), total, max_support, int(flat)
     a.temperature = float(temperature)
+    a.flags = support_flag(support)
     p_mi, p_mf, p_si, p_sf, p_row = m_i64.data_ptr(), m_f32.data_ptr(), s_i64.data_ptr(), s_f32.data_ptr(), s_row.data_ptr()
     a.merged_idx, a.merged_lbl, a.merged_scr = p_mi, p_mi + nq * stride * 8, p_mf
     a.row_cursor = cursors.data_ptr()

@@ -18,6 +18,13 @@ from vod_amd import _native
 from vod_amd import types as vt
 
 
+def support_flag(support: str) -> int:
+    """`support="reference" | "keep_top"` -> the flag bit of include/vodhip.h (VODHIP_SAMPLE_KEEP_TOP_SUPPORT)."""
+    if support not in ("reference", "keep_top"):
+        raise ValueError(f"support must be 'reference' or 'keep_top', got {support!r}")
+    return 2 if support == "keep_top" else 0
+
+
 @dataclasses.dataclass(frozen=True)
 class PrioritySampledSections:
     batch: vt.RetrievalBatch
@@ -37,8 +44,13 @@ def labeled_priority_sampling_tensors(
     normalized: bool = True,
     temperature: float = 1.0,
     max_support_size: int | None = None,
+    support: str = "reference",
 ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Device-tensor API: returns (samples i64 [nq,k_total], log_weights f32, labels bool, lse f32 [nq,2])."""
+    """Device-tensor API: returns (samples i64 [nq,k_total], log_weights f32, labels bool, lse f32 [nq,2]).
+
+    `support`: what `max_support_size` does to each class's candidates - "reference" removes the `max_support_size` best ones (the
+    reference's behaviour, SURVEY 9 Q8: sample.py:176-178 masks `>= threshold`), "keep_top" keeps them and masks the rest (the
+    corrected mode).  The default is bit parity with the reference."""
     lib = _native.load_library()
     if not scores.is_cuda:
         raise _native.NativeLibraryError("labeled_priority_sampling_tensors needs device tensors (there is no CPU path)")
@@ -58,7 +70,7 @@ def labeled_priority_sampling_tensors(
         _native.check(
             lib.vodhip_priority_sample(
                 sc.data_ptr(), lb.data_ptr(), nz.data_ptr(), nq, width, int(k_positive), int(k_total), float(temperature),
-                int(max_support_size), int(bool(normalized)), samples.data_ptr(), logw.data_ptr(), olab.data_ptr(),
+                int(max_support_size), int(bool(normalized)) | support_flag(support), samples.data_ptr(), logw.data_ptr(), olab.data_ptr(),
                 lse.data_ptr(), _native.current_stream_ptr(dev),
             )
         )
@@ -74,6 +86,7 @@ def sample_search_results(
     temperature: float = 1.0,
     max_support_size: None | int = None,
     device: int = 0,
+    support: str = "reference",
 ) -> PrioritySampledSections:
     """Sample positive and negative sections with per-label priority sampling (sample.py:22-84)."""
     from vod_amd.core.collate import sample_merged_on_device
@@ -97,7 +110,7 @@ def sample_search_results(
         raw={k: up(np.asarray(v, dtype=np.float32)) for k, v in raw_scores.items()}, stage_max=None, k_lookup=width, engine_k=[],
     )
     out = sample_merged_on_device(merged, up(noise), total=total, max_pos_sections=max_pos_sections, temperature=temperature,
-                                  max_support_size=max_support_size, width=width)
+                                  max_support_size=max_support_size, width=width, support=support)
     host = lambda t: t.cpu().numpy()  # noqa: E731
     return PrioritySampledSections(
         batch=vt.RetrievalBatch(indices=host(out.indices).astype(search_results.indices.dtype, copy=False), scores=host(out.scores),

@@ -130,6 +130,7 @@ struct SampleArgs {
     int k_positive, k_total;
     float temperature;
     int max_support, normalized;
+    int keep_top;                // support truncation keeps the `max_support` best entries (the corrected mode) instead of removing them (Q8)
     int64_t* out_samples;
     float* out_logw;
     uint8_t* out_labels;
@@ -307,8 +308,8 @@ __global__ __launch_bounds__(SM_THREADS) void priority_sample_kernel(SampleArgs 
         // log_p = scores * T
         for (int s_ = tid; s_ < m; s_ += SM_THREADS) lp[s_] = sc[col_of[s_]] * t_inv;
         __syncthreads();
-        // support truncation: mask everything >= the max_support-th largest value (Q8), NaN sorts as the largest;
-        // equal values rank by the smaller column (= the smaller slot)
+        // support truncation: mask everything >= the max_support-th largest value (Q8: the reference REMOVES its best entries), or -
+        // `keep_top`, the corrected mode - everything below it; NaN sorts as the largest; equal values rank by the smaller column
         if (max_support > 0 && m > max_support) {
             for (int s_ = tid; s_ < m; s_ += SM_THREADS) keys[s_] = ((u64)ord32(lp[s_], 0xFFFFFFFFu) << 32) | (u64)(0xFFFFFFFFu - (unsigned)s_);
             __syncthreads();
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(SM_THREADS) void priority_sample_kernel(SampleArgs 
             const float thr = lp[slot];
             __syncthreads();
             for (int s_ = tid; s_ < m; s_ += SM_THREADS)
-                if (lp[s_] >= thr) lp[s_] = -__builtin_inff();  // false for a NaN threshold
+                if (a.keep_top ? lp[s_] < thr : lp[s_] >= thr) lp[s_] = -__builtin_inff();  // false for a NaN threshold
             __syncthreads();
         }
         SM_PROBE(3 + cls * 5);
@@ -429,7 +430,8 @@ hipError_t launch_priority_sample(const float* scores, const uint8_t* labels, co
     a.k_total = k_total;
     a.temperature = temperature;
     a.max_support = max_support_size;
-    a.normalized = normalized;
+    a.normalized = normalized & 1;
+    a.keep_top = (normalized >> 1) & 1;
     a.out_samples = out_samples;
     a.out_logw = out_log_weights;
     a.out_labels = out_labels;
@@ -458,7 +460,8 @@ hipError_t launch_priority_sample_merged(const SampleMergedArgs& m, hipStream_t 
     a.k_total = m.k_total;
     a.temperature = m.temperature;
     a.max_support = m.max_support;
-    a.normalized = m.normalized;
+    a.normalized = m.normalized & 1;
+    a.keep_top = (m.normalized >> 1) & 1;
     a.out_samples = m.out_samples;
     a.out_logw = m.out_logw;
     a.out_labels = m.out_labels;

@@ -1102,7 +1102,7 @@ int vodhip_collate(const vodhip_collate_args_t* c, void* stream_) {
     m.k_total = c->k_total;
     m.temperature = c->temperature;
     m.max_support = c->max_support_size;
-    m.normalized = 1;
+    m.normalized = 1 | (c->flags & VODHIP_SAMPLE_KEEP_TOP_SUPPORT);
     m.out_samples = c->out_local;
     m.out_ids = c->out_ids;
     m.out_scores = c->out_scores;
