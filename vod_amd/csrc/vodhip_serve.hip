@@ -173,6 +173,7 @@ struct vodhip_batcher {
     tp_t t_last_completion;         // when the previous batch completed (= when a batch enqueued behind it started to run)
     // stats
     int64_t n_batches = 0, n_requests = 0, n_queries = 0, n_fused_max = 0, n_grace_waits = 0, n_grace_full = 0;
+    int64_t n_merge_holds = 0, n_merge_waits = 0;  // decisions for ONE scan instead of two alternating groups (busy branch / idle branch)
     int64_t idle_ns = 0, busy_ns = 0, last_batch_queries = 0, last_batch_requests = 0;
     tp_t t_busy_since;
 };
@@ -335,7 +336,10 @@ bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
                     if (it == b->clients.end() || !it->second.answered || it->second.ema_gap_ns <= 0.0) known = false;
                     else gap = std::max(gap, it->second.ema_gap_ns);
                 }
-                if (known && gap <= (double)b->grace_us * 1e3 && merge_pays(b, pend_q, run->nq, gap)) return false;
+                if (known && gap <= (double)b->grace_us * 1e3 && merge_pays(b, pend_q, run->nq, gap)) {
+                    ++b->n_merge_holds;
+                    return false;
+                }
             }
             return true;
         }
@@ -383,6 +387,7 @@ bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
     }
     if (missing == 0) return true;
     if (full_tile && !merge_pays(b, pend_q, missing_q, (double)ns_between(now, last_due))) return true;
+    if (full_tile) ++b->n_merge_waits;
     if (now >= deadline) {
         ++b->n_grace_full;
         return true;
@@ -699,6 +704,9 @@ int vodhip_batcher_get_stat(vodhip_batcher_t* b, const char* key, int64_t* out) 
     else if (!strcmp(key, "last_batch_queries")) *out = b->last_batch_queries;
     else if (!strcmp(key, "last_batch_requests")) *out = b->last_batch_requests;
     else if (!strcmp(key, "flat_scan_ns")) *out = (int64_t)b->ema_flat_scan_ns;
+    else if (!strcmp(key, "merge_holds")) *out = b->n_merge_holds;
+    else if (!strcmp(key, "merge_waits")) *out = b->n_merge_waits;
+    else if (!strncmp(key, "tiles_ns_", 9) && key[9] >= '1' && key[9] <= '8' && !key[10]) *out = (int64_t)b->ema_tiles_ns[key[9] - '0'];
     else if (!strcmp(key, "in_flight")) *out = (int64_t)b->inflight.size();
     else if (!strcmp(key, "pending")) *out = (int64_t)b->pending.size();
     else if (!strcmp(key, "active_clients")) *out = (int64_t)b->clients.size();
