@@ -160,6 +160,7 @@ struct vodhip_batcher {
     int callers = 0;       // threads inside vodhip_batcher_search (destroy waits for them before it frees the handle)
     std::thread th_sched, th_compl;
     double ema_flat_scan_ns = 0.0;  // duration of batches of <= flat_queries queries that started on an idle engine
+    int tiles_samples[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double ema_tiles_ns[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... and of batches of t query tiles (256 queries each) that started on an idle engine
     double estimate_ns(int64_t nq) const {  // expected duration of a batch of nq queries: its own bucket, else scaled from the nearest known one
         const int t = (int)std::min<int64_t>(8, std::max<int64_t>(1, (nq + 255) / 256));
@@ -485,8 +486,13 @@ void complete_locked(vodhip_batcher* b, Batch* bt, tp_t now) {
     if (bt->rc == 0 && !bt->subset && bt->nq <= 2048) {
         // a batch that started on an idle engine ran `dur`; one that was enqueued behind another ran from its predecessor's completion
         const double own = bt->pipeline_was_empty ? dur : (double)ns_between(std::max(bt->t_submit, b->t_last_completion), now);
-        double& e = b->ema_tiles_ns[(int)std::min<int64_t>(8, std::max<int64_t>(1, (bt->nq + 255) / 256))];
-        e = e <= 0.0 ? own : 0.7 * e + 0.3 * own;
+        const int t = (int)std::min<int64_t>(8, std::max<int64_t>(1, (bt->nq + 255) / 256));
+        // the FIRST batch of a size pays for growing the library's workspace and the staging slot (a 512-query batch right after
+        // 256-query ones: 11.7 ms against 6.9 from then on - measured; that one sample kept the merge rule off for good): not recorded
+        if (b->tiles_samples[t]++ > 0) {
+            double& e = b->ema_tiles_ns[t];
+            e = e <= 0.0 ? own : (own < e ? 0.5 * e + 0.5 * own : 0.7 * e + 0.3 * own);
+        }
     }
     b->t_last_completion = now;
     bt->slot->users = (int)bt->reqs.size();
