@@ -1221,49 +1221,3 @@ def test_native_http_front_sends_any_content_type_the_fallback_chooses():
     finally:
         front.close()
         mb.close()
-
-
-def test_native_batcher_merges_two_alternating_groups_when_one_scan_is_cheaper():
-    """Closed-loop clients that fell into TWO groups of a full query tile each (one group on the engine while the other waits) pay the
-    scan's fixed cost twice per cycle.  With a cost model like a brute-force scan's (fixed part + per-query part) the batcher waits for
-    the returning group and scans once for everybody; with a purely per-query cost it keeps the two groups (the engine never idles)."""
-    import threading
-    import time
-
-    from vod_amd.search.native import NativeBatcher
-
-    x = np.zeros((16, 8), np.float32)
-
-    def run(fixed_ms, per_query_us):
-        class Model(_OracleEngine):
-            def search(self, q, k):
-                time.sleep(fixed_ms * 1e-3 + per_query_us * 1e-6 * len(q))
-                return np.zeros((len(q), k), np.float32), np.zeros((len(q), k), np.int64)
-
-        mb = NativeBatcher(engine=Model(x), dim=8, flat_queries=256)
-        stop = threading.Event()
-        q = np.zeros((64, 8), np.float32)
-
-        def loop(i, delay):
-            time.sleep(delay)
-            while not stop.is_set():
-                mb.search(q, 4, client=i + 1)
-
-        # two groups of four clients, the second arriving while the first is on the engine: the alternating state
-        threads = [threading.Thread(target=loop, args=(i, 0.0 if i < 4 else 0.004)) for i in range(8)]
-        for t in threads:
-            t.start()
-        time.sleep(0.6)
-        a = mb.stats()
-        time.sleep(0.8)
-        b_ = mb.stats()
-        stop.set()
-        for t in threads:
-            t.join(timeout=20)
-        mb.close()
-        return (b_["queries"] - a["queries"]) / max(1, b_["batches"] - a["batches"])
-
-    merged = run(fixed_ms=6.0, per_query_us=10.0)    # t(256) = 8.6 ms, t(512) = 11.1 ms: one scan for all eight beats 2 x 8.6
-    assert merged > 440, merged                       # (512 when every cycle merges)
-    split = run(fixed_ms=0.0, per_query_us=30.0)     # no fixed cost: two groups keep the engine busy, merging would only add the gap
-    assert split < 330, split

@@ -71,7 +71,6 @@ def run_cell(client, P, nq, dim, k, seconds, stats=lambda: {}, think_ms=0.0):
         cell["server"] = {"batches": nb, "mean_queries_per_batch": (s1["queries"] - s0["queries"]) / nb,
                           "mean_requests_per_batch": (s1["requests"] - s0["requests"]) / nb, "engine_idle_fraction": idle / max(1, busy + idle),
                           "grace_waits": s1["grace_waits"] - s0["grace_waits"], "grace_expired": s1["grace_expired"] - s0["grace_expired"],
-                          "merge_holds": s1.get("merge_holds", 0) - s0.get("merge_holds", 0), "merge_waits": s1.get("merge_waits", 0) - s0.get("merge_waits", 0),
                           "scan_ms_by_tiles": {t: round(s1.get(f"tiles_ns_{t}", 0) / 1e6, 3) for t in (1, 2, 4, 8)}}
     return cell
 

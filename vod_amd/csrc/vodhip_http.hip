@@ -471,8 +471,8 @@ bool try_native(vodhip_http* h, int fd, uint64_t client, bool raw, int64_t raw_t
 
 std::string stats_json(vodhip_http* h) {
     static const char* keys[] = {"batches", "requests", "queries", "fused_requests_max", "grace_waits", "grace_expired", "idle_ns", "busy_ns",
-                                 "last_batch_queries", "last_batch_requests", "flat_scan_ns", "in_flight", "pending", "active_clients", "merge_holds",
-                                 "merge_waits", "tiles_ns_1", "tiles_ns_2", "tiles_ns_4", "tiles_ns_8"};
+                                 "last_batch_queries", "last_batch_requests", "flat_scan_ns", "in_flight", "pending", "active_clients", "tiles_ns_1",
+                                 "tiles_ns_2", "tiles_ns_4", "tiles_ns_8"};
     std::string out = "{";
     char tmp[320];
     for (const char* k : keys) {

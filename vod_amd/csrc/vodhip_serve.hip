@@ -152,7 +152,6 @@ struct vodhip_batcher {
         tp_t last_done;          // when its latest request was answered (its rows copied out)
         double ema_gap_ns = 0.0; // how long it usually takes to come back after an answer (turn-around + think time)
         bool answered = false;
-        int64_t last_nq = 0;     // queries of its latest request (what it is expected to bring when it comes back)
     };
     std::unordered_map<uint64_t, Client> clients;  // client tag -> what is known about its rhythm
     bool stop = false;
@@ -174,7 +173,6 @@ struct vodhip_batcher {
     tp_t t_last_completion;         // when the previous batch completed (= when a batch enqueued behind it started to run)
     // stats
     int64_t n_batches = 0, n_requests = 0, n_queries = 0, n_fused_max = 0, n_grace_waits = 0, n_grace_full = 0;
-    int64_t n_merge_holds = 0, n_merge_waits = 0;  // decisions for ONE scan instead of two alternating groups (busy branch / idle branch)
     int64_t idle_ns = 0, busy_ns = 0, last_batch_queries = 0, last_batch_requests = 0;
     tp_t t_busy_since;
 };
@@ -264,18 +262,6 @@ void slot_free(vodhip_batcher* b, Slot& s) {
     s = Slot();
 }
 
-// One scan for everybody, or two?  With `a` queries pending and the callers of `r` more about to come back (in `gap_ns`), scanning a + r
-// together costs t(a + r) + gap (the engine idles while they return); scanning them as two alternating groups costs t(a) + t(r) with the
-// engine never idle - but each group pays the scan's fixed cost (a brute-force scan of a 10 M-row store: ~1.3 ms + ~10 us per query).
-// Measured, 8 clients x 64 queries: two groups of 256 = 67.7 k queries/s, one batch of 512 = 75 k.  Durations come from the per-size table
-// the batcher keeps (an unknown size is extrapolated optimistically, tried once, and measured from then on).
-bool merge_pays(const vodhip_batcher* b, int64_t a, int64_t r, double gap_ns) {
-    if (a <= 0 || r <= 0 || a + r > b->max_queries) return false;
-    const double t_a = b->estimate_ns(a), t_r = b->estimate_ns(r), t_both = b->estimate_ns(a + r);
-    if (t_a <= 0.0 || t_r <= 0.0 || t_both <= 0.0) return false;
-    return t_both + gap_ns + 50e3 < 0.97 * (t_a + t_r);
-}
-
 // ---- the policy ------------------------------------------------------------------------------------------------------------------
 // Called with b->mu held and at least one request pending.  Returns true = assemble and submit a batch now; false = wait (until
 // `*until`, or for ever when `*until` == tp_t::max(); any arrival / completion wakes the scheduler and the decision is taken again).
@@ -287,11 +273,12 @@ bool merge_pays(const vodhip_batcher* b, int64_t a, int64_t r, double gap_ns) {
 //   * engine busy, pending < flat_queries                                  -> keep collecting until the running batch completes
 //                                                                            (enqueuing early would freeze a small batch that costs
 //                                                                            a whole scan of its own)
-//   * engine busy, pending >= flat_queries (time is linear in the batch)   -> enqueue BEHIND the running batch (no gap on the device) -
-//                                                                            unless ONE scan for the pending requests and the running
-//                                                                            batch's callers (who are about to come back) is cheaper
-//                                                                            than two alternating groups (merge_pays): then hold, and
-//                                                                            wait for them when the engine goes idle
+//   * engine busy, pending >= flat_queries (time is linear in the batch)   -> enqueue BEHIND the running batch (no gap on the device).
+//                                                                            (Holding instead, to scan ONCE for both groups when they
+//                                                                            alternate, was tried in round 4: the scan's fixed cost at
+//                                                                            256 queries is ~0.75 ms of 3.8 on a 10 M-row store against
+//                                                                            a ~0.45 ms come-back gap - 0-4 %, unstable at the margin:
+//                                                                            profiles/r04_ab_merge_groups.txt)
 //   * pending >= max_queries                                               -> now, whenever a pipeline slot is free
 bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
     *until = tp_t::max();
@@ -324,26 +311,7 @@ bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
                 for (const Request* r : bt->reqs) has = has || r->client == kv.first;
             if (!has) ++missing;
         }
-        if (missing == 0) {
-            // everybody is pending or on the device.  When ONE batch is running and scanning its callers' next requests together with
-            // what is pending beats two alternating groups (merge_pays), nothing is enqueued behind it: the completion wakes the
-            // scheduler and the idle branch below waits for the returning callers
-            if (in_flight == 1 && !b->inflight.front()->subset && b->grace_us > 0) {
-                const Batch* run = b->inflight.front();
-                double gap = 0.0;
-                bool known = true;
-                for (const Request* r : run->reqs) {
-                    auto it = r->client ? b->clients.find(r->client) : b->clients.end();
-                    if (it == b->clients.end() || !it->second.answered || it->second.ema_gap_ns <= 0.0) known = false;
-                    else gap = std::max(gap, it->second.ema_gap_ns);
-                }
-                if (known && gap <= (double)b->grace_us * 1e3 && merge_pays(b, pend_q, run->nq, gap)) {
-                    ++b->n_merge_holds;
-                    return false;
-                }
-            }
-            return true;
-        }
+        if (missing == 0) return true;
         const Batch* oldest = b->inflight.front();
         const double est = b->estimate_ns(oldest->nq);
         if (est <= 0.0) return true;  // no estimate yet for a batch of that size: round 3's behaviour (enqueue behind at once)
@@ -359,8 +327,7 @@ bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
         *until = window_end;
         return false;
     }
-    if (b->grace_us <= 0 || b->ema_flat_scan_ns <= 0.0) return true;
-    const bool full_tile = pend_q >= b->flat_queries;  // the scan no longer costs the same with company aboard: waiting must pay (merge_pays)
+    if (pend_q >= b->flat_queries || b->grace_us <= 0 || b->ema_flat_scan_ns <= 0.0) return true;
     // expected company: clients that (a) searched within the last few cycles, (b) have nothing pending right now and (c) are DUE - their
     // usual come-back time after an answer (an EMA per client) ends before the grace does.  A worker that tokenises for 5 ms between
     // requests is not waited for (measured: waiting for it cost 8 workers with 2 ms pauses +0.85 ms per request and 9 % throughput);
@@ -369,8 +336,6 @@ bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
     const auto active_window = std::chrono::nanoseconds((int64_t)std::max(5e6, 4.0 * (b->ema_flat_scan_ns + grace_ns)));
     const tp_t deadline = std::max(first->t_arrive, b->t_idle_since) + std::chrono::nanoseconds((int64_t)grace_ns);
     int missing = 0;
-    int64_t missing_q = 0;    // what the awaited clients are expected to bring
-    tp_t last_due = now;
     tp_t give_up = deadline;  // the earliest moment one of the awaited clients stops being plausible
     for (const auto& kv : b->clients) {
         const vodhip_batcher::Client& c = kv.second;
@@ -382,13 +347,9 @@ bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
         const tp_t late = c.last_done + std::chrono::nanoseconds((int64_t)(2.0 * c.ema_gap_ns + 100e3));
         if (due > deadline || now > late) continue;  // not expected in time / overdue: somebody who went to do something else
         ++missing;
-        missing_q += c.last_nq;
-        last_due = std::max(last_due, due);
         give_up = std::min(give_up, late);
     }
     if (missing == 0) return true;
-    if (full_tile && !merge_pays(b, pend_q, missing_q, (double)ns_between(now, last_due))) return true;
-    if (full_tile) ++b->n_merge_waits;
     if (now >= deadline) {
         ++b->n_grace_full;
         return true;
@@ -710,8 +671,6 @@ int vodhip_batcher_get_stat(vodhip_batcher_t* b, const char* key, int64_t* out) 
     else if (!strcmp(key, "last_batch_queries")) *out = b->last_batch_queries;
     else if (!strcmp(key, "last_batch_requests")) *out = b->last_batch_requests;
     else if (!strcmp(key, "flat_scan_ns")) *out = (int64_t)b->ema_flat_scan_ns;
-    else if (!strcmp(key, "merge_holds")) *out = b->n_merge_holds;
-    else if (!strcmp(key, "merge_waits")) *out = b->n_merge_waits;
     else if (!strncmp(key, "tiles_ns_", 9) && key[9] >= '1' && key[9] <= '8' && !key[10]) *out = (int64_t)b->ema_tiles_ns[key[9] - '0'];
     else if (!strcmp(key, "in_flight")) *out = (int64_t)b->inflight.size();
     else if (!strcmp(key, "pending")) *out = (int64_t)b->pending.size();
@@ -765,7 +724,6 @@ int vodhip_batcher_search(vodhip_batcher_t* b, const void* queries, int q_dtype,
             c.ema_gap_ns = c.ema_gap_ns <= 0.0 ? gap : 0.7 * c.ema_gap_ns + 0.3 * gap;
         }
         c.last_seen = r.t_arrive;
-        c.last_nq = nq;
     }
     if (b->clients.size() > 4096) {  // tags of clients long gone (no forget call): keep the table small
         for (auto it = b->clients.begin(); it != b->clients.end();)

@@ -89,7 +89,7 @@ class NativeBatcher:
 
     def stats(self) -> dict[str, int]:
         keys = ("batches", "requests", "queries", "fused_requests_max", "grace_waits", "grace_expired", "idle_ns", "busy_ns",
-                "last_batch_queries", "last_batch_requests", "flat_scan_ns", "in_flight", "pending", "active_clients", "merge_holds", "merge_waits",
+                "last_batch_queries", "last_batch_requests", "flat_scan_ns", "in_flight", "pending", "active_clients",
                 "tiles_ns_1", "tiles_ns_2", "tiles_ns_4", "tiles_ns_8")
         return {k: self.get_stat(k) for k in keys}
 
