@@ -453,8 +453,8 @@ int vodhip_http_get_stat(vodhip_http_t* http, const char* key, int64_t* out);  /
  * socket or a GPU (tests/test_host_logic.py):
  *   npy_header         np.lib.format.write_array_header_1_0 for a C-ordered [rows, cols] array; dtype VODHIP_F32 | VODHIP_F16 | 3 (int64);
  *                      out >= 192 bytes; returns the header length (the data offset)
- *   parse_npy          0 + dtype / rows / cols / data offset for a version-1.0 little-endian float32 | float16 C-order 2-D array
- *                      whose data is complete; -1 for anything else (not an error: the host's reader takes over)
+ *   parse_npy          0 + dtype / rows / cols / data offset for a version-1.0 little-endian float32 | float16 | int64 (dtype code 3)
+ *                      C-order 2-D array whose data is complete; -1 for anything else (not an error: the host's reader takes over)
  *   parse_fast_search  0 + the [begin, end) span of the "vectors" payload and top_k (default 3) for the plain hot document; 1 otherwise
  *   fast_search_reply  the /fast-search reply body; out = NULL returns the size needed */
 int64_t vodhip_wire_npy_header(int dtype, int64_t rows, int64_t cols, uint8_t* out, int64_t cap);

@@ -673,14 +673,16 @@ def test_http_shell_on_a_unix_domain_socket(tmp_path, shell):
                 res = c.search(vector=q, top_k=9)
             np.testing.assert_array_equal(res.indices, ri)
             np.testing.assert_array_equal(res.scores, rs)
-            assert type(c._local.conn).__name__ == "_UnixHTTPConnection"
+            import socket as _socket
+
+            assert c._local.lean.sock.family == _socket.AF_UNIX            # the searches went through the Unix-domain socket
             clone = pickle.loads(pickle.dumps(c))
             np.testing.assert_array_equal(clone.search(vector=q, top_k=9).indices, ri)
         # a socket path that does not exist on this host (a client on another machine, a rank that derived another path - round-3 advisor):
         # the searches fall back to the TCP address instead of failing
         far = vclient.HipMipsClient("http://127.0.0.1", port, uds=str(tmp_path / "nobody-listens.sock"))
         np.testing.assert_array_equal(far.search(vector=q, top_k=9).indices, ri)
-        assert type(far._local.conn).__name__ != "_UnixHTTPConnection"
+        assert far._local.lean.sock.family != _socket.AF_UNIX
     finally:
         stop()
     assert not os.path.exists(path)
@@ -1221,3 +1223,60 @@ def test_native_http_front_sends_any_content_type_the_fallback_chooses():
     finally:
         front.close()
         mb.close()
+
+
+def test_client_lean_connection_and_its_fallbacks():
+    """`HipMipsClient` talks to `http://` servers through its own minimal HTTP/1.1 exchange (`_LeanConnection`).  It must survive what a
+    kept-alive connection meets: the server closing it between two requests (re-opened once), error replies with bodies, a reply without a
+    Content-Length (handed to `http.client` from then on), `Connection: close`."""
+    import socket as _socket
+    import threading
+
+    from oracle.flat_ip import flat_ip_topk
+
+    rng = np.random.default_rng(8)
+    x = rng.integers(-4, 5, size=(100, 8)).astype(np.float32)
+    q = rng.integers(-4, 5, size=(3, 8)).astype(np.float32)
+    rs, ri = flat_ip_topk(q, x, 4)
+    port, stop = _serve_in_thread(_OracleEngine(x), shell="native")
+    try:
+        c = vclient.HipMipsClient("http://127.0.0.1", port)
+        np.testing.assert_array_equal(c.search(vector=q, top_k=4).indices, ri)
+        first = c._local.lean
+        first.sock.shutdown(_socket.SHUT_RDWR)                         # what an idle timeout on the server's side looks like from here
+        np.testing.assert_array_equal(c.search(vector=q, top_k=4).indices, ri)
+        assert c._local.lean is not first and c._local.lean.used
+        with pytest.raises(vclient.requests.exceptions.HTTPError, match="500"):
+            c.search(vector=q, top_k=0)                                # an error reply (with its JSON body) on the same connection
+        np.testing.assert_array_equal(c.search(vector=q, top_k=4).indices, ri)
+    finally:
+        stop()
+
+    # a server that answers without Content-Length (close-delimited body): the client falls back to http.client for good
+    body = bytes(vio.json_body_with_arrays({"scores": rs, "indices": ri}))
+    srv = _socket.socket()
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(4)
+
+    def serve():
+        for _ in range(2):
+            conn, _a = srv.accept()
+            data = b""
+            while b"\r\n\r\n" not in data:
+                data += conn.recv(65536)
+            head, _, rest = data.partition(b"\r\n\r\n")
+            need = int([ln for ln in head.split(b"\r\n") if ln.lower().startswith(b"content-length")][0].split(b":")[1])
+            while len(rest) < need:
+                rest += conn.recv(65536)
+            conn.sendall(b"HTTP/1.1 200 OK\r\ncontent-type: application/json\r\nconnection: close\r\n\r\n" + body)
+            conn.close()
+
+    t = threading.Thread(target=serve, daemon=True)
+    t.start()
+    try:
+        c2 = vclient.HipMipsClient("http://127.0.0.1", srv.getsockname()[1])
+        np.testing.assert_array_equal(c2.search(vector=q, top_k=4).indices, ri)
+        assert c2._local.no_lean is True
+    finally:
+        t.join(timeout=10)
+        srv.close()

@@ -101,7 +101,8 @@ bool find_field(const char* h, size_t n, const char* key, const char** val, size
     return false;
 }
 
-// version 1.0, little-endian float32 / float16, C order, 2-D: the layout every client of this service sends.  Anything else -> -1
+// version 1.0, little-endian float32 / float16 (queries, scores) or int64 (indices: dtype code 3), C order, 2-D: the layouts this service
+// sends and receives.  Anything else -> -1
 // (the caller falls back to the host's NumPy reader, which also produces the reference's error for a malformed payload).
 int parse_npy_2d(const uint8_t* data, int64_t n, int* dtype, int64_t* rows, int64_t* cols, int64_t* offset) {
     if (n < 10 || memcmp(data, "\x93NUMPY\x01\x00", 8)) return -1;
@@ -113,6 +114,7 @@ int parse_npy_2d(const uint8_t* data, int64_t n, int* dtype, int64_t* rows, int6
     if (!find_field(h, (size_t)hlen, "descr", &v, &vn) || vn < 5 || v[0] != '\'') return -1;
     if (!memcmp(v, "'<f4'", 5)) *dtype = VODHIP_F32;
     else if (!memcmp(v, "'<f2'", 5)) *dtype = VODHIP_F16;
+    else if (!memcmp(v, "'<i8'", 5)) *dtype = 3;  // (the reply's indices: read by the host's client through vodhip_wire_parse_npy)
     else return -1;
     if (!find_field(h, (size_t)hlen, "fortran_order", &v, &vn) || vn < 5 || memcmp(v, "False", 5)) return -1;
     if (!find_field(h, (size_t)hlen, "shape", &v, &vn) || vn < 2 || v[0] != '(') return -1;
@@ -140,7 +142,7 @@ int parse_npy_2d(const uint8_t* data, int64_t n, int* dtype, int64_t* rows, int6
         while (i < vn && v[i] == ' ') ++i;
     }
     if (i >= vn || v[i] != ')') return -1;
-    const int64_t es = *dtype == VODHIP_F32 ? 4 : 2;
+    const int64_t es = *dtype == 3 ? 8 : (*dtype == VODHIP_F32 ? 4 : 2);
     int64_t payload = 0;
     if (__builtin_mul_overflow(dims[0], dims[1], &payload) || __builtin_mul_overflow(payload, es, &payload)) return -1;
     if (payload > n - 10 - hlen) return -1;
@@ -436,7 +438,7 @@ bool try_native(vodhip_http* h, int fd, uint64_t client, bool raw, int64_t raw_t
     int dtype = 0;
     int64_t rows = 0, cols = 0, off = 0;
     if (parse_npy_2d(npy, npy_n, &dtype, &rows, &cols, &off)) return false;
-    if (cols != h->dim || rows < 1 || rows > 65536 || top_k < 1 || top_k > VODHIP_MAX_K) return false;  // the host raises the reference's errors (and takes the oversized batches)
+    if (dtype == 3 || cols != h->dim || rows < 1 || rows > 65536 || top_k < 1 || top_k > VODHIP_MAX_K) return false;  // the host raises the reference's errors (and takes the oversized batches)
     const int k = (int)top_k;
     cs.scores.resize((size_t)rows * k);
     cs.ids.resize((size_t)rows * k);
