@@ -507,6 +507,8 @@ def test_master_with_a_unix_domain_socket(tmp_path):
             rs, ri = flat_ip_topk(q, x, 50)
             np.testing.assert_array_equal(res.indices, ri)
             np.testing.assert_array_equal(res.scores, rs)
-            assert type(cl._local.conn).__name__ == "_UnixHTTPConnection"
+            import socket as _socket
+
+            assert cl._local.lean.sock.family == _socket.AF_UNIX
         path = c.uds
     assert not os.path.exists(path)
