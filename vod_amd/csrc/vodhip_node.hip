@@ -159,6 +159,33 @@ int vodhip_node_index_create(int n_devices, const int* devices, int64_t dim, int
             if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) nx->peer_ok[g] = 0;
             (void)hipGetLastError();
         }
+        if (nx->peer_ok[g]) {
+            // the runtime said yes: prove it with a 256-byte round trip devices[0] -> devices[g] -> devices[0] before any search depends
+            // on it (a node whose fabric is half configured answers "can access" and then fails the copy: host staging still works)
+            void *a = nullptr, *b2 = nullptr;
+            unsigned char probe[256], back[256];
+            for (int i = 0; i < 256; ++i) probe[i] = (unsigned char)(i * 7 + g);
+            memset(back, 0, sizeof(back));
+            hipError_t pe = hipSetDevice(devices[0]);
+            if (pe == hipSuccess) pe = hipMalloc(&a, 512);
+            if (pe == hipSuccess) pe = hipSetDevice(devices[g]);
+            if (pe == hipSuccess) pe = hipMalloc(&b2, 256);
+            if (pe == hipSuccess) pe = hipSetDevice(devices[0]);
+            if (pe == hipSuccess) pe = hipMemcpy(a, probe, 256, hipMemcpyHostToDevice);
+            if (pe == hipSuccess) pe = hipMemcpyPeerAsync(b2, devices[g], a, devices[0], 256, nx->stream[0]);
+            if (pe == hipSuccess) pe = hipStreamSynchronize(nx->stream[0]);
+            if (pe == hipSuccess) pe = hipSetDevice(devices[g]);
+            if (pe == hipSuccess) pe = hipMemcpyPeerAsync((char*)a + 256, devices[0], b2, devices[g], 256, nx->stream[g]);
+            if (pe == hipSuccess) pe = hipStreamSynchronize(nx->stream[g]);
+            if (pe == hipSuccess) pe = hipSetDevice(devices[0]);
+            if (pe == hipSuccess) pe = hipMemcpy(back, (char*)a + 256, 256, hipMemcpyDeviceToHost);
+            if (pe != hipSuccess || memcmp(probe, back, 256) != 0) nx->peer_ok[g] = 0;
+            (void)hipSetDevice(devices[0]);
+            if (a) (void)hipFree(a);
+            (void)hipSetDevice(devices[g]);
+            if (b2) (void)hipFree(b2);
+            (void)hipGetLastError();
+        }
     }
     (void)hipSetDevice(devices[0]);
     *out = nx;
