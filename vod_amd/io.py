@@ -273,12 +273,11 @@ def load_npy_view(body) -> np.ndarray:
     """`np.load` of raw `.npy` bytes as a VIEW into `body` where the layout allows it (C order, no objects, aligned data):
     a 3 MB query batch is not copied once more on its way to the device.  Anything else goes through `np.load`."""
     mv = memoryview(body)
-    if bytes(mv[:8]) == b"\x93NUMPY\x01\x00":
-        head = io.BytesIO(bytes(mv[:65546]))
-        head.seek(8)
-        shape, fortran, dt = np.lib.format.read_array_header_1_0(head)
-        off = head.tell()
-        count = int(np.prod(shape, dtype=np.int64))
-        if not dt.hasobject and not fortran and off + count * dt.itemsize <= mv.nbytes and off % dt.itemsize == 0:
-            return np.frombuffer(mv, dtype=dt, count=count, offset=off).reshape(shape)
+    if mv.nbytes >= 10:
+        layout = _npy_layout(np.frombuffer(mv, dtype=np.uint8))
+        if layout is not None:
+            dt, shape, off = layout
+            count = int(np.prod(shape, dtype=np.int64))
+            if off + count * dt.itemsize <= mv.nbytes and off % dt.itemsize == 0:
+                return np.frombuffer(mv, dtype=dt, count=count, offset=off).reshape(shape)
     return np.load(io.BytesIO(bytes(mv)), allow_pickle=False)
