@@ -135,7 +135,9 @@ class Endpoints:
         """POST /search (server.py:68-73): JSON lists in, JSON lists out."""
         query = SearchQuery(**document)
         scores, indices = self.search(np.asarray(query.vectors, dtype=np.float32), query.top_k, client=client)
-        rows = [[(None if np.isneginf(v) else float(v)) for v in r] for r in scores]
+        rows = scores.astype(np.float64).tolist()  # (float(v) of every float32, in C)
+        if np.isneginf(scores).any():  # pads of a store with fewer than top_k rows: JSON has no -inf literal in strict mode -> null
+            rows = [[(None if v == -np.inf else v) for v in r] for r in rows]
         return SearchResponse(scores=rows, indices=indices.tolist()).model_dump()
 
     def fast_search(self, body, client: int = 0) -> bytearray:
