@@ -56,9 +56,9 @@ case $P in
     timeout 900 python tests/fuzz/fuzz_collate.py --trials 4000 --seed 505 2>/dev/null | tail -2 | tee -a $OUT/fuzz_collate.txt
     timeout 1200 python tools/bench_http_load.py --routes fast --out $OUT/http_load_native.json > $OUT/http_load_native.log 2>&1; tail -12 $OUT/http_load_native.log | cut -c1-420 ;;
   campaign)  # long randomised campaigns on seeds never used before (budget that would otherwise lapse)
-    timeout 2400 python tests/fuzz/fuzz_search.py --trials 9000 --seed 601 2>/dev/null | tail -3 | tee -a $OUT/fuzz_search.txt
-    timeout 1200 python tests/fuzz/fuzz_collate.py --trials 12000 --seed 602 2>/dev/null | tail -3 | tee -a $OUT/fuzz_collate.txt
-    for args in "--requests 6000 --threads 24 --seed 603 --churn" "--requests 1500 --threads 16 --seed 604 --node" "--requests 1500 --threads 16 --seed 605 --group"; do
+    timeout 2400 python tests/fuzz/fuzz_search.py --trials 9000 --seed ${SEED_A:-601} 2>/dev/null | tail -3 | tee -a $OUT/fuzz_search.txt
+    timeout 1200 python tests/fuzz/fuzz_collate.py --trials 12000 --seed ${SEED_B:-602} 2>/dev/null | tail -3 | tee -a $OUT/fuzz_collate.txt
+    for args in "--requests 6000 --threads 24 --seed ${SEED_C:-603} --churn" "--requests 1500 --threads 16 --seed 604 --node" "--requests 1500 --threads 16 --seed 605 --group"; do
       timeout 1200 python tests/fuzz/fuzz_server.py $args 2>/dev/null | tail -2 | tee -a $OUT/fuzz_server.txt
     done ;;
   *) echo "unknown pass $P"; exit 2 ;;
