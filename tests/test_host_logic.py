@@ -1280,3 +1280,29 @@ def test_client_lean_connection_and_its_fallbacks():
     finally:
         t.join(timeout=10)
         srv.close()
+
+
+def test_npy_readers_take_every_layout_the_reference_codec_can_send():
+    """The readers parse the `.npy` header natively for the service's own layouts (2-D float32 / float16 / int64) and through NumPy for
+    everything else: same arrays either way, views where the alignment allows, errors for truncated payloads."""
+    rng = np.random.default_rng(12)
+    cases = [rng.normal(size=(5, 7)).astype(np.float32), rng.normal(size=(3, 4)).astype(np.float16), rng.integers(-9, 9, size=(6, 2)).astype(np.int64),
+             rng.normal(size=(4, 3)), rng.integers(0, 5, size=(7,)).astype(np.int32), rng.normal(size=(2, 3, 4)).astype(np.float32),
+             np.zeros((0, 8), np.float32), np.asfortranarray(rng.normal(size=(3, 5)).astype(np.float32)), rng.uniform(size=(4, 4)) > 0.5]
+    for arr in cases:
+        text = vio.serialize_np_array(arr)
+        body = b'{"k": "' + text.encode() + b'"}'
+        got = vio.deserialize_np_array_span(body, 7, 7 + len(text))
+        np.testing.assert_array_equal(got, arr)
+        assert got.dtype == arr.dtype and got.shape == arr.shape
+        buf = __import__("io").BytesIO()
+        np.save(buf, arr)
+        view = vio.load_npy_view(buf.getvalue())
+        np.testing.assert_array_equal(view, arr)
+        assert view.dtype == arr.dtype
+    # a header that promises more data than the payload holds
+    buf = __import__("io").BytesIO()
+    np.save(buf, cases[0])
+    cut = buf.getvalue()[:-8]
+    with pytest.raises(Exception):
+        vio.load_npy_view(cut)
