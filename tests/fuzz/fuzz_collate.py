@@ -76,22 +76,23 @@ def fuzz_sampling(rng):
     k_pos = int(rng.integers(0, k_tot + 1))
     temp = float(rng.choice([0.0, 0.5, 1.0, 3.0]))
     support = int(rng.choice([-1, -1, 1, 10, 100, 2000]))
-    LAST.clear(); LAST.update(kind="sampling", nq=nq, n=n, k_pos=k_pos, k_tot=k_tot, temp=temp, support=support)
+    keep_top = bool(rng.random() < 0.4)  # the corrected support truncation beside the reference's
+    LAST.clear(); LAST.update(kind="sampling", nq=nq, n=n, k_pos=k_pos, k_tot=k_tot, temp=temp, support=support, keep_top=keep_top)
     scores = (rng.normal(size=(nq, n)) * 3).astype(np.float32)
     scores[rng.uniform(size=scores.shape) < float(rng.choice([0.0, 0.1, 0.8]))] = -np.inf
     labels = rng.uniform(size=scores.shape) < float(rng.choice([0.0, 0.05, 0.5]))
     noise = rng.exponential(size=scores.shape).astype(np.float32)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
     out = labeled_priority_sampling_tensors(t(scores), t(labels), t(noise), k_pos, k_tot, normalized=True, temperature=temp,
-                                            max_support_size=support)
+                                            max_support_size=support, support="keep_top" if keep_top else "reference")
     smp, logw, lab, lse = [o.cpu().numpy() for o in out]
     sup = max(support, k_tot) if support >= 0 else -1
-    r_smp, r_logw, r_lab, r_lse = labeled_priority_sampling_2d(scores, labels, noise, k_pos, k_tot, True, temp, sup)
+    r_smp, r_logw, r_lab, r_lse = labeled_priority_sampling_2d(scores, labels, noise, k_pos, k_tot, True, temp, sup, keep_top)
     # The reference orders the samples by an fp32 key through an unstable argsort and computes the weights with
     # log1p(-exp(-exp(log_p - log_tau))) in fp32, which loses ~eps / x relative accuracy for a sample of inclusion
     # probability x << 1: ids are compared as per-row SETS split by label, weights after aligning by id, and the tolerance
     # of a weight follows its conditioning, measured as the distance between the oracle run in fp32 and in fp64.
-    r64 = labeled_priority_sampling_2d(scores.astype(np.float64), labels, noise.astype(np.float64), k_pos, k_tot, True, temp, sup)
+    r64 = labeled_priority_sampling_2d(scores.astype(np.float64), labels, noise.astype(np.float64), k_pos, k_tot, True, temp, sup, keep_top)
     finite = np.isfinite(r_logw)
     assert np.array_equal(lab, r_lab), "sample labels"
     assert np.array_equal(smp < 0, r_smp < 0), "sample count"
@@ -118,7 +119,7 @@ def fuzz_sampling(rng):
     both = np.isfinite(r_lse)
     assert np.array_equal(np.isfinite(lse), both), "finite lse"
     np.testing.assert_allclose(lse[both], r_lse[both], rtol=5e-5, atol=5e-5)  # tree vs sequential float32 sums of up to 4096 terms
-    return dict(kind="sampling", nq=nq, n=n, k_pos=k_pos, k_tot=k_tot, temp=temp, support=support)
+    return dict(kind="sampling", nq=nq, n=n, k_pos=k_pos, k_tot=k_tot, temp=temp, support=support, keep_top=keep_top)
 
 
 def fuzz_gradients(rng):
@@ -244,9 +245,11 @@ def fuzz_chain(rng):
     kpos = min(total, int(rng.choice([1, 2, 8, total])))  # (k_positive > k_total is undefined in the reference: its numba loop overruns the output row)
     temp = float(rng.choice([0.0, 0.5, 1.0, 3.0]))
     support = None if rng.random() < 0.5 else int(rng.choice([1, 10, 100, 1000]))
+    keep_top = bool(rng.random() < 0.4)
+    mode = "keep_top" if keep_top else "reference"
     dup = float(rng.choice([0.0, 0.0, 0.5]))
     flat = bool(rng.random() < 0.5) and nq * total <= 8192
-    LAST.clear(); LAST.update(kind="chain", nq=nq, kl=kl, ks=ks, pool=pool, total=total, kpos=kpos, temp=temp, support=support, dup=dup, flat=flat)
+    LAST.clear(); LAST.update(kind="chain", nq=nq, kl=kl, ks=ks, pool=pool, total=total, kpos=kpos, temp=temp, support=support, keep_top=keep_top, dup=dup, flat=flat)
 
     def eng(k):
         idx = np.full((nq, k), -1, dtype=np.int64)
@@ -269,10 +272,10 @@ def fuzz_chain(rng):
         m_idx, m_scr, m_lbl, m_raw = merge_hybrid((l_idx, np.zeros(l_idx.shape, np.float32), l_lbl), dict(zip(names, engs)), weights)
     w = m_idx.shape[1]
     noise = rng.exponential(size=(nq, kl + sum(ks) + 1)).astype(np.float32)
-    ref = osmp.sample_search_results(m_idx, m_scr, m_lbl, m_raw, noise[:, :w], total, kpos, temp, support)
+    ref = osmp.sample_search_results(m_idx, m_scr, m_lbl, m_raw, noise[:, :w], total, kpos, temp, support, keep_top=keep_top)
     engines = {n: (t(i), t(sc)) for n, (i, sc) in zip(names, engs)}
     out = collate_on_device(t(l_idx), t(l_lbl), engines, weights, t(noise), total=total, max_pos_sections=kpos, temperature=temp,
-                            max_support_size=support)
+                            max_support_size=support, support=mode)
     fin = np.isfinite(ref["log_weights"])
     got_w = out.log_weights.cpu().numpy()
     _eq(np.isfinite(got_w), fin, "chain finite weights")
@@ -298,7 +301,7 @@ def fuzz_chain(rng):
     # log-weights: `log_p - log1p(-exp(-exp(log_p - log_tau)))` is ill-conditioned for inclusion probabilities << 1; the reference's
     # own float32 and float64 evaluations differ there, and that difference sets the tolerance (as in fuzz_sampling)
     with np.errstate(all="ignore"):
-        ref64 = osmp.sample_search_results(m_idx, m_scr.astype(np.float64), m_lbl, {}, noise[:, :w].astype(np.float64), total, kpos, temp, support)
+        ref64 = osmp.sample_search_results(m_idx, m_scr.astype(np.float64), m_lbl, {}, noise[:, :w].astype(np.float64), total, kpos, temp, support, keep_top=keep_top)
     same = ids_comparable and np.array_equal(np.where(fin, ref64["local"], -1), np.where(fin, ref["local"], -1)) and np.array_equal(got_ids[fin], ref["indices"][fin])
     if same:
         cond = np.abs(np.where(fin, ref["log_weights"].astype(np.float64) - ref64["log_weights"], 0.0)).max(axis=1, keepdims=True)
@@ -317,7 +320,7 @@ def fuzz_chain(rng):
             _eq(out.raw_scores[n].cpu().numpy()[fin], ref["raw"][n][fin], f"chain raw {n}")
     if flat:
         fl = collate_on_device(t(l_idx), t(l_lbl), engines, weights, t(noise), total=total, max_pos_sections=kpos, temperature=temp,
-                               max_support_size=support, in_batch_negatives=True)
+                               max_support_size=support, in_batch_negatives=True, support=mode)
         rf = osmp.flatten_samples(out.indices.cpu().numpy(), out.scores.cpu().numpy(), out.labels.cpu().numpy(), out.log_weights.cpu().numpy(),
                                   {n: v.cpu().numpy() for n, v in out.raw_scores.items()})
         _eq(fl.indices.cpu().numpy(), rf["indices"], "chain flat ids")
