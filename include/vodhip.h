@@ -449,6 +449,22 @@ int vodhip_http_stop(vodhip_http_t* http);
 int vodhip_http_destroy(vodhip_http_t* http);
 int vodhip_http_get_stat(vodhip_http_t* http, const char* key, int64_t* out);  /* "requests_native", "requests_fallback", "connections", "open_connections" */
 
+/* vodhip_client  the CLIENT side of the search service: one kept-alive HTTP/1.1 connection (TCP, or a Unix-domain socket when `unix_path`
+ * is given) that speaks POST /fast-search - the reference's documents, byte for byte what its client sends and parses - and POST
+ * /raw-search.  Replaces: FaissClient.search (src/vod_search/faiss_search/client.py:64-110) + io.serialize_np_array /
+ * deserialize_np_array (src/vod_search/io.py:17-32) for consumers that are not Python (cgo / JNI: same C-ABI as the in-process index) and
+ * for Python workers (one call with the GIL released instead of ~150 us of interpreter per exchange).
+ *   One handle = one connection = one caller at a time (a handle per thread).  A connection the server closed while idle is re-opened once.
+ *   search: queries host [nq, dim] F32 | F16; route 0 = /fast-search, 1 = /raw-search; timeout_s <= 0 = 120 s.
+ *           returns 0 with out_scores / out_ids [nq, k] filled; > 0 = the HTTP status of an error reply (its body: vodhip_client_last_body -
+ *           the server's `{"detail": ...}`); -1 = transport / protocol failure (vodhip_last_error; "timed out ..." for a timeout). */
+typedef struct vodhip_client vodhip_client_t;
+int vodhip_client_create(const char* host, int port, const char* unix_path, vodhip_client_t** out);
+int vodhip_client_destroy(vodhip_client_t* client);
+int vodhip_client_search(vodhip_client_t* client, const void* queries, int q_dtype, int64_t nq, int64_t dim, int k, int route, double timeout_s,
+                         float* out_scores, int64_t* out_ids);
+const char* vodhip_client_last_body(vodhip_client_t* client);
+
 /* The native front's wire pieces, exposed so that they can be checked byte for byte against NumPy / the Python codec without a
  * socket or a GPU (tests/test_host_logic.py):
  *   npy_header         np.lib.format.write_array_header_1_0 for a C-ordered [rows, cols] array; dtype VODHIP_F32 | VODHIP_F16 | 3 (int64);

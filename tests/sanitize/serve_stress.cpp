@@ -112,6 +112,8 @@ int main() {
 
     auto worker = [&](int t) {
         std::mt19937 r((unsigned)(100 + t));
+        vodhip_client_t* cli = nullptr;
+        if (vodhip_client_create("127.0.0.1", port, nullptr, &cli)) { ++g_errors; return; }
         for (int it = 0; it < 40; ++it) {
             const int64_t nq = 1 + (int64_t)(r() % 9);
             const int k = (it % 13 == 12) ? 77 : 1 + (int)(r() % 20);
@@ -132,12 +134,18 @@ int main() {
                     if (!http_raw_search(port, q, nq, 5, s, id, true)) ++g_errors;
                     continue;
                 }
-                for (int attempt = 0; attempt < 50 && !ok; ++attempt) ok = http_raw_search(port, q, nq, k, s, id, false);
+                if (it % 2 == 0) {
+                    for (int attempt = 0; attempt < 50 && !ok; ++attempt) ok = http_raw_search(port, q, nq, k, s, id, false);
+                } else {  // the library's own client: kept-alive connection, both routes (a batch failed by a k = 77 neighbour comes back as 500: retried)
+                    for (int attempt = 0; attempt < 50 && !ok; ++attempt)
+                        ok = vodhip_client_search(cli, q.data(), VODHIP_F32, nq, D, k, it % 4 == 1 ? 0 : 1, 10.0, s.data(), id.data()) == 0;
+                }
             }
             if (!ok) { ++g_errors; continue; }
             brute(q.data(), nq, k, rs.data(), rid.data());
             if (memcmp(s.data(), rs.data(), sizeof(float) * s.size()) || memcmp(id.data(), rid.data(), sizeof(int64_t) * id.size())) { ++g_errors; ++g_mismatch; }
         }
+        vodhip_client_destroy(cli);
     };
     std::vector<std::thread> ts;
     for (int t = 0; t < 12; ++t) ts.emplace_back(worker, t);

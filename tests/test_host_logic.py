@@ -666,23 +666,29 @@ def test_http_shell_on_a_unix_domain_socket(tmp_path, shell):
     try:
         assert os.path.exists(path)
         rs, ri = flat_ip_topk(q, x, 9)
-        for binary in (False, True):
-            c = vclient.HipMipsClient("http://127.0.0.1", port, binary=binary, uds=path)
-            assert c.ping()
-            for _ in range(3):
-                res = c.search(vector=q, top_k=9)
-            np.testing.assert_array_equal(res.indices, ri)
-            np.testing.assert_array_equal(res.scores, rs)
-            import socket as _socket
+        import socket as _socket
 
-            assert c._local.lean.sock.family == _socket.AF_UNIX            # the searches went through the Unix-domain socket
-            clone = pickle.loads(pickle.dumps(c))
-            np.testing.assert_array_equal(clone.search(vector=q, top_k=9).indices, ri)
+        for binary in (False, True):
+            for native in (True, False):  # libvodhip's client / the Python exchange
+                c = vclient.HipMipsClient("http://127.0.0.1", port, binary=binary, uds=path, native=native)
+                assert c.ping()
+                for _ in range(3):
+                    res = c.search(vector=q, top_k=9)
+                np.testing.assert_array_equal(res.indices, ri)
+                np.testing.assert_array_equal(res.scores, rs)
+                if native:
+                    assert c._local.native_h is not None and getattr(c._local, "lean", None) is None   # the searches never left the library
+                else:
+                    assert c._local.lean.sock.family == _socket.AF_UNIX        # ... went through the Unix-domain socket
+                clone = pickle.loads(pickle.dumps(c))
+                np.testing.assert_array_equal(clone.search(vector=q, top_k=9).indices, ri)
         # a socket path that does not exist on this host (a client on another machine, a rank that derived another path - round-3 advisor):
         # the searches fall back to the TCP address instead of failing
-        far = vclient.HipMipsClient("http://127.0.0.1", port, uds=str(tmp_path / "nobody-listens.sock"))
-        np.testing.assert_array_equal(far.search(vector=q, top_k=9).indices, ri)
-        assert far._local.lean.sock.family != _socket.AF_UNIX
+        for native in (True, False):
+            far = vclient.HipMipsClient("http://127.0.0.1", port, uds=str(tmp_path / "nobody-listens.sock"), native=native)
+            np.testing.assert_array_equal(far.search(vector=q, top_k=9).indices, ri)
+            if not native:
+                assert far._local.lean.sock.family != _socket.AF_UNIX
     finally:
         stop()
     assert not os.path.exists(path)
@@ -1242,7 +1248,7 @@ def test_client_lean_connection_and_its_fallbacks():
     rs, ri = flat_ip_topk(q, x, 4)
     port, stop = _serve_in_thread(_OracleEngine(x), shell="native")
     try:
-        c = vclient.HipMipsClient("http://127.0.0.1", port)
+        c = vclient.HipMipsClient("http://127.0.0.1", port, native=False)
         np.testing.assert_array_equal(c.search(vector=q, top_k=4).indices, ri)
         first = c._local.lean
         first.sock.shutdown(_socket.SHUT_RDWR)                         # what an idle timeout on the server's side looks like from here
@@ -1276,7 +1282,7 @@ def test_client_lean_connection_and_its_fallbacks():
     t = threading.Thread(target=serve, daemon=True)
     t.start()
     try:
-        c2 = vclient.HipMipsClient("http://127.0.0.1", srv.getsockname()[1])
+        c2 = vclient.HipMipsClient("http://127.0.0.1", srv.getsockname()[1], native=False)
         np.testing.assert_array_equal(c2.search(vector=q, top_k=4).indices, ri)
         assert c2._local.no_lean is True
     finally:
@@ -1308,3 +1314,115 @@ def test_npy_readers_take_every_layout_the_reference_codec_can_send():
     cut = buf.getvalue()[:-8]
     with pytest.raises(Exception):
         vio.load_npy_view(cut)
+
+
+def test_native_client_of_the_library():
+    """`vodhip_client_*` (what `HipMipsClient` uses by default, and what a non-Python consumer links): both routes and both query dtypes
+    equal the oracle; the request bytes are the Python codec's; a stale keep-alive is re-opened; an error reply comes back as its HTTP
+    status + body (-> HTTPError with the server's trace); an unframed reply or a dead address falls through to the Python path, which
+    reports it; a timeout is a ReadTimeout."""
+    import socket as _socket
+    import threading
+
+    from oracle.flat_ip import flat_ip_topk
+    from vod_amd import _native
+
+    rng = np.random.default_rng(21)
+    x = rng.integers(-4, 5, size=(150, 8)).astype(np.float32)
+    q = rng.integers(-4, 5, size=(6, 8)).astype(np.float32)
+    rs, ri = flat_ip_topk(q, x, 7)
+    port, stop = _serve_in_thread(_OracleEngine(x), shell="native")
+    lib = _native.load_library()
+    try:
+        for binary in (False, True):
+            for dt in (np.float32, np.float16):
+                c = vclient.HipMipsClient("http://127.0.0.1", port, binary=binary, wire_dtype=np.dtype(dt).name)
+                res = c.search(vector=q, top_k=7)
+                np.testing.assert_array_equal(res.indices, ri)
+                np.testing.assert_array_equal(res.scores, rs)
+                assert c._local.native_h is not None and res.meta["time"] > 0
+        # plain C-ABI use, as a cgo / JNI consumer would: create, search, error reply, destroy
+        h = ctypes.c_void_p()
+        assert lib.vodhip_client_create(b"127.0.0.1", port, None, ctypes.byref(h)) == 0
+        s, i = np.empty((6, 7), np.float32), np.empty((6, 7), np.int64)
+        for route in (0, 1):
+            assert lib.vodhip_client_search(h, q.ctypes.data, 2, 6, 8, 7, route, 5.0, s.ctypes.data, i.ctypes.data) == 0
+            np.testing.assert_array_equal(i, ri)
+            np.testing.assert_array_equal(s, rs)
+        rc = lib.vodhip_client_search(h, q.ctypes.data, 2, 6, 8, 5000, 0, 5.0, s.ctypes.data, i.ctypes.data)   # top_k out of range: the server's 500
+        assert rc == 500 and b"detail" in lib.vodhip_client_last_body(h)
+        assert lib.vodhip_client_search(h, q.ctypes.data, 2, 6, 8, 7, 0, 5.0, s.ctypes.data, i.ctypes.data) == 0   # the connection survived
+        bad = np.zeros((6, 5), np.float32)                                                                            # wrong dimension: 500 as well
+        assert lib.vodhip_client_search(h, bad.ctypes.data, 2, 6, 5, 7, 1, 5.0, s.ctypes.data, i.ctypes.data) == 500
+        assert lib.vodhip_client_destroy(h) == 0
+        # through the Python client: HTTPError with the status, then business as usual
+        c = vclient.HipMipsClient("http://127.0.0.1", port)
+        with pytest.raises(vclient.requests.exceptions.HTTPError, match="500"):
+            c.search(vector=q, top_k=5000)
+        np.testing.assert_array_equal(c.search(vector=q, top_k=7).indices, ri)
+    finally:
+        stop()
+    # the server is gone: the native client fails, the Python path reports it the way callers of the reference client expect
+    with pytest.raises(vclient.requests.exceptions.ConnectionError):
+        c.search(vector=q, top_k=7)
+
+    # a server that never answers: ReadTimeout from the native path
+    srv = _socket.socket()
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(2)
+    held = []
+    t = threading.Thread(target=lambda: held.append(srv.accept()), daemon=True)
+    t.start()
+    try:
+        slow = vclient.HipMipsClient("http://127.0.0.1", srv.getsockname()[1])
+        with pytest.raises(vclient.requests.exceptions.ReadTimeout):
+            slow.search(vector=q, top_k=7, timeout=0.3)
+    finally:
+        t.join(timeout=5)
+        for conn, _a in held:
+            conn.close()
+        srv.close()
+
+
+def test_native_client_reopens_a_connection_the_server_closed_while_idle():
+    import socket as _socket
+    import threading
+
+    rng = np.random.default_rng(22)
+    q = rng.integers(-4, 5, size=(3, 8)).astype(np.float32)
+    scores = rng.normal(size=(3, 4)).astype(np.float32)
+    ids = rng.integers(0, 99, size=(3, 4)).astype(np.int64)
+    body = bytes(vio.json_body_with_arrays({"scores": scores, "indices": ids}))
+    srv = _socket.socket()
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(4)
+    seen = []
+
+    def serve():
+        for _ in range(2):  # answers ONE request per connection, keeps quiet about closing it
+            conn, _a = srv.accept()
+            data = b""
+            while b"\r\n\r\n" not in data:
+                data += conn.recv(65536)
+            head, _, rest = data.partition(b"\r\n\r\n")
+            need = int([ln for ln in head.split(b"\r\n") if ln.lower().startswith(b"content-length")][0].split(b":")[1])
+            while len(rest) < need:
+                rest += conn.recv(65536)
+            seen.append(rest)
+            conn.sendall(b"HTTP/1.1 200 OK\r\ncontent-type: application/json\r\ncontent-length: %d\r\n\r\n" % len(body) + body)
+            conn.close()
+
+    t = threading.Thread(target=serve, daemon=True)
+    t.start()
+    try:
+        c = vclient.HipMipsClient("http://127.0.0.1", srv.getsockname()[1])
+        for _ in range(2):
+            res = c.search(vector=q, top_k=4)
+            np.testing.assert_array_equal(res.indices, ids)
+            np.testing.assert_array_equal(res.scores, scores)
+        assert c._local.native_h is not None and getattr(c._local, "lean", None) is None   # both went through the library
+        # the request document is the Python codec's, byte for byte (what the reference server parses)
+        assert seen[0] == bytes(vio.json_body_with_arrays({"vectors": q}, {"top_k": 4})) == seen[1]
+    finally:
+        t.join(timeout=10)
+        srv.close()

@@ -1,4 +1,4 @@
-"""The native serving layer (vod_amd/csrc/vodhip_serve.hip + vodhip_http.hip: scheduler / completion threads, caller hand-off, one thread per HTTP
+"""The native serving layer (vod_amd/csrc/vodhip_serve.hip + vodhip_http.hip + vodhip_client.hip: scheduler / completion threads, caller hand-off, one thread per HTTP
 connection, the wire parsers, the shutdown paths) under ThreadSanitizer and AddressSanitizer.  GPU sanitizers are not available on the
 pool, so the file is compiled as HOST C++ and driven by tests/sanitize/serve_stress.cpp with a callback engine (exact brute force on the
 host): 12 threads x 40 requests through `vodhip_batcher_search` and through real sockets, engine failures, non-`.npy` bodies through the
@@ -24,7 +24,7 @@ def test_serving_layer_is_clean_under(sanitizer, tmp_path):
     exe = tmp_path / f"serve_stress_{sanitizer}"
     libdir = ROOT / "vod_amd" / "csrc"
     cmd = [CLANG, "-std=c++17", "-g", "-O1", f"-fsanitize={sanitizer}", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-x", "c++",
-           str(libdir / "vodhip_serve.hip"), "-x", "c++", str(libdir / "vodhip_http.hip"), str(ROOT / "tests" / "sanitize" / "serve_stress.cpp"), "-I", str(ROOT / "include"), "-I", str(libdir),
+           str(libdir / "vodhip_serve.hip"), "-x", "c++", str(libdir / "vodhip_http.hip"), "-x", "c++", str(libdir / "vodhip_client.hip"), str(ROOT / "tests" / "sanitize" / "serve_stress.cpp"), "-I", str(ROOT / "include"), "-I", str(libdir),
            "-I", "/opt/rocm/include", "-L", str(libdir), "-lvodhip", "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}",
            "-Wl,-rpath,/opt/rocm/lib", "-lpthread", "-o", str(exe)]
     built = subprocess.run(cmd, capture_output=True, text=True, timeout=600)

@@ -103,6 +103,10 @@ SIGNATURES: dict[str, tuple] = {
     "vodhip_batcher_get_stat": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i64)]),
     "vodhip_batcher_search": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _i32, _c.c_uint64, _vp, _vp]),
     "vodhip_batcher_forget_client": (_i32, [_vp, _c.c_uint64]),
+    "vodhip_client_create": (_i32, [_c.c_char_p, _i32, _c.c_char_p, _c.POINTER(_vp)]),
+    "vodhip_client_destroy": (_i32, [_vp]),
+    "vodhip_client_search": (_i32, [_vp, _vp, _i32, _i64, _i64, _i32, _i32, _c.c_double, _vp, _vp]),
+    "vodhip_client_last_body": (_c.c_char_p, [_vp]),
     "vodhip_http_reply_set": (_i32, [_vp, _i32, _c.c_char_p, _vp, _i64, _c.c_char_p]),
     "vodhip_http_create": (_i32, [_vp, _i64, _vp, _vp, _i64, _c.POINTER(_vp)]),
     "vodhip_http_listen_tcp": (_i32, [_vp, _c.c_char_p, _i32]),

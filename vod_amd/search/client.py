@@ -134,14 +134,33 @@ class _LeanConnection:
         return status, headers, bytes(payload) if n_body < 4096 else payload
 
 
+class _NativeClientHandle:
+    """Owner of one `vodhip_client` handle (one kept-alive connection): lives in a thread's local storage and closes the connection
+    when the thread - or the client object - goes away.  A forked child never uses (or frees) its parent's handle."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle, self.pid = lib, handle, os.getpid()
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            if self.handle and self.pid == os.getpid():
+                self.lib.vodhip_client_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class HipMipsClient(base.SearchClient):
     """HTTP client of the HIP MIPS server."""
 
     requires_vectors = True
 
     def __init__(self, host: str = "http://localhost", port: int = 7678, binary: bool = False, forward_subset_ids: bool = False,
-                 wire_dtype: str | None = None, uds: str | None = None):
+                 wire_dtype: str | None = None, uds: str | None = None, native: bool = True):
         self.host = host
+        # the exchange itself (request document, framing, reply parsing) runs in libvodhip's client (`vodhip_client_*`, one call with the
+        # GIL released) when the library can be loaded in this process and the address is plain http / a Unix socket; anything it cannot do
+        # (subset filters, https, a transport hiccup) goes through the Python path below, which also produces the exceptions
+        self.native = native
         self.port = port
         # a Unix-domain socket path the server also listens on (`--uds`): the searches go through it (same HTTP, no TCP stack);
         # `ping()` keeps using host:port, so a client on another host simply leaves it unset
@@ -167,6 +186,7 @@ class HipMipsClient(base.SearchClient):
         self.__dict__.update(state)
         self.__dict__.setdefault("wire_dtype", None)
         self.__dict__.setdefault("uds", None)
+        self.__dict__.setdefault("native", True)
         self._local = threading.local()
 
     @property
@@ -311,7 +331,12 @@ class HipMipsClient(base.SearchClient):
         timeout: float = 120,
     ) -> vt.RetrievalBatch:
         start = time.time()
-        if self.binary and not (self.forward_subset_ids and subset_ids is not None):
+        filtered = self.forward_subset_ids and subset_ids is not None
+        if self.native and not filtered:
+            out = self._search_native(vector, top_k, timeout)
+            if out is not None:
+                return vt.RetrievalBatch(scores=out[0], indices=out[1], labels=None, meta={"time": time.time() - start})
+        if self.binary and not filtered:
             return self._search_binary(np.asarray(vector), top_k, timeout, start)
         extra: dict = {"top_k": top_k}
         if self.forward_subset_ids and subset_ids is not None:
@@ -324,6 +349,61 @@ class HipMipsClient(base.SearchClient):
         take = lambda key: io.deserialize_np_array_span(content, *spans[key]) if key in spans else io.deserialize_np_array(small[key])  # noqa: E731
         return vt.RetrievalBatch.cast(indices=take("indices"), scores=take("scores"), labels=None, meta={"time": time.time() - start})
 
+
+    def _native_handle(self):
+        """This thread's `vodhip_client` handle (None: the library is not loadable here, or the address is not plain http / a socket)."""
+        import ctypes
+        import urllib.parse
+
+        loc = self._local
+        if getattr(loc, "native_off", False):
+            return None
+        h = getattr(loc, "native_h", None)
+        if h is not None and h.pid == os.getpid():
+            return h
+        try:
+            from vod_amd import _native
+
+            lib = _native.load_library()
+        except Exception:
+            loc.native_off = True
+            return None
+        u = urllib.parse.urlsplit(self.host if "://" in self.host else "http://" + self.host)
+        if u.scheme != "http" or not u.hostname:
+            loc.native_off = True
+            return None
+        uds = self.uds if (self.uds and os.path.exists(self.uds)) else None
+        handle = ctypes.c_void_p()
+        if lib.vodhip_client_create(u.hostname.encode(), int(self.port), uds.encode() if uds else None, ctypes.byref(handle)) != 0:
+            loc.native_off = True
+            return None
+        loc.native_h = _NativeClientHandle(lib, handle)
+        return loc.native_h
+
+    def _search_native(self, vector, top_k: int, timeout: float):
+        """One call into libvodhip's client.  (scores, indices), or None when the Python path should take this request: a layout the
+        native client does not send, or a transport failure - which the Python path then meets (and reports) itself."""
+        v = self._wire(vector)
+        if v.ndim != 2 or v.shape[0] < 1 or v.shape[1] < 1 or v.dtype not in (np.float32, np.float16) or not 1 <= int(top_k) <= 1 << 20:
+            return None
+        h = self._native_handle()
+        if h is None:
+            return None
+        lib, handle = h.lib, h.handle
+        nq, k = int(v.shape[0]), int(top_k)
+        scores = np.empty((nq, k), dtype=np.float32)
+        indices = np.empty((nq, k), dtype=np.int64)
+        rc = lib.vodhip_client_search(handle, v.ctypes.data, 2 if v.dtype == np.float32 else 0, nq, int(v.shape[1]), k, 1 if self.binary else 0,
+                                      float(timeout), scores.ctypes.data, indices.ctypes.data)
+        if rc == 0:
+            return scores, indices
+        if rc > 0:  # an error reply of the server: the reference client's behaviour (print the trace, raise HTTPError)
+            body = lib.vodhip_client_last_body(handle) or b""
+            self._raise_for_status(int(rc), body, f"{self.url}/{'raw' if self.binary else 'fast'}-search")
+        msg = (lib.vodhip_last_error() or b"").decode("utf-8", "replace")
+        if "timed out" in msg:
+            raise requests.exceptions.ReadTimeout(f"POST {self.url}: {msg} (timeout {timeout} s)")
+        return None
 
     def _search_binary(self, vector: np.ndarray, top_k: int, timeout: float, start: float) -> vt.RetrievalBatch:
         v = self._wire(vector)
