@@ -501,14 +501,18 @@ def test_master_with_a_unix_domain_socket(tmp_path):
     with HipMipsMaster(tmp_path / "v.npy", port=-1, logging_level="warning", uds=True) as m:
         c = m.get_client()
         assert c.uds and os.path.exists(c.uds) and c.ping()
-        for binary in (False, True):
-            cl = type(c)(host=c.host, port=c.port, uds=c.uds, binary=binary)
-            res = cl.search(vector=q, top_k=50)
-            rs, ri = flat_ip_topk(q, x, 50)
-            np.testing.assert_array_equal(res.indices, ri)
-            np.testing.assert_array_equal(res.scores, rs)
-            import socket as _socket
+        import socket as _socket
 
-            assert cl._local.lean.sock.family == _socket.AF_UNIX
+        for binary in (False, True):
+            for native in (True, False):  # libvodhip's client / the Python exchange, both over the socket file
+                cl = type(c)(host=c.host, port=c.port, uds=c.uds, binary=binary, native=native)
+                res = cl.search(vector=q, top_k=50)
+                rs, ri = flat_ip_topk(q, x, 50)
+                np.testing.assert_array_equal(res.indices, ri)
+                np.testing.assert_array_equal(res.scores, rs)
+                if native:
+                    assert cl._local.native_h is not None and getattr(cl._local, "lean", None) is None
+                else:
+                    assert cl._local.lean.sock.family == _socket.AF_UNIX
         path = c.uds
     assert not os.path.exists(path)
