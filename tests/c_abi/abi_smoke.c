@@ -176,6 +176,25 @@ static int serving_case(vodhip_index_t* ix, const float* q, int64_t nq, int64_t 
     int64_t n_native = 0;
     CHECK(vodhip_http_get_stat(h, "requests_native", &n_native));
     if (n_native != 1) { fprintf(stderr, "requests_native = %lld\n", (long long)n_native); return 1; }
+    /* the same searches through the library's own client (what a C / cgo / JNI trainer links): both routes, one kept-alive connection */
+    vodhip_client_t* cli = NULL;
+    CHECK(vodhip_client_create("127.0.0.1", port, NULL, &cli));
+    for (int route = 0; route < 2; ++route) {
+        memset(s, 0, sizeof(float) * (size_t)(nq * k));
+        memset(id, 0, sizeof(int64_t) * (size_t)(nq * k));
+        CHECK(vodhip_client_search(cli, q, VODHIP_F32, nq, d, k, route, 30.0, s, id));
+        if (memcmp(s, want_s, sizeof(float) * (size_t)(nq * k)) != 0 || memcmp(id, want_i, sizeof(int64_t) * (size_t)(nq * k)) != 0) {
+            fprintf(stderr, "client route %d differs from the direct search\n", route);
+            return 1;
+        }
+    }
+    if (vodhip_client_search(cli, q, VODHIP_F32, nq, d, 0, 0, 30.0, s, id) < 400 || !strstr(vodhip_client_last_body(cli), "detail")) {
+        fprintf(stderr, "client: top_k = 0 did not come back as an error reply\n");
+        return 1;
+    }
+    CHECK(vodhip_client_destroy(cli));
+    CHECK(vodhip_http_get_stat(h, "requests_native", &n_native));
+    if (n_native != 3) { fprintf(stderr, "requests_native = %lld after the client's searches\n", (long long)n_native); return 1; }
     CHECK(vodhip_http_destroy(h));
     CHECK(vodhip_batcher_destroy(b));
     free(s); free(id); free(body); free(reply);
