@@ -315,6 +315,15 @@ int vodhip_client_search(vodhip_client_t* c, const void* queries, int q_dtype, i
     }
     c->used = true;
     if (r.close_after) drop(c);
+    struct Trim {  // a handle that once carried an unusually large batch does not keep its buffers (runs on every way out below)
+        vodhip_client* c;
+        ~Trim() {
+            constexpr size_t KEEP = 64u << 20;
+            if (c->out.capacity() > KEEP) std::vector<char>().swap(c->out);
+            if (c->in.capacity() > KEEP) std::vector<char>().swap(c->in);
+            if (c->raw.capacity() > KEEP) std::vector<uint8_t>().swap(c->raw);
+        }
+    } trim{c};
     const char* body = c->in.data() + r.body_off;
     if (r.status != 200) {
         c->last_body.assign(body, r.body_len);
