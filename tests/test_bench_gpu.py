@@ -180,7 +180,7 @@ def test_bench_default_line_carries_the_side_workloads():
     assert "error" not in c5, c5
     assert c5["verify"]["ok"] is True and c5["verify"]["collate_cases"] >= 4 and c5["verify"]["gradient_cases"] == 5
     assert c5["collate_merge_sample"]["host_syncs"] == 0 and c5["collate_merge_sample_flatten"]["host_syncs"] == 0
-    assert 0 < c5["collate_merge_sample"]["device_us"] < c5["collate_merge_sample"]["wall_us"] < 2000
+    assert 0 < c5["collate_merge_sample"]["wall_us"] < 2000 and 0 < c5["collate_merge_sample"]["device_us"] < 1.5 * c5["collate_merge_sample"]["wall_us"]  # (two separate medians)
     assert c5["retrieval_loss_inbatch_64x2048"]["fwd_bwd_wall_us"] > 0
     for shape in ("retrieval_loss_3d_64x32", "retrieval_loss_inbatch_64x2048"):  # the same step as one captured hipGraph
         assert c5[shape]["graphed_equals_eager"] is True and 0 < c5[shape]["graphed_fwd_bwd_wall_us"] < 400  # (the eager step varies 110-220 us with the box)
