@@ -304,7 +304,9 @@ bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
         int missing = 0;
         const auto active_window = std::chrono::nanoseconds((int64_t)std::max(5e6, 4.0 * (b->ema_flat_scan_ns + 1e6)));
         for (const auto& kv : b->clients) {
-            if (now - kv.second.last_seen > active_window) continue;
+            // (recently ACTIVE = sent a request or was ANSWERED within the window: with 32 clients x 64 queries a client's cycle is ~27 ms, its
+            // last arrival older than the window when its answer leaves - and it is the next to come back)
+            if (now - std::max(kv.second.last_seen, kv.second.answered ? kv.second.last_done : kv.second.last_seen) > active_window) continue;
             bool has = false;
             for (const Request* r : b->pending) has = has || r->client == kv.first;
             for (const Batch* bt : b->inflight)
@@ -339,7 +341,7 @@ bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
     tp_t give_up = deadline;  // the earliest moment one of the awaited clients stops being plausible
     for (const auto& kv : b->clients) {
         const vodhip_batcher::Client& c = kv.second;
-        if (now - c.last_seen > active_window || !c.answered || c.ema_gap_ns <= 0.0) continue;
+        if (!c.answered || c.ema_gap_ns <= 0.0 || now - std::max(c.last_seen, c.last_done) > active_window) continue;
         bool has = false;
         for (const Request* r : b->pending) has = has || r->client == kv.first;
         if (has) continue;
