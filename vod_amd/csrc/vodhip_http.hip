@@ -51,8 +51,6 @@ int sfail(const char* fmt, ...) {
     return -1;
 }
 
-inline int64_t ns_between(tp_t a, tp_t b) { return std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); }
-inline int elem_bytes(int dtype) { return dtype == VODHIP_F32 ? 4 : 2; }
 
 }  // namespace
 
