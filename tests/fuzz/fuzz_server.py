@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--wait-ms", type=float, default=0.0)
     ap.add_argument("--group", action="store_true", help="serve through the worker group (devices=[0, 0], gloo)")
     ap.add_argument("--node", action="store_true", help="serve through the one-process node index (devices=[0, 0], group_backend=node)")
-    ap.add_argument("--http", default="native", choices=["native", "asyncio", "uvicorn"])
+    ap.add_argument("--http", default="native", choices=["native", "uvicorn"])
     ap.add_argument("--churn", action="store_true", help="a NEW client object (new connections) every 25 requests per route: connection churn for soak runs")
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()

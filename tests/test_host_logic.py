@@ -512,64 +512,28 @@ def test_master_command_line_for_a_multi_gpu_group(tmp_path):
     assert cmd1[cmd1.index("--device") + 1] == "2" and "--devices" not in cmd1
 
 
-# ---- the HTTP shells - libvodhip's native front (production) and the asyncio server - speak the same contract over real sockets ---
-SHELLS = ["native", "asyncio"]
+# ---- the HTTP shell - libvodhip's native front (the one hot-route server) - over real sockets -----------------------------------
+SHELLS = ["native"]
 
 
-def _serve_in_thread(engine, micro_batch_wait_ms=0.0, uds=None, shell="asyncio"):
-    import asyncio
-    import threading
-
-    if shell == "native":
-        from vod_amd.search.native import NativeHttpFront
-        from vod_amd.search.server import Endpoints
-
-        endpoints = Endpoints(engine, micro_batch_wait_ms)
-        batcher = endpoints._batcher_for(8)  # the test engines have no fixed dimension of their own: every store here is 8 wide
-        endpoints.batcher = batcher
-        front = NativeHttpFront(batcher, endpoints)
-        port = front.listen("127.0.0.1", 0, uds)
-        front.start()
-
-        def stop_native():
-            front.close()
-            endpoints.close()
-
-        stop_native.front = front
-        return port, stop_native
-
-    from vod_amd.search import fastserver
+def _serve_in_thread(engine, micro_batch_wait_ms=0.0, uds=None, shell="native"):
+    assert shell == "native"
+    from vod_amd.search.native import NativeHttpFront
     from vod_amd.search.server import Endpoints
-    from vod_amd.search.socket import find_available_port
 
-    port = find_available_port()
-    state = {}
+    endpoints = Endpoints(engine, micro_batch_wait_ms)
+    batcher = endpoints._batcher_for(8)  # the test engines have no fixed dimension of their own: every store here is 8 wide
+    endpoints.batcher = batcher
+    front = NativeHttpFront(batcher, endpoints)
+    port = front.listen("127.0.0.1", 0, uds)
+    front.start()
 
-    def run():
-        async def main():
-            state["loop"], state["stop"] = asyncio.get_running_loop(), asyncio.Event()
-            ready = asyncio.Event()
-            task = asyncio.create_task(fastserver.serve(Endpoints(engine, micro_batch_wait_ms), "127.0.0.1", port, workers=16, ready=ready,
-                                                        stop=state["stop"], uds=uds))
-            await ready.wait()
-            state["ready"] = True
-            await task
+    def stop_native():
+        front.close()
+        endpoints.close()
 
-        asyncio.run(main())
-
-    th = threading.Thread(target=run, daemon=True)
-    th.start()
-    for _ in range(200):
-        if state.get("ready"):
-            break
-        __import__("time").sleep(0.02)
-    assert state.get("ready"), "server did not start"
-
-    def stop():
-        state["loop"].call_soon_threadsafe(state["stop"].set)
-        th.join(timeout=10)
-
-    return port, stop
+    stop_native.front = front
+    return port, stop_native
 
 
 @pytest.mark.parametrize("shell", SHELLS)
@@ -689,9 +653,37 @@ def test_http_shell_on_a_unix_domain_socket(tmp_path, shell):
             np.testing.assert_array_equal(far.search(vector=q, top_k=9).indices, ri)
             if not native:
                 assert far._local.lean.sock.family != _socket.AF_UNIX
+        # a second server must not take over (unlink) a socket a live listener still answers on (round-4 advisor)
+        with pytest.raises(Exception, match="live server"):
+            _serve_in_thread(_OracleEngine(x), uds=path, shell=shell)
+        assert os.path.exists(path)
+        np.testing.assert_array_equal(vclient.HipMipsClient("http://127.0.0.1", port, uds=path).search(vector=q, top_k=9).indices, ri)
+        # conflicting repeated Content-Length headers are a 400 (RFC 9110), agreeing ones are fine
+        import http.client as _hc
+
+        for lens, want in (((5, 7), 400), ((2, 2), 200)):
+            raw = _socket.create_connection(("127.0.0.1", port))
+            raw.sendall(b"POST /fast-search HTTP/1.1\r\nHost: x\r\n" + b"".join(b"Content-Length: %d\r\n" % n for n in lens)
+                        + b"Connection: close\r\n\r\n" + b"{}" + b"x" * 8)
+            status = int(raw.recv(65536).split(b" ", 2)[1])
+            raw.close()
+            assert (status == 400) == (want == 400), (lens, status)
     finally:
         stop()
     assert not os.path.exists(path)
+
+
+def test_default_socket_directory_is_private_to_the_user():
+    import os
+    import stat
+
+    from vod_amd.search.socket import private_socket_dir
+
+    d = private_socket_dir()
+    st = os.stat(d)
+    assert stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not st.st_mode & 0o022
+    m = vclient.HipMipsMaster("synthetic:10x8", port=7011, skip_setup=True, uds=True)
+    assert os.path.dirname(m.uds) == d and m.uds.endswith("vodhip-7011.sock")
 
 
 @pytest.mark.parametrize("shell", SHELLS)
@@ -1349,11 +1341,15 @@ def test_native_client_of_the_library():
             assert lib.vodhip_client_search(h, q.ctypes.data, 2, 6, 8, 7, route, 5.0, s.ctypes.data, i.ctypes.data) == 0
             np.testing.assert_array_equal(i, ri)
             np.testing.assert_array_equal(s, rs)
-        rc = lib.vodhip_client_search(h, q.ctypes.data, 2, 6, 8, 5000, 0, 5.0, s.ctypes.data, i.ctypes.data)   # top_k out of range: the server's 500
-        assert rc == 500 and b"detail" in lib.vodhip_client_last_body(h)
+        # top_k outside [1, VODHIP_MAX_K] never leaves the native client (a 200 reply would not fit the caller's [nq, k] buffers)
+        for bad_k in (0, -3, 5000):
+            assert lib.vodhip_client_search(h, q.ctypes.data, 2, 6, 8, bad_k, 0, 5.0, s.ctypes.data, i.ctypes.data) == -1
+            assert b"out of range" in lib.vodhip_last_error()
         assert lib.vodhip_client_search(h, q.ctypes.data, 2, 6, 8, 7, 0, 5.0, s.ctypes.data, i.ctypes.data) == 0   # the connection survived
         bad = np.zeros((6, 5), np.float32)                                                                            # wrong dimension: 500 as well
         assert lib.vodhip_client_search(h, bad.ctypes.data, 2, 6, 5, 7, 1, 5.0, s.ctypes.data, i.ctypes.data) == 500
+        assert b"detail" in lib.vodhip_client_last_body(h)
+        assert lib.vodhip_client_search(h, q.ctypes.data, 2, 6, 8, 7, 1, 5.0, s.ctypes.data, i.ctypes.data) == 0   # the connection survived
         assert lib.vodhip_client_destroy(h) == 0
         # through the Python client: HTTPError with the status, then business as usual
         c = vclient.HipMipsClient("http://127.0.0.1", port)

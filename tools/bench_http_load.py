@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--clients", type=int, nargs="+", default=[1, 8, 32])
     ap.add_argument("--nq", type=int, nargs="+", default=[32, 64, 256])
     ap.add_argument("--micro-batch-ms", type=float, nargs="+", default=[0.0])
-    ap.add_argument("--http", default="native", choices=["native", "asyncio", "uvicorn"])
+    ap.add_argument("--http", default="native", choices=["native", "uvicorn"])
     ap.add_argument("--routes", nargs="+", default=["fast", "raw"], choices=["fast", "raw"])
     ap.add_argument("--batcher-param", action="append", default=[], metavar="KEY=VALUE")
     ap.add_argument("--devices", type=int, nargs="+", default=None, help="serve the store row-sharded over these GPUs (a device may repeat)")

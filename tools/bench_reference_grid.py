@@ -50,7 +50,7 @@ def main() -> None:
     ap.add_argument("--rows", type=int, nargs="+", default=[100, 1000, 10_000, 100_000])
     ap.add_argument("--dims", type=int, nargs="+", default=[128, 512, 1024])
     ap.add_argument("--repeats", type=int, default=50)
-    ap.add_argument("--http", default="native", choices=["native", "asyncio", "uvicorn"])
+    ap.add_argument("--http", default="native", choices=["native", "uvicorn"])
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import torch

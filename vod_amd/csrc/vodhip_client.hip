@@ -272,6 +272,8 @@ int vodhip_client_search(vodhip_client_t* c, const void* queries, int q_dtype, i
     if (nq < 1 || dim < 1 || !queries || !out_scores || !out_ids) return cfail("invalid query / output arguments");
     if (q_dtype != VODHIP_F32 && q_dtype != VODHIP_F16) return cfail("q_dtype must be VODHIP_F32 or VODHIP_F16");
     if (route != 0 && route != 1) return cfail("route must be 0 (/fast-search) or 1 (/raw-search)");
+    if (k < 1 || k > VODHIP_MAX_K) return cfail("k=%d out of range [1, %d]", k, VODHIP_MAX_K);
+    if (nq > (int64_t)1 << 31 || dim > (int64_t)1 << 24 || nq * dim > (int64_t)1 << 40) return cfail("query batch too large");
     // ---- request: head + body in one buffer ----
     uint8_t npy_head[192];
     const int64_t n_head = vodhip_wire_npy_header(q_dtype, nq, dim, npy_head, sizeof(npy_head));

@@ -300,6 +300,7 @@ struct vodhip_http {
     void* user = nullptr;
     int64_t dim = 0;
     int64_t max_body = 512ll << 20;
+    int idle_timeout_s = 900;  // SO_RCVTIMEO of accepted sockets (0 = none; VODHIP_HTTP_IDLE_TIMEOUT_S at create)
     std::vector<int> listen_fds;
     std::vector<std::string> unix_paths;
     std::thread th_accept;
@@ -582,6 +583,7 @@ void conn_main(vodhip_http* h, int fd, uint64_t client) {
                     while (ve > vb && (ve[-1] == ' ' || ve[-1] == '\t')) --ve;
                     const size_t nn = (size_t)(ne - nb);
                     if (ieq(nb, nn, "content-length")) {
+                        const long long previous = content_length;  // a repeated header must agree (RFC 9110 8.6: conflicting values -> 400)
                         content_length = 0;
                         if (vb == ve) bad_len = true;
                         for (const char* c = vb; c < ve; ++c) {
@@ -591,6 +593,7 @@ void conn_main(vodhip_http* h, int fd, uint64_t client) {
                             }
                             content_length = content_length * 10 + (*c - '0');
                         }
+                        if (previous >= 0 && previous != content_length) bad_len = true;
                     } else if (ieq(nb, nn, "connection")) {
                         connection.assign(vb, (size_t)(ve - vb));
                     } else if (ieq(nb, nn, "expect")) {
@@ -730,6 +733,10 @@ void accept_main(vodhip_http* h) {
             }
             int one = 1;
             (void)setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));  // (fails harmlessly on a Unix-domain socket)
+            // idle / slow-sender bound: a kept-alive connection that stays silent this long is closed (its client re-opens on the next
+            // search: vodhip_client retries once, the Python client's pool likewise) - a thread and its buffers are not held for ever
+            struct timeval idle = {h->idle_timeout_s, 0};
+            if (h->idle_timeout_s > 0) (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &idle, sizeof(idle));
             const uint64_t client = h->client_base + h->next_client.fetch_add(1);
             {
                 std::lock_guard<std::mutex> lk(h->mu);
@@ -775,6 +782,7 @@ int vodhip_http_create(vodhip_batcher_t* batcher, int64_t dim, vodhip_http_fallb
     h->fallback = fallback;
     h->user = user;
     if (max_body_bytes > 0) h->max_body = max_body_bytes;
+    if (const char* ev = getenv("VODHIP_HTTP_IDLE_TIMEOUT_S")) h->idle_timeout_s = std::max(0, atoi(ev));
     h->client_base = ((uint64_t)(uintptr_t)h) << 20;  // tags unique across fronts that share a batcher
     if (pipe(h->wake_pipe)) {
         delete h;
@@ -835,6 +843,15 @@ int vodhip_http_listen_unix(vodhip_http_t* h, const char* path) {
     memset(&sa, 0, sizeof(sa));
     sa.sun_family = AF_UNIX;
     strncpy(sa.sun_path, path, sizeof(sa.sun_path) - 1);
+    {   // a stale socket file of a dead server is removed; one a LIVE listener still answers on is somebody's server: refuse
+        const int probe = socket(AF_UNIX, SOCK_STREAM, 0);
+        const bool live = probe >= 0 && connect(probe, (struct sockaddr*)&sa, sizeof(sa)) == 0;
+        if (probe >= 0) close(probe);
+        if (live) {
+            close(fd);
+            return sfail("%s: a live server is listening on this socket", path);
+        }
+    }
     (void)unlink(path);
     if (bind(fd, (struct sockaddr*)&sa, sizeof(sa)) || listen(fd, 256)) {
         const int e = errno;
@@ -867,9 +884,14 @@ int vodhip_http_stop(vodhip_http_t* h) {
     h->unix_paths.clear();
     std::unique_lock<std::mutex> lk(h->mu);
     for (int fd : h->conn_fds) (void)shutdown(fd, SHUT_RDWR);  // unblocks the connection threads' recv()
-    // a thread inside a search (or inside the host's fallback) finishes its request first
-    h->cv.wait_for(lk, std::chrono::seconds(10), [&] { return h->n_conn_threads == 0; });
-    return h->n_conn_threads == 0 ? 0 : sfail("%d connection threads still running", h->n_conn_threads);
+    // A thread inside a search (or inside the host's fallback) finishes its request first.  No bound on this wait: the threads hold
+    // `h` and its batcher, and the caller destroys both right after - returning early left them running on freed memory (round-4
+    // advisor).  Every wait they can be in ends: recv() fails on the shut-down socket, a search completes, the fallback returns.
+    while (h->n_conn_threads != 0) {
+        h->cv.wait_for(lk, std::chrono::seconds(1), [&] { return h->n_conn_threads == 0; });
+        for (int fd : h->conn_fds) (void)shutdown(fd, SHUT_RDWR);
+    }
+    return 0;
 }
 
 int vodhip_http_destroy(vodhip_http_t* h) {

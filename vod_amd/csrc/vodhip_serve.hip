@@ -408,11 +408,12 @@ int submit(vodhip_batcher* b, Batch* bt) {
     Slot& s = *bt->slot;
     const size_t es = (size_t)elem_bytes(bt->q_dtype);
     const size_t row_bytes = (size_t)b->dim * es;
+    // the slot's device buffers must live on the INDEX's device: select it before the first allocation (a fresh thread starts on device 0)
+    if (b->kind != ENGINE_CALLBACK) SHIP(hipSetDevice(b->device));
     if (slot_reserve(b, s, (size_t)bt->nq * row_bytes, (size_t)bt->nq * bt->k, bt->subset ? (size_t)bt->nq * bt->n_subset : 0)) return -1;
     for (Request* r : bt->reqs) memcpy((char*)s.q_host + (size_t)r->row0 * row_bytes, r->q, (size_t)r->nq * row_bytes);
     if (bt->subset) memcpy(s.sub_host, bt->reqs[0]->subset, (size_t)bt->nq * bt->n_subset * sizeof(int32_t));
     if (b->kind == ENGINE_INDEX) {
-        SHIP(hipSetDevice(b->device));
         SHIP(hipMemcpyAsync(s.q_dev, s.q_host, (size_t)bt->nq * row_bytes, hipMemcpyHostToDevice, b->stream));
         if (bt->subset) {
             SHIP(hipMemcpyAsync(s.sub_dev, s.sub_host, (size_t)bt->nq * bt->n_subset * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
@@ -479,6 +480,7 @@ void complete_locked(vodhip_batcher* b, Batch* bt, tp_t now) {
 }
 
 void scheduler_main(vodhip_batcher* b) {
+    if (b->kind != ENGINE_CALLBACK) (void)hipSetDevice(b->device);  // this thread allocates the slots' buffers and enqueues the searches
     std::unique_lock<std::mutex> lk(b->mu);
     for (;;) {
         while (!b->stop && b->pending.empty()) b->cv_sched.wait(lk);
@@ -585,12 +587,21 @@ int vodhip_batcher_create(vodhip_index_t* index, vodhip_node_index_t* node, vodh
         hipPointerAttribute_t attr;
         if (vodhip_index_data(index, &data, &stride, &dt) == 0 && data && hipPointerGetAttributes(&attr, data) == hipSuccess) b->device = attr.device;
         (void)hipGetLastError();
+        int caller_device = -1;
+        if (hipGetDevice(&caller_device) != hipSuccess) caller_device = -1;
         hipError_t e = hipSetDevice(b->device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+        if (caller_device >= 0 && caller_device != b->device) (void)hipSetDevice(caller_device);  // the caller's current device is its own
         if (e != hipSuccess) {
             delete b;
             return sfail("creating the batcher's stream failed: %s", hipGetErrorString(e));
         }
+    }
+    if (node) {  // the node index merges on its first shard's device: the slots' pinned buffers are allocated with that device current
+        vodhip_index_t* sh = nullptr;
+        int64_t base = 0;
+        int dev0 = 0;
+        if (vodhip_node_index_shard(node, 0, &sh, &base, &dev0) == 0) b->device = dev0;
     }
     b->slots.resize(4);  // depth (<= 3) batches on the device + one being assembled / copied out
     b->t_idle_since = clock_t_::now();

@@ -35,7 +35,7 @@ class HipMipsFactoryConfig:
     uds: bool = False               # also serve on a Unix-domain socket and hand its path to the clients (single-host jobs)
     group_backend: str = "nccl"     # with `devices`: "nccl" / "gloo" = one worker process per GPU on a process group; "node" = ONE
                                     # server process drives every GPU (vodhip_node_index: the reference server's own shape)
-    http: str = "native"            # the server's HTTP shell: libvodhip's native front | "asyncio" | "uvicorn"
+    http: str = "native"            # the server's HTTP shell: libvodhip's native front | "uvicorn" (FastAPI fallback)
     # Request fusion is ON by default (the DataLoader workers of every trainer rank each send their own small batch:
     # src/vod_dataloaders/realm_dataloader.py:92-118): concurrent requests share corpus scans, a lone request never waits.
     micro_batch_wait_ms: float = 0.0  # > 0: every batch additionally waits this long for company (a fixed window; not needed)

@@ -22,7 +22,7 @@ import requests
 from vod_amd import io
 from vod_amd import types as vt
 from vod_amd.search import base
-from vod_amd.search.socket import find_available_port
+from vod_amd.search.socket import find_available_port, private_socket_dir
 
 
 class _UnixHTTPConnection(http.client.HTTPConnection):
@@ -384,7 +384,7 @@ class HipMipsClient(base.SearchClient):
         """One call into libvodhip's client.  (scores, indices), or None when the Python path should take this request: a layout the
         native client does not send, or a transport failure - which the Python path then meets (and reports) itself."""
         v = self._wire(vector)
-        if v.ndim != 2 or v.shape[0] < 1 or v.shape[1] < 1 or v.dtype not in (np.float32, np.float16) or not 1 <= int(top_k) <= 1 << 20:
+        if v.ndim != 2 or v.shape[0] < 1 or v.shape[1] < 1 or v.dtype not in (np.float32, np.float16) or not 1 <= int(top_k) <= 2048:  # VODHIP_MAX_K
             return None
         h = self._native_handle()
         if h is None:
@@ -454,7 +454,7 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         serve_on_gpu: bool = True,  # noqa: ARG002 - accepted for call-site compatibility: this engine only exists on the GPU
         group_backend: str = "nccl",  # with `devices`: "nccl" (RCCL, one GPU per worker), "gloo" (host-staged; workers may share a GPU) or "node" (ONE server process drives every GPU: vodhip_node_index, no workers)
         micro_batch_wait_ms: float = 0.0,  # > 0: every batch additionally waits this long for company (concurrent requests are fused by default)
-        http: str = "native",  # the server's HTTP shell: "native" (libvodhip's front, default), "asyncio" (in-tree Python) or "uvicorn" (FastAPI)
+        http: str = "native",  # the server's HTTP shell: "native" (libvodhip's front, default) or "uvicorn" (FastAPI fallback)
         batcher_params: None | dict[str, int] = None,  # vodhip_batcher_set_param on the server (max_queries, grace_us, grace_pct, flat_queries, depth)
         uds: bool | str = False,  # also listen on a Unix-domain socket (True = a path under the temp dir); `get_client()` then uses it
     ):
@@ -474,14 +474,12 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         self.http = http
         self.batcher_params = dict(batcher_params or {})
         if uds is True:
-            import tempfile
-
             # named after the PORT only: a rank built with `skip_setup=True` (it only connects) must derive the same path as the
-            # rank that spawned the server, whatever its pid
-            uds = os.path.join(tempfile.gettempdir(), f"vodhip-{self.port}.sock")
+            # rank that spawned the server, whatever its pid - inside a directory only THIS user can write to
+            uds = os.path.join(private_socket_dir(), f"vodhip-{self.port}.sock")
         self.uds = uds or None
         if self.uds and http == "uvicorn":
-            raise ValueError("`uds` needs the in-tree HTTP shells (http='native' | 'asyncio'): the uvicorn shell does not open the socket")
+            raise ValueError("`uds` needs http='native': the uvicorn shell does not open the socket")
 
     def _make_env(self) -> dict[str, str]:
         env = copy(dict(os.environ))

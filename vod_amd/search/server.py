@@ -72,8 +72,7 @@ class Endpoints:
     """Routes, validation and error mapping of the search service, independent of the HTTP shell around them.
 
     `handle(method, path, query, body)` -> (status, content type, payload bytes-like, extra headers).  Every shell - libvodhip's native
-    front (production: it answers the plain hot requests itself and hands everything else here), the asyncio server of
-    `vod_amd.search.fastserver` and the FastAPI app of `create_app` (ASGI hosting, tests) - answers with exactly what this returns, so
+    front (production: it answers the plain hot requests itself and hands everything else here) and the FastAPI app of `create_app` (ASGI hosting, tests) - answers with exactly what this returns, so
     the contract is the reference's whatever carries it:
       422 + `{"detail": [...]}` for a document that fails the pydantic model (`extra="forbid"`, wrong types: models.py:43-79),
       500 + `{"detail": <trace>}` for a failing search (server.py:89-91), 404 / 405 for unknown routes.
@@ -493,12 +492,12 @@ def parse_args(argv=None) -> argparse.Namespace:
                    help="comma-separated GPU ids: the store is row-sharded over them, one worker process per GPU on an RCCL "
                         "group, rank 0 answers HTTP (the reference's `--serve-on-gpu` = faiss index_cpu_to_all_gpus, server.py:51-54)")
     p.add_argument("--subset-ids-path", type=str, default=None, help=".npy with one subset id (string) per vector")
-    p.add_argument("--http", type=str, default="native", choices=["native", "asyncio", "uvicorn"],
-                   help="HTTP shell: libvodhip's native front (default: the hot routes never enter the interpreter), the in-tree asyncio "
-                        "server, or uvicorn + FastAPI")
-    p.add_argument("--http-workers", type=int, default=64, help="handler threads = requests that may be in flight at once")
-    p.add_argument("--max-body-mb", type=int, default=512, help="largest request body the native / asyncio shells accept (413 above it)")
-    p.add_argument("--uds", type=str, default=None, help="also serve on this Unix-domain socket path (native / asyncio shells; clients on the same host)")
+    p.add_argument("--http", type=str, default="native", choices=["native", "uvicorn"],
+                   help="HTTP shell: libvodhip's native front (default: the hot routes never enter the interpreter), or uvicorn + FastAPI "
+                        "(fallback: ASGI hosting; every route runs in the interpreter)")
+    p.add_argument("--http-workers", type=int, default=64, help="(unused by the native front: one native thread per connection; kept for command-line compatibility)")
+    p.add_argument("--max-body-mb", type=int, default=512, help="largest request body the native front accepts (413 above it)")
+    p.add_argument("--uds", type=str, default=None, help="also serve on this Unix-domain socket path (native front; clients on the same host)")
     p.add_argument("--micro-batch-wait-ms", type=float, default=0.0,
                    help="> 0: every batch additionally waits this long for company.  Not needed: concurrent requests are fused by default "
                         "(batch-while-busy, no fixed window: vodhip_batcher in include/vodhip.h)")
@@ -622,26 +621,22 @@ def _bounded(fn, seconds: float) -> None:
 
 
 def _serve(engine, args: argparse.Namespace, host: str) -> None:
-    """Run the HTTP shell around `engine` until SIGTERM: the asyncio server (default) or uvicorn + FastAPI (`--http uvicorn`)."""
+    """Run the HTTP shell around `engine` until SIGTERM: libvodhip's native front (default) or uvicorn + FastAPI (`--http uvicorn`, the
+    documented fallback: every route through the interpreter)."""
     if args.http == "uvicorn":
         import uvicorn
 
         if args.uds:
-            raise SystemExit("--uds needs --http native or --http asyncio (the uvicorn shell does not open the socket)")
+            raise SystemExit("--uds needs --http native (the uvicorn shell does not open the socket)")
         app = create_app(engine, micro_batch_wait_ms=args.micro_batch_wait_ms)
         _apply_batcher_params(app.state.endpoints, args)
         uvicorn.run(app, host=host, port=args.port, workers=1, log_level=args.logging_level.lower())
         return
     endpoints = Endpoints(engine, micro_batch_wait_ms=args.micro_batch_wait_ms)
     _apply_batcher_params(endpoints, args)
-    if args.http == "native":
-        from vod_amd.search import native
+    from vod_amd.search import native
 
-        native.run(endpoints, host, args.port, max_body=args.max_body_mb << 20, uds=args.uds)
-    else:
-        from vod_amd.search import fastserver
-
-        fastserver.run(endpoints, host, args.port, workers=args.http_workers, max_body=args.max_body_mb << 20, uds=args.uds)
+    native.run(endpoints, host, args.port, max_body=args.max_body_mb << 20, uds=args.uds)
 
 
 def _apply_batcher_params(endpoints, args: argparse.Namespace) -> None:

@@ -36,3 +36,31 @@ def find_available_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
         sock.bind(("localhost", 0))  # port 0: the OS picks a free one
         return sock.getsockname()[1]
+
+
+def private_socket_dir() -> str:
+    """A directory for Unix-domain sockets that only the current user can write to: `$XDG_RUNTIME_DIR` when it is set and ours,
+    otherwise `<tmpdir>/vodhip-<uid>` created 0700.  A socket in the shared temp dir itself could be pre-created (or removed) by
+    any other user of the host; here it cannot.  Deterministic per user, so ranks that only connect derive the same path."""
+    import os
+    import stat
+    import tempfile
+
+    uid = os.getuid()
+    xdg = os.environ.get("XDG_RUNTIME_DIR")
+    if xdg:
+        try:
+            st = os.stat(xdg)
+            if stat.S_ISDIR(st.st_mode) and st.st_uid == uid and not st.st_mode & 0o022 and os.access(xdg, os.W_OK):
+                return xdg
+        except OSError:
+            pass
+    path = os.path.join(tempfile.gettempdir(), f"vodhip-{uid}")
+    try:
+        os.mkdir(path, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(path)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != uid or st.st_mode & 0o077:
+        raise PermissionError(f"{path} exists but is not a private directory of uid {uid}: refusing to place a socket there")
+    return path
