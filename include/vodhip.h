@@ -31,6 +31,11 @@ extern "C" {
 
 /* element types of vectors handed to / stored by the library */
 enum { VODHIP_F16 = 0, VODHIP_BF16 = 1, VODHIP_F32 = 2 };
+/* OR-ed into the store dtype at create: the store ALSO keeps the float32 rows and every search returns what a float32 brute force
+ * over the unrounded rows and queries returns (H2 below) - the reference's own arithmetic: faiss IndexFlat holds float32
+ * (`index.add(vectors.astype(float32))`, src/vod_search/faiss_search/build.py:65-73; float32 queries, faiss_search/server.py:71,81).
+ * Costs 4 more bytes per element of HBM and ~1-3 % of search time. */
+#define VODHIP_EXACT_F32 0x100
 /* where a caller buffer lives */
 enum { VODHIP_HOST = 0, VODHIP_DEVICE = 1 };
 
@@ -47,7 +52,7 @@ int vodhip_version(void);
  * The store is a row-major [capacity, dim_padded] fp16/bf16 matrix in HBM on `device`
  * (dim padded with zeros to a multiple of 64).  Rows get ids 0,1,2,... in insertion order.
  * ------------------------------------------------------------------------------------------- */
-int vodhip_index_create(int device, int64_t dim, int store_dtype /* VODHIP_F16 | VODHIP_BF16 */,
+int vodhip_index_create(int device, int64_t dim, int store_dtype /* VODHIP_F16 | VODHIP_BF16, optionally | VODHIP_EXACT_F32 */,
                         int64_t capacity_rows, vodhip_index_t** out);
 int vodhip_index_destroy(vodhip_index_t* index);
 
@@ -69,6 +74,10 @@ int vodhip_index_data(const vodhip_index_t* index, void** dev_ptr, int64_t* row_
  * to `dst` in host or device memory; async on `stream` for device destinations. */
 int vodhip_index_get_rows(const vodhip_index_t* index, int64_t row_begin, int64_t n_rows, void* dst,
                           int dst_location, void* stream);
+/* VODHIP_EXACT_F32 stores only: the float32 plane (what faiss.write_index would persist, factory.py:167) - raw view, and rows
+ * [row_begin, row_begin + n_rows) unpadded [n_rows, dim] float32 into host or device memory.  -1 for a store without the plane. */
+int vodhip_index_data_f32(const vodhip_index_t* index, void** dev_ptr, int64_t* row_stride_elems);
+int vodhip_index_get_rows_f32(const vodhip_index_t* index, int64_t row_begin, int64_t n_rows, void* dst, int dst_location, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * H2  exact brute-force inner-product top-k over the store.
@@ -79,6 +88,14 @@ int vodhip_index_get_rows(const vodhip_index_t* index, int64_t row_begin, int64_
  * `id_base` is added to every valid id (row offset of this shard inside a sharded corpus,
  * the reference's `indices += offset` at src/vod_search/sharded_search.py:103,155 -- pads stay -1).
  * out_scores / out_ids are DEVICE pointers [nq, k].  1 <= k <= VODHIP_MAX_K.
+ *
+ * VODHIP_EXACT_F32 stores: the fp16 / bf16 scan is only the FILTER.  Scores are float32 dot products of the UNROUNDED query and row
+ * (one fixed summation order: the same bits from every path, batch and shard), the k best by (score desc, id asc) over ALL rows -
+ * guaranteed, not statistical: the scan's top-k' list (k' > k, param "exact_expand") is re-scored from the float32 plane, and the
+ * device checks per query that no row outside the list can reach the k-th re-scored score, using the bound
+ * |s - s~| <= |q - q~| max|x| + |q~| max|x - x~| (+ summation slack) with the norms of the actual data; a query that fails the check
+ * is searched again with every row inside that band as a candidate.  The queries must stay valid until finish, as
+ * always; q_dtype F32 is the point of the mode, F16 / BF16 queries are taken as exact values.
  *
  * vodhip_index_search        enqueue + wait + exactness check (if a query's candidate list overflowed, that query is
  *                            searched again with thresholds seeded from its incomplete result; the exhaustive
@@ -115,11 +132,14 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
  *   "force_safe" (1 = exhaustive schedule: dense chunks of <= cand_cap rows), "tile" (0 = auto; 1 = 128x128, 42 / 46 = small-batch
  *   rings, 8 / 9 = persistent 256x256 without / with the wave stagger), "small_chunk_tiles", "profile" (1 = HIP events around
  *   every filter launch), "ingest_threads" (CPU threads staging pageable host rows, 0 = auto), "kflags" (timing knobs of
- *   diagnostic builds).
+ *   diagnostic builds), "exact_expand" (x100, VODHIP_EXACT_F32 stores: the scan lists k' = k * exact_expand / 100 + 16 rows per
+ *   query; 0 = default: 125 for an fp16 store, 200 for bf16; speed only - results are exact for any value).
  * stats (of the search completed by the last vodhip_index_search_finish): "last_overflow" (a candidate list overflowed),
  *   "last_safe_reruns" (recovery passes run), "last_recovered_queries" (queries the first recovery pass re-searched),
  *   "last_chunks" (stages), "last_filter_launches", "last_filter_ns" (with "profile"), "last_recovery_launches",
- *   "last_recovery_ns" (the filter launches of the recovery passes, accounted separately). */
+ *   "last_recovery_ns" (the filter launches of the recovery passes, accounted separately); "exact" (1 for a VODHIP_EXACT_F32 store),
+ *   "last_exact_kx" (k' of the last search), "last_exact_band_queries" (queries whose list did not prove complete and ran a band
+ *   pass), "last_exact_band_passes". */
 int vodhip_index_set_param(vodhip_index_t* index, const char* key, int64_t value);
 /* Host-side planning only (no device and no HIP runtime call): the stage list a search of `nq` queries for the top `k` of
  * `ntotal` rows would run on a device with `n_cu` compute units (<= 0 = 256, the MI355X), with the given tunables (<= 0 =

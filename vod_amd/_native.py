@@ -14,6 +14,7 @@ _lock = threading.Lock()
 _lib: ctypes.CDLL | None = None
 
 F16, BF16, F32 = 0, 1, 2
+EXACT_F32 = 0x100  # VODHIP_EXACT_F32: OR-ed into the store dtype at create
 HOST, DEVICE = 0, 1
 MAX_K = 2048
 MAX_ENGINES = 4
@@ -48,6 +49,8 @@ SIGNATURES: dict[str, tuple] = {
     "vodhip_index_capacity": (_i32, [_vp, _c.POINTER(_i64)]),
     "vodhip_index_data": (_i32, [_vp, _c.POINTER(_vp), _c.POINTER(_i64), _c.POINTER(_i32)]),
     "vodhip_index_get_rows": (_i32, [_vp, _i64, _i64, _vp, _i32, _vp]),
+    "vodhip_index_data_f32": (_i32, [_vp, _c.POINTER(_vp), _c.POINTER(_i64)]),
+    "vodhip_index_get_rows_f32": (_i32, [_vp, _i64, _i64, _vp, _i32, _vp]),
     "vodhip_index_search": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]),
     "vodhip_index_search_async": (_i32, [_vp, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp]),
     "vodhip_index_search_finish": (_i32, [_vp, _vp]),

@@ -1,0 +1,307 @@
+// Exact-fp32 mode of the store (round 5): results equal a float32 brute force over the UNROUNDED inputs.
+//
+// The reference keeps and searches float32 (faiss IndexFlat filled by `index.add(vectors.astype(float32))`,
+// /root/reference/src/vod_search/faiss_search/build.py:65-73; `faiss_index.search(float32 queries, k)`, server.py:71-72,81-84; the
+// vectors on disk are `<f4`, src/vod_tools/ts_factory/ts_factory.py:71-76).  The MFMA scan of this library works on fp16 / bf16
+// copies; with VODHIP_EXACT_F32 the store keeps the float32 rows in a second plane and the scan becomes a FILTER with a rigorous
+// error bound:
+//
+//   s(q, x)   = the float32 dot product of the unrounded query and row, summed in the fixed order of `exact_dot` below - the
+//               score this mode returns, whatever path, shard or batch computed it;
+//   s~(q, x)  = what the scan computes: fp32-accumulated products of the ROUNDED query q~ and row x~;
+//   |s - s~| <= eps_q = |q - q~| max|x| + |q~| max|x - x~| + (accumulation slack)       (Cauchy-Schwarz, norms taken from the
+//               actual data: the row maxima are tracked at ingest, the query norms computed per query).
+//
+//   1. the scan returns its top-k' list by s~ (k' > k: `exact_kx`), rows gathered from the float32 plane are re-scored, the k
+//      best by (s desc, id asc) leave;
+//   2. a row outside the list has s~ <= s~_(k'), hence s <= s~_(k') + eps_q: if that is below the k-th re-scored score the
+//      result is complete - checked per query ON THE DEVICE;
+//   3. a query that fails the check is searched again as a BAND pass: every row with s~ >= s_(k) - eps_q (s_(k) = the k-th
+//      re-scored score, a lower bound of the true k-th best) is a candidate and is re-scored - complete by construction;
+//      candidate lists that overflow split the pass into more stages, down to dense chunks that cannot overflow.
+//
+// One kernel does the re-scoring in both shapes (a top-k' list / a stage's candidate list folded into a running top-k).
+#include <algorithm>
+
+#include "mips_common.h"
+
+namespace vodhip {
+
+namespace {
+
+// every lane ends with the same value: the pairs of a butterfly step add the same two numbers, and the step order is fixed
+__device__ __forceinline__ float wave_sum_fixed(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// THE score function of exact mode: lane l accumulates columns 4l .. 4l+3 (mod 256) in increasing column order with one fma chain
+// per component, the four chains are added as (0 + 1) + (2 + 3), the 64 lane sums by the butterfly above.  Zero padded columns add
+// exact zeros, so the value depends on the row and the query alone.  NC rows at once: their loads are in flight together.
+template <int NC>
+__device__ __forceinline__ void exact_dot(const float* __restrict__ plane, int64_t stride, const int (&rows)[NC], const float* qs,
+                                          int dim_pad, int lane, float (&out)[NC]) {
+    float acc[NC][4];
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.f;
+    for (int c = lane * 4; c < dim_pad; c += 256) {
+        const float4 qv = *reinterpret_cast<const float4*>(qs + c);
+        float4 xv[NC];
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+            xv[n] = rows[n] >= 0 ? *reinterpret_cast<const float4*>(plane + (size_t)rows[n] * stride + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            acc[n][0] = __builtin_fmaf(xv[n].x, qv.x, acc[n][0]);
+            acc[n][1] = __builtin_fmaf(xv[n].y, qv.y, acc[n][1]);
+            acc[n][2] = __builtin_fmaf(xv[n].z, qv.z, acc[n][2]);
+            acc[n][3] = __builtin_fmaf(xv[n].w, qv.w, acc[n][3]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NC; ++n) out[n] = wave_sum_fixed((acc[n][0] + acc[n][1]) + (acc[n][2] + acc[n][3]));
+}
+
+__device__ __forceinline__ float round_to_store(float f, int store_dtype) {
+    if (store_dtype == 0) return (float)(_Float16)f;
+    return (float)(__bf16)f;
+}
+
+// descending bitonic sort of P (power of two, >= 2) keys in LDS by 256 threads
+__device__ __forceinline__ void sort_desc_lds(key_t64* keys, int P, int tid) {
+    const int half = P >> 1;
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < half; t += 256) {
+                const int pos = 2 * t - (t & (stride - 1));
+                const key_t64 a = keys[pos], b = keys[pos + stride];
+                const bool desc = (pos & size) == 0;
+                if ((a < b) == desc) {
+                    keys[pos] = b;
+                    keys[pos + stride] = a;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+}  // namespace
+
+// ---- ingest ---------------------------------------------------------------------------------------------------------------
+// One wavefront per row: the float32 plane, the fp16 / bf16 plane (round-to-nearest-even) and the two row statistics the error
+// bound needs - max |x|^2 and max |x - x~|^2 over the rows ever added (bit patterns of non-negative floats order like integers:
+// atomicMax on the words).  Rows with a non-finite norm do not move the maxima (their scores are inf / NaN in any arithmetic).
+template <int SRC, int DST>
+__global__ __launch_bounds__(256) void ingest_exact_kernel(const void* __restrict__ src, int64_t n_rows, int64_t dim,
+                                                           uint16_t* __restrict__ dst16, float* __restrict__ dst32, int64_t stride,
+                                                           unsigned int* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    float n2 = 0.f, d2 = 0.f;
+    for (int64_t c0 = (int64_t)lane * 8; c0 < stride; c0 += 512) {
+        uint16_t h[8];
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t c = c0 + e;
+            float v = 0.f;
+            if (c < dim) {
+                if constexpr (SRC == 2) v = ((const float*)src)[row * dim + c];
+                else if constexpr (SRC == 0) v = (float)(((const _Float16*)src)[row * dim + c]);
+                else v = (float)(((const __bf16*)src)[row * dim + c]);
+            }
+            f[e] = v;
+            float r;
+            if constexpr (DST == 0) {
+                const _Float16 hv = (_Float16)v;
+                h[e] = __builtin_bit_cast(uint16_t, hv);
+                r = (float)hv;
+            } else {
+                const __bf16 hv = (__bf16)v;
+                h[e] = __builtin_bit_cast(uint16_t, hv);
+                r = (float)hv;
+            }
+            n2 = __builtin_fmaf(v, v, n2);
+            d2 = __builtin_fmaf(v - r, v - r, d2);
+        }
+        *reinterpret_cast<uint4*>(dst16 + row * stride + c0) = *reinterpret_cast<const uint4*>(h);
+        *reinterpret_cast<float4*>(dst32 + row * stride + c0) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(dst32 + row * stride + c0 + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    }
+    n2 = wave_sum_fixed(n2);
+    d2 = wave_sum_fixed(d2);
+    if (lane == 0 && n2 < __builtin_inff()) {  // (false for NaN too)
+        atomicMax(stats + 0, __float_as_uint(n2));
+        if (d2 < __builtin_inff()) atomicMax(stats + 1, __float_as_uint(d2));
+    }
+}
+
+hipError_t launch_ingest_exact(const void* src, int src_dtype, int64_t n_rows, int64_t dim, void* dst16, int dst_dtype, float* dst32,
+                               int64_t stride, unsigned int* stats, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n_rows + 3) / 4);
+#define VOD_ING(S, D)                                                                                                          \
+    if (src_dtype == S && dst_dtype == D) {                                                                                    \
+        hipLaunchKernelGGL((ingest_exact_kernel<S, D>), dim3(blocks), dim3(256), 0, stream, src, n_rows, dim, (uint16_t*)dst16, \
+                           dst32, stride, stats);                                                                              \
+        return hipGetLastError();                                                                                              \
+    }
+    VOD_ING(0, 0) VOD_ING(1, 0) VOD_ING(2, 0) VOD_ING(0, 1) VOD_ING(1, 1) VOD_ING(2, 1)
+#undef VOD_ING
+    return hipErrorInvalidValue;
+}
+
+// ---- re-scoring -----------------------------------------------------------------------------------------------------------
+// One workgroup per query.  LDS: the float32 query [dim_pad] + P keys.
+//   LIST  candidates = the scan's top-kx list (list_s / list_i rows of the caller's batch); output = the k best by (s, id), the
+//         per-query bound eps, and the completeness flag (2. above).
+//   CAND  candidates = this stage's candidate list of the BAND pass (cand / cnt, or a dense chunk of dense_n slots); they are
+//         folded into the running exact top-k kept in the caller's output rows (EXACT_FIRST: the rows are taken as empty); the
+//         scan threshold of the next stages rises to (k-th exact score - eps) when that is higher; a list that lost
+//         candidates flags the query (the host splits the pass).
+__global__ __launch_bounds__(256) void exact_rescore_kernel(ExactArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* qs = reinterpret_cast<float*>(smem);
+    key_t64* kb = reinterpret_cast<key_t64*>(smem + (size_t)a.dim_pad * sizeof(float));
+    __shared__ float red[8];
+    const int r = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t qo = a.q_map ? (int64_t)a.q_map[r] : (int64_t)r;
+    const bool cand_mode = (a.mode & EXACT_CAND) != 0;
+    const bool first = (a.mode & EXACT_FIRST) != 0;
+    const int k = a.k;
+
+    // 1. the query, unrounded, and the two norms of the bound
+    float n2 = 0.f, d2 = 0.f;
+    for (int c = tid; c < a.dim_pad; c += 256) {
+        float f = 0.f;
+        if (c < a.dim) {
+            if (a.q_dtype == 2) f = ((const float*)a.q_src)[qo * a.dim + c];
+            else if (a.q_dtype == 0) f = (float)(((const _Float16*)a.q_src)[qo * a.dim + c]);
+            else f = (float)(((const __bf16*)a.q_src)[qo * a.dim + c]);
+        }
+        const float fr = round_to_store(f, a.store_dtype);
+        qs[c] = f;
+        n2 = __builtin_fmaf(fr, fr, n2);
+        d2 = __builtin_fmaf(f - fr, f - fr, d2);
+    }
+    n2 = wave_sum_fixed(n2);
+    d2 = wave_sum_fixed(d2);
+    if (lane == 0) {
+        red[wave] = n2;
+        red[4 + wave] = d2;
+    }
+    __syncthreads();
+    n2 = (red[0] + red[1]) + (red[2] + red[3]);
+    d2 = (red[4] + red[5]) + (red[6] + red[7]);
+    // |s - s~| <= |q - q~| |x| + |q~| |x - x~|, plus the rounding of the two fp32 summations (each below dim_pad * 2^-23 * |q| |x|
+    // whatever the order), everything inflated by 2^-9 for the float arithmetic of the norms themselves
+    const float xn = __builtin_sqrtf(__uint_as_float(a.stats[0])), dxn = __builtin_sqrtf(__uint_as_float(a.stats[1]));
+    const float qn = __builtin_sqrtf(n2), dqn = __builtin_sqrtf(d2);
+    const float eps = (dqn * xn + qn * dxn + 2.f * (float)a.dim_pad * 1.1920929e-7f * (qn + dqn) * xn) * 1.002f;
+
+    // 2. candidates, P - KR at a time behind the running top-k (KR slots)
+    const int KR = cand_mode ? a.kr : 0;
+    if (cand_mode)
+        for (int c = tid; c < KR; c += 256) {
+            key_t64 key = 0ull;
+            if (!first && c < k) {
+                const int64_t id = a.out_ids[qo * k + c];
+                if (id >= 0) key = make_key(a.out_scores[qo * k + c], (unsigned)(id - a.id_base));
+            }
+            kb[c] = key;
+        }
+    int n_total;
+    bool lost = false;
+    if (cand_mode) {
+        unsigned n = a.dense_n >= 0 ? (unsigned)a.dense_n : a.cnt[(size_t)r * CNT_STRIDE];
+        if (n > (unsigned)a.cap) {
+            lost = true;
+            n = (unsigned)a.cap;
+        }
+        n_total = (int)n;
+    } else {
+        n_total = a.kx;
+    }
+    const int CH = a.P - KR;
+    int done = 0;
+    do {
+        const int take = min(CH, n_total - done);
+        for (int j0 = wave * 4; j0 < take; j0 += 16) {
+            int rows[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int j = j0 + n;
+                int row = -1;
+                if (j < take) {
+                    if (cand_mode) {
+                        const key_t64 key = a.cand[(size_t)r * a.cap + done + j];
+                        if (key != 0ull) row = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+                    } else {
+                        const int64_t id = a.list_i[qo * a.kx + done + j];
+                        if (id >= 0) row = (int)id;
+                    }
+                }
+                rows[n] = __builtin_amdgcn_readfirstlane(row);
+            }
+            float s[4];
+            exact_dot<4>(a.plane, a.stride, rows, qs, a.dim_pad, lane, s);
+            if (lane == 0) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (j0 + n < take) kb[KR + j0 + n] = (rows[n] >= 0 && s[n] == s[n]) ? make_key(s[n], (unsigned)rows[n]) : 0ull;  // NaN never enters
+            }
+        }
+        int P_eff = 2;
+        while (P_eff < KR + take) P_eff <<= 1;
+        for (int c = KR + take + tid; c < P_eff; c += 256) kb[c] = 0ull;
+        sort_desc_lds(kb, P_eff, tid);  // (starts and ends with a barrier)
+        done += take;
+    } while (done < n_total);
+
+    // 3. results
+    const key_t64 kth = kb[k - 1];  // (k <= KR in CAND mode, k <= kx <= P in LIST mode; slots behind the candidates are zero)
+    const float s_k = kth ? unflip_f32((unsigned)(kth >> 32)) : -__builtin_inff();
+    for (int c = tid; c < k; c += 256) {
+        const key_t64 key = kb[c];
+        a.out_scores[qo * k + c] = key ? unflip_f32((unsigned)(key >> 32)) : -__builtin_inff();
+        a.out_ids[qo * k + c] = key ? a.id_base + (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : -1;
+    }
+    if (tid == 0) {
+        if (cand_mode) {
+            if (kth) {  // every row of the true top-k has s >= s_k, hence s~ >= s_k - eps
+                const float t = s_k - eps;
+                if (t > a.thr_s[r]) {
+                    a.thr_s[r] = t;
+                    a.thr_key[r] = (key_t64)flip_f32(t) << 32;  // low word 0: every row with s~ == t still passes `key > thr_key`
+                }
+            }
+            a.cnt[(size_t)r * CNT_STRIDE] = 0;
+            if (lost) {
+                atomicOr(a.flag_word, 1u);
+                if (a.flag_q) a.flag_q[r] = 1u;
+            }
+        } else {
+            a.eps[qo] = eps;
+            // rows outside the list have s~ <= the list's last s~, i.e. s <= that + eps
+            const bool full = a.list_i[qo * a.kx + a.kx - 1] >= 0;
+            const bool complete = !full || (a.list_s[qo * a.kx + a.kx - 1] + eps < s_k);
+            a.flag_q[qo] = complete ? 0u : 1u;
+            if (!complete) atomicOr(a.flag_word, 1u);
+        }
+    }
+}
+
+hipError_t launch_exact_rescore(const ExactArgs& a, int64_t nq, hipStream_t stream) {
+    if (nq <= 0) return hipSuccess;
+    const int bytes = (int)((size_t)a.dim_pad * sizeof(float) + (size_t)a.P * sizeof(key_t64));
+    if (hipError_t e = allow_dynamic_lds((const void*)exact_rescore_kernel, bytes); e != hipSuccess) return e;
+    hipLaunchKernelGGL(exact_rescore_kernel, dim3((unsigned)nq), dim3(256), bytes, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace vodhip

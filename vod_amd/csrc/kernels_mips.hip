@@ -1035,7 +1035,7 @@ __global__ void mips_prepare_kernel(const void* __restrict__ q_src, int q_dtype,
                                     float* __restrict__ thr_s, key_t64* __restrict__ thr_key,
                                     unsigned int* __restrict__ overflow, unsigned int* __restrict__ ovf_q, int clear_overflow,
                                     const float* __restrict__ seed_scores, const int64_t* __restrict__ seed_ids, int k,
-                                    const int* __restrict__ q_map) {
+                                    const int* __restrict__ q_map, const float* __restrict__ seed_margin) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t chunks_per_row = dim_pad / 8;
     if (i < nq_pad * chunks_per_row) {
@@ -1072,7 +1072,8 @@ __global__ void mips_prepare_kernel(const void* __restrict__ q_src, int q_dtype,
         const int64_t srow = (q_map && i < nq) ? (int64_t)q_map[i] : i;
         if (ovf_q != nullptr && i < nq) ovf_q[i] = 0u;
         if (seed_scores != nullptr && i < nq && seed_ids[srow * k + (k - 1)] >= 0) {
-            const float s = seed_scores[srow * k + (k - 1)];
+            float s = seed_scores[srow * k + (k - 1)];
+            if (seed_margin != nullptr) s -= seed_margin[srow];
             if (s == s) {
                 ts = s;
                 tk = (key_t64)flip_f32(s) << 32;  // low word 0: every row with this score still passes `key > thr_key`
@@ -1086,14 +1087,15 @@ __global__ void mips_prepare_kernel(const void* __restrict__ q_src, int q_dtype,
 
 hipError_t launch_search_prepare(const SearchWorkspace& ws, const void* q_src, int q_dtype, int64_t nq, int64_t dim,
                                  int store_dtype, int64_t nq_pad, int64_t dim_pad, bool clear_overflow,
-                                 const float* seed_scores, const int64_t* seed_ids, int k, const int* q_map, hipStream_t stream) {
+                                 const float* seed_scores, const int64_t* seed_ids, int k, const int* q_map, hipStream_t stream,
+                                 const float* seed_margin) {
     const int64_t n_topk = nq_pad * ws.kp;
     const int64_t n = std::max(n_topk, nq_pad * (dim_pad / 8));
     const int threads = 256;
     const unsigned blocks = (unsigned)((n + threads - 1) / threads);
     hipLaunchKernelGGL(mips_prepare_kernel, dim3(blocks), dim3(threads), 0, stream, q_src, q_dtype, nq, dim,
                        (uint16_t*)ws.q_pad, store_dtype, nq_pad, dim_pad, ws.topk, n_topk, ws.cnt, ws.thr_s, ws.thr_key,
-                       ws.overflow, ws.ovf_q, clear_overflow ? 1 : 0, seed_scores, seed_ids, k, q_map);
+                       ws.overflow, ws.ovf_q, clear_overflow ? 1 : 0, seed_scores, seed_ids, k, q_map, seed_margin);
     return hipGetLastError();
 }
 

@@ -68,6 +68,8 @@ struct PendingSearch {
     const int* q_map = nullptr;    // recovery of a few queries: workspace row -> row of the caller's batch (device)
     int slot = 0;                  // overflow-flag word / completion event of this search
     size_t ev_begin = 0, ev_end = 0;  // profile events of this search in ev_pool
+    int kx = 0;                    // exact mode: the scan's list length k' (> k; 0 = not an exact-mode search)
+    bool band = false;             // exact mode: a BAND pass - candidates are re-scored into the caller's rows (kernels_exact.hip)
 };
 
 constexpr int MAX_IN_FLIGHT = 4;  // searches that may be enqueued before the oldest is finished
@@ -91,6 +93,19 @@ struct vodhip_index {
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     int64_t ingest_threads = 0;  // CPU threads that fill the pinned staging slots (0 = auto: min(8, hardware threads))
     int64_t last_ingest_pinned_src = 0;
+    // VODHIP_EXACT_F32 (kernels_exact.hip): the float32 rows, the statistics of the error bound, per-slot lists of the scan
+    bool exact = false;
+    float* data32 = nullptr;                 // [capacity + 1][dim_pad]
+    unsigned int* norm_stats = nullptr;      // device [2]: bit patterns of max |x|^2, max |x - x~|^2
+    float* x_list_s[4] = {nullptr, nullptr, nullptr, nullptr};     // per in-flight slot: the scan's top-k' list [nq][k']
+    int64_t* x_list_i[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t x_list_cap[4] = {0, 0, 0, 0};     // elements
+    float* x_eps = nullptr;                  // device [MAX_IN_FLIGHT][OVF_ROWS]: the per-query bound of a slot's search
+    unsigned int* x_flag_q = nullptr;        // device [MAX_IN_FLIGHT][OVF_ROWS]: the queries whose list did not prove complete
+    unsigned int* x_flag_word = nullptr;     // device [MAX_IN_FLIGHT]
+    unsigned int* x_flag_host = nullptr;     // pinned [MAX_IN_FLIGHT]
+    int64_t exact_expand_x100 = 0;           // k' = k * this / 100 (+ 16); 0 = by store dtype (fp16: 125, bf16: 200)
+    int64_t last_exact_kx = 0, last_exact_band_queries = 0, last_exact_band_passes = 0;
     SearchWorkspace ws;
     unsigned int* overflow_host = nullptr;  // pinned, one word per in-flight slot
     unsigned int* ovf_q = nullptr;          // device [MAX_IN_FLIGHT][OVF_ROWS]: which queries of a slot's search overflowed
@@ -317,9 +332,10 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
         const int* q_map = ps.q_map ? ps.q_map + qb : nullptr;
         const int64_t row0 = ps.q_map ? 0 : qb;
         ix->ws.ovf_q = track_ovf ? ix->ovf_q + (size_t)ps.slot * OVF_ROWS + qb : nullptr;
+        const float* margin = ps.band ? ix->x_eps + (size_t)ps.slot * OVF_ROWS + row0 : nullptr;  // BAND pass: seeded k-th exact score - eps
         HIP_OK(launch_search_prepare(ws, (const char*)ps.queries + (size_t)row0 * ix->dim * q_es, ps.q_dtype, nq, ix->dim,
                                      ix->dtype, nq_pad, ix->dim_pad, qb == 0, recovery > 0 ? ps.out_scores + row0 * k : nullptr,
-                                     recovery > 0 ? ps.out_ids + row0 * k : nullptr, k, q_map, stream));
+                                     recovery > 0 ? ps.out_ids + row0 * k : nullptr, k, q_map, stream, margin));
         ix->ws.extra.q_label = ps.q_label ? ps.q_label + (size_t)row0 * ps.n_qlab : nullptr;
         ix->ws.extra.q_map = q_map;
         for (size_t c = 0; c < stages.size(); ++c) {
@@ -364,6 +380,35 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
                 dense_n = sg.n_groups;
                 flags |= 2;
             }
+            if (ps.band) {  // exact mode: the stage's candidates are re-scored from the float32 plane into the caller's rows
+                ExactArgs xa;
+                xa.plane = ix->data32;
+                xa.stride = ix->dim_pad;
+                xa.dim = (int)ix->dim;
+                xa.dim_pad = (int)ix->dim_pad;
+                xa.q_src = (const char*)ps.queries + (size_t)row0 * ix->dim * q_es;
+                xa.q_dtype = ps.q_dtype;
+                xa.q_map = q_map;
+                xa.store_dtype = ix->dtype;
+                xa.stats = ix->norm_stats;
+                xa.mode = EXACT_CAND | (c == 0 ? EXACT_FIRST : 0);
+                xa.cand = ws.cand;
+                xa.cnt = ws.cnt;
+                xa.cap = (int)ws.cap;
+                xa.dense_n = sg.kind == ST_DENSE ? (int)(sg.e - sg.b) : -1;
+                xa.thr_s = ws.thr_s;
+                xa.thr_key = ws.thr_key;
+                xa.kr = 2;
+                while (xa.kr < k) xa.kr <<= 1;
+                xa.P = std::max(2 * xa.kr, 1024);
+                xa.k = k;
+                xa.id_base = ps.id_base;
+                xa.out_scores = ps.out_scores + row0 * k;
+                xa.out_ids = ps.out_ids + row0 * k;
+                xa.flag_word = ws.overflow;
+                HIP_OK(launch_exact_rescore(xa, nq, stream));
+                continue;
+            }
             HIP_OK(launch_select(ws, nq, k, dense_n, flags, stream, ps.id_base, ps.out_scores + row0 * k, ps.out_ids + row0 * k, q_map));
         }
         if (stages.empty())  // empty index: nothing was selected, the cleared top-k leaves as pads
@@ -381,6 +426,71 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, int rec
     return rc;
 }
 
+// ---- exact mode (kernels_exact.hip) ----------------------------------------------------------------------------------------
+// the scan's list length k' for the caller's k: enough rows that the list usually PROVES itself complete (rows within eps of the
+// k-th score: ~5 % more than k for an fp16 store of N(0, 1) x 768 rows, ~70 % more for bf16 x 1024 - profiles/r05_exact_*.json);
+// a query whose list does not is searched again as a band pass, so this is a speed knob, never a correctness one
+int exact_kx(const vodhip_index* ix, int k) {
+    const int64_t x100 = ix->exact_expand_x100 > 0 ? ix->exact_expand_x100 : (ix->dtype == VODHIP_F16 ? 125 : 200);
+    const int64_t kx = ((int64_t)k * x100 + 99) / 100 + 16;
+    return (int)std::min<int64_t>(VODHIP_MAX_K, std::max<int64_t>(kx, k));
+}
+
+// the scan behind an exact-mode search: same queries, k' results into the slot's list buffers, LOCAL ids
+PendingSearch exact_inner(const vodhip_index* ix, const PendingSearch& ps) {
+    PendingSearch in = ps;
+    in.k = ps.kx;
+    in.kx = 0;
+    in.id_base = 0;
+    in.out_scores = ix->x_list_s[ps.slot];
+    in.out_ids = ix->x_list_i[ps.slot];
+    return in;
+}
+
+// re-score the list of every query of `ps` (LIST mode), then fetch the "some query is incomplete" word and re-arm the slot's event
+int enqueue_exact_list(vodhip_index* ix, const PendingSearch& ps, hipStream_t stream) {
+    ExactArgs xa;
+    xa.plane = ix->data32;
+    xa.stride = ix->dim_pad;
+    xa.dim = (int)ix->dim;
+    xa.dim_pad = (int)ix->dim_pad;
+    xa.q_src = ps.queries;
+    xa.q_dtype = ps.q_dtype;
+    xa.store_dtype = ix->dtype;
+    xa.stats = ix->norm_stats;
+    xa.mode = EXACT_LIST;
+    xa.list_s = ix->x_list_s[ps.slot];
+    xa.list_i = ix->x_list_i[ps.slot];
+    xa.kx = ps.kx;
+    xa.P = 2;
+    while (xa.P < ps.kx) xa.P <<= 1;
+    xa.k = ps.k;
+    xa.id_base = ps.id_base;
+    xa.out_scores = ps.out_scores;
+    xa.out_ids = ps.out_ids;
+    xa.eps = ix->x_eps + (size_t)ps.slot * OVF_ROWS;
+    xa.flag_word = ix->x_flag_word + ps.slot;
+    xa.flag_q = ix->x_flag_q + (size_t)ps.slot * OVF_ROWS;
+    HIP_OK(hipMemsetAsync(ix->x_flag_word + ps.slot, 0, sizeof(unsigned int), stream));
+    HIP_OK(launch_exact_rescore(xa, ps.nq, stream));
+    HIP_OK(hipMemcpyAsync(ix->x_flag_host + ps.slot, ix->x_flag_word + ps.slot, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipEventRecord(ix->done[ps.slot], stream));
+    return 0;
+}
+
+int exact_reserve_lists(vodhip_index* ix, int slot, size_t elems) {
+    if (ix->x_list_cap[slot] >= elems) return 0;
+    (void)hipFree(ix->x_list_s[slot]);
+    (void)hipFree(ix->x_list_i[slot]);
+    ix->x_list_s[slot] = nullptr;
+    ix->x_list_i[slot] = nullptr;
+    ix->x_list_cap[slot] = 0;
+    HIP_OK(hipMalloc((void**)&ix->x_list_s[slot], elems * sizeof(float)));
+    HIP_OK(hipMalloc((void**)&ix->x_list_i[slot], elems * sizeof(int64_t)));
+    ix->x_list_cap[slot] = elems;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -391,7 +501,10 @@ int vodhip_version(void) { return VODHIP_VERSION; }
 int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capacity_rows, vodhip_index_t** out) {
     if (!out) return fail("out is NULL");
     if (dim <= 0 || capacity_rows < 0) return fail("invalid dim=%lld / capacity=%lld", (long long)dim, (long long)capacity_rows);
-    if (store_dtype != VODHIP_F16 && store_dtype != VODHIP_BF16) return fail("store dtype must be F16 or BF16");
+    const bool exact = (store_dtype & VODHIP_EXACT_F32) != 0;
+    store_dtype &= ~VODHIP_EXACT_F32;
+    if (store_dtype != VODHIP_F16 && store_dtype != VODHIP_BF16) return fail("store dtype must be F16 or BF16 (optionally | VODHIP_EXACT_F32)");
+    if (exact && (dim + 63) / 64 * 64 > 16384) return fail("VODHIP_EXACT_F32 stores take dim <= 16384");
     if (capacity_rows >= (1ll << 31) - 2 * ROW_ALIGN) return fail("capacity must be < 2^31 rows per device");
     HIP_OK(hipSetDevice(device));
     vodhip_index* ix = new vodhip_index();
@@ -401,6 +514,7 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
     ix->capacity = capacity_rows;
     ix->capacity_pad = round_up(capacity_rows, ROW_ALIGN) + 2 * ROW_ALIGN;  // the last tile (up to 384 rows from a 256-aligned start) never reads past the allocation
     ix->dtype = store_dtype;
+    ix->exact = exact;
     if (hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ix->n_cu < 1) ix->n_cu = 256;
     ix->ws.n_cu = ix->n_cu;
     const size_t bytes = (size_t)ix->capacity_pad * ix->dim_pad * 2;
@@ -417,8 +531,33 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
     if (e == hipSuccess) e = hipMalloc((void**)&ix->q_map, MAX_IN_FLIGHT * OVF_ROWS * sizeof(int));
     if (e == hipSuccess) e = hipHostMalloc((void**)&ix->overflow_host, MAX_IN_FLIGHT * sizeof(unsigned int), hipHostMallocDefault);
     for (int i = 0; i < MAX_IN_FLIGHT && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ix->done[i], hipEventDisableTiming);
+    if (exact && e == hipSuccess) {
+        // the float32 plane (rows are written whole, zero padded columns included: no fill needed) + the bound's bookkeeping
+        const size_t bytes32 = ((size_t)capacity_rows + 1) * ix->dim_pad * sizeof(float);
+        e = hipMalloc((void**)&ix->data32, bytes32);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(ix->data);
+            (void)hipFree(ix->ovf_q);
+            (void)hipFree(ix->q_map);
+            (void)hipHostFree(ix->overflow_host);
+            delete ix;
+            return fail("hipMalloc of the %zu-byte float32 plane (VODHIP_EXACT_F32) failed: %s", bytes32, hipGetErrorString(e));
+        }
+        if (e == hipSuccess) e = hipMalloc((void**)&ix->norm_stats, 2 * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMemset(ix->norm_stats, 0, 2 * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMalloc((void**)&ix->x_eps, MAX_IN_FLIGHT * OVF_ROWS * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&ix->x_flag_q, MAX_IN_FLIGHT * OVF_ROWS * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMalloc((void**)&ix->x_flag_word, MAX_IN_FLIGHT * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipHostMalloc((void**)&ix->x_flag_host, MAX_IN_FLIGHT * sizeof(unsigned int), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess)
+            for (int i = 0; i < MAX_IN_FLIGHT; ++i) ix->x_flag_host[i] = 0;
+    }
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         (void)hipFree(ix->data);
+        (void)hipFree(ix->data32);
         delete ix;
         return fail("store initialisation failed: %s", hipGetErrorString(e));
     }
@@ -441,6 +580,16 @@ int vodhip_index_destroy(vodhip_index_t* ix) {
         (void)hipHostFree(ix->stage_pin[b]);
         if (ix->stage_done[b]) (void)hipEventDestroy(ix->stage_done[b]);
     }
+    (void)hipFree(ix->data32);
+    (void)hipFree(ix->norm_stats);
+    (void)hipFree(ix->x_eps);
+    (void)hipFree(ix->x_flag_q);
+    (void)hipFree(ix->x_flag_word);
+    (void)hipHostFree(ix->x_flag_host);
+    for (int i = 0; i < MAX_IN_FLIGHT; ++i) {
+        (void)hipFree(ix->x_list_s[i]);
+        (void)hipFree(ix->x_list_i[i]);
+    }
     (void)hipFree(ix->row_label);
     (void)hipFree(ix->ovf_q);
     (void)hipFree(ix->q_map);
@@ -459,9 +608,15 @@ int vodhip_index_add(vodhip_index_t* ix, const void* rows, int64_t n_rows, int s
     hipStream_t stream = (hipStream_t)stream_;
     HIP_OK(hipSetDevice(ix->device));
     const int es = elem_size(src_dtype);
+    // one launch per slice: the rounded plane, and for VODHIP_EXACT_F32 stores also the float32 plane + the row statistics
+    auto ingest = [&](const void* dev_src, int64_t n, int64_t first_row) -> hipError_t {
+        if (ix->exact)
+            return launch_ingest_exact(dev_src, src_dtype, n, ix->dim, ix->data + (size_t)first_row * ix->dim_pad, ix->dtype,
+                                       ix->data32 + (size_t)first_row * ix->dim_pad, ix->dim_pad, ix->norm_stats, stream);
+        return launch_convert_rows(dev_src, src_dtype, n, ix->dim, ix->data + (size_t)first_row * ix->dim_pad, ix->dtype, ix->dim_pad, stream);
+    };
     if (src_location == VODHIP_DEVICE) {
-        HIP_OK(launch_convert_rows(rows, src_dtype, n_rows, ix->dim, ix->data + (size_t)ix->ntotal * ix->dim_pad, ix->dtype,
-                                   ix->dim_pad, stream));
+        HIP_OK(ingest(rows, n_rows, ix->ntotal));
         ix->ntotal += n_rows;
         return 0;
     }
@@ -511,8 +666,7 @@ int vodhip_index_add(vodhip_index_t* ix, const void* rows, int64_t n_rows, int s
             dma_src = dst;
         }
         HIP_OK(hipMemcpyAsync(ix->stage_dev[slot], dma_src, bytes, hipMemcpyHostToDevice, stream));
-        HIP_OK(launch_convert_rows(ix->stage_dev[slot], src_dtype, n, ix->dim, ix->data + (size_t)(ix->ntotal + r) * ix->dim_pad, ix->dtype,
-                                   ix->dim_pad, stream));
+        HIP_OK(ingest(ix->stage_dev[slot], n, ix->ntotal + r));
         HIP_OK(hipEventRecord(ix->stage_done[slot], stream));
         used[slot] = true;
     }
@@ -524,6 +678,12 @@ int vodhip_index_add(vodhip_index_t* ix, const void* rows, int64_t n_rows, int s
 int vodhip_index_reset(vodhip_index_t* ix) {
     if (!ix) return fail("index is NULL");
     if (!ix->inflight.empty()) return fail("%d searches are in flight: finish them before resetting the index", (int)ix->inflight.size());
+    if (ix->exact) {  // the row maxima of the error bound start over with the store (stale maxima would only loosen it)
+        HIP_OK(hipSetDevice(ix->device));
+        HIP_OK(hipDeviceSynchronize());  // ingests of the old rows may still run on some stream
+        HIP_OK(hipMemset(ix->norm_stats, 0, 2 * sizeof(unsigned int)));
+        HIP_OK(hipStreamSynchronize(nullptr));
+    }
     ix->ntotal = 0;
     return 0;
 }
@@ -562,6 +722,29 @@ int vodhip_index_get_rows(const vodhip_index_t* ix, int64_t row_begin, int64_t n
     const hipMemcpyKind kind = dst_location == VODHIP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     HIP_OK(hipMemcpy2DAsync(dst, (size_t)ix->dim * 2, ix->data + (size_t)row_begin * ix->dim_pad, (size_t)ix->dim_pad * 2,
                             (size_t)ix->dim * 2, (size_t)n_rows, kind, stream));
+    if (dst_location != VODHIP_DEVICE) HIP_OK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int vodhip_index_data_f32(const vodhip_index_t* ix, void** dev_ptr, int64_t* row_stride_elems) {
+    if (!ix) return fail("index is NULL");
+    if (!ix->exact) return fail("the index was not created with VODHIP_EXACT_F32: it keeps no float32 rows");
+    if (dev_ptr) *dev_ptr = ix->data32;
+    if (row_stride_elems) *row_stride_elems = ix->dim_pad;
+    return 0;
+}
+
+int vodhip_index_get_rows_f32(const vodhip_index_t* ix, int64_t row_begin, int64_t n_rows, void* dst, int dst_location, void* stream_) {
+    if (!ix) return fail("index is NULL");
+    if (!ix->exact) return fail("the index was not created with VODHIP_EXACT_F32: it keeps no float32 rows");
+    if (row_begin < 0 || n_rows < 0 || row_begin + n_rows > ix->ntotal) return fail("row range out of bounds");
+    if (n_rows == 0) return 0;
+    if (!dst) return fail("dst is NULL");
+    HIP_OK(hipSetDevice(ix->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    const hipMemcpyKind kind = dst_location == VODHIP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    HIP_OK(hipMemcpy2DAsync(dst, (size_t)ix->dim * 4, ix->data32 + (size_t)row_begin * ix->dim_pad, (size_t)ix->dim_pad * 4,
+                            (size_t)ix->dim * 4, (size_t)n_rows, kind, stream));
     if (dst_location != VODHIP_DEVICE) HIP_OK(hipStreamSynchronize(stream));
     return 0;
 }
@@ -610,6 +793,7 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
     if (ix->cand_cap < ROW_ALIGN || ix->cand_cap < k) return fail("cand_cap too small");
     if ((int)ix->inflight.size() + ix->unfinished >= MAX_IN_FLIGHT)
         return fail("%d searches are already in flight on this index: call vodhip_index_search_finish first", MAX_IN_FLIGHT);
+    if (ix->exact && nq > OVF_ROWS) return fail("VODHIP_EXACT_F32: at most %lld queries per search", (long long)OVF_ROWS);
     HIP_OK(hipSetDevice(ix->device));
     PendingSearch ps;
     ps.active = true;
@@ -625,12 +809,72 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
     ps.slot = ix->next_slot;
     if (ix->inflight.empty() && ix->unfinished == 0) ix->ev_used = 0;  // profile events are recycled once nothing refers to them
     ps.ev_begin = ix->ev_used;
-    if (nq > 0 && enqueue_search(ix, ps, ix->force_safe != 0, 0, (hipStream_t)stream_)) return -1;
+    if (ix->exact && nq > 0) {
+        // exact mode: the scan fills the slot's top-k' list, the re-scoring kernel behind it writes the caller's rows (no host round
+        // trip in between: the list is re-scored even if it later turns out that a candidate list overflowed - finish repeats it then)
+        ps.kx = exact_kx(ix, k);
+        if (ix->cand_cap < ps.kx) return fail("cand_cap too small for the exact-mode list of %d rows", ps.kx);
+        if (exact_reserve_lists(ix, ps.slot, (size_t)nq * ps.kx)) return -1;
+        if (enqueue_search(ix, exact_inner(ix, ps), ix->force_safe != 0, 0, (hipStream_t)stream_)) return -1;
+        if (enqueue_exact_list(ix, ps, (hipStream_t)stream_)) {
+            (void)hipStreamSynchronize((hipStream_t)stream_);
+            return -1;
+        }
+    } else if (nq > 0 && enqueue_search(ix, ps, ix->force_safe != 0, 0, (hipStream_t)stream_)) {
+        return -1;
+    }
     ps.ev_end = ix->ev_used;
     ix->next_slot = (ix->next_slot + 1) % MAX_IN_FLIGHT;
     ix->inflight.push_back(ps);
     return 0;
 }
+
+namespace {
+
+// Recovery of a search whose candidate lists overflowed (overflow_host[slot] set): the result is valid (real rows, real scores)
+// but may miss hits.  Recovery passes re-scan the store against thresholds seeded from that result - its k-th score is a lower
+// bound of the true k-th best, so few rows survive - in 1, 2, 4, ... FILTER stages, and in the exhaustive schedule (dense chunks
+// of <= cap rows, cannot overflow) once the stages are that short.  Returns the number of passes run, or -1.
+int recover_overflow(vodhip_index* ix, const PendingSearch& ps, hipStream_t stream) {
+    PendingSearch rs = ps;  // what the recovery passes search: the whole batch, or only the queries that overflowed
+    int pass = 0;
+    while (ix->overflow_host[ps.slot]) {
+        if (++pass > 40) return fail("internal error: the exhaustive schedule overflowed");
+        ix->last_overflow = 1;
+        ix->last_safe_reruns += 1;
+        if (pass == 1 && ps.nq <= OVF_ROWS && !ps.band) {
+            // the select kernels flagged the queries whose lists overflowed: usually a few (their neighbours are
+            // clustered in the store): only they are searched again, as a small batch on the small-batch kernels
+            std::vector<unsigned int> flags((size_t)ps.nq);
+            HIP_OK(hipMemcpy(flags.data(), ix->ovf_q + (size_t)ps.slot * OVF_ROWS, (size_t)ps.nq * sizeof(unsigned int), hipMemcpyDeviceToHost));
+            std::vector<int> rows;
+            for (int64_t q = 0; q < ps.nq; ++q)
+                if (flags[(size_t)q]) rows.push_back((int)q);
+            ix->last_recovered_queries = rows.empty() ? ps.nq : (int64_t)rows.size();
+            if (!rows.empty() && (int64_t)rows.size() < ps.nq) {
+                int* dmap = ix->q_map + (size_t)ps.slot * OVF_ROWS;
+                HIP_OK(hipMemcpy(dmap, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+                rs.q_map = dmap;
+                rs.nq = (int64_t)rows.size();
+            }
+        }
+        const size_t ev_first = ix->ev_used;  // behind the events of every younger search in flight
+        // (a BAND pass is itself "recovery" pass 1: its overflow passes start at 2 stages)
+        if (enqueue_search(ix, rs, false, pass + (ps.band ? 1 : 0), stream)) return -1;
+        HIP_OK(hipStreamSynchronize(stream));
+        // the recovery launches are accounted separately ("last_recovery_ns"): the time they take is real
+        for (size_t e = ev_first; e + 1 < ix->ev_used; e += 2) {
+            float ms = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms, ix->ev_pool[e], ix->ev_pool[e + 1]));
+            ix->last_recovery_ns += (int64_t)((double)ms * 1e6);
+            ++ix->last_recovery_launches;
+        }
+        ix->ev_used = ev_first;
+    }
+    return pass;
+}
+
+}  // namespace
 
 int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
     if (!ix) return fail("index is NULL");
@@ -656,43 +900,52 @@ int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
     ix->last_recovered_queries = 0;
     ix->last_recovery_launches = 0;
     ix->last_recovery_ns = 0;
-    if (ps.nq > 0) {
-        // A candidate list overflowed: the result is valid (real rows, real scores) but may miss hits.  Recovery
-        // passes re-scan the store against thresholds seeded from that result - its k-th score is a lower bound of the
-        // true k-th best, so few rows survive - in 1, 2, 4, ... FILTER stages, and in the exhaustive schedule (dense
-        // chunks of <= cap rows, cannot overflow) once the stages are that short.
-        PendingSearch rs = ps;  // what the recovery passes search: the whole batch, or only the queries that overflowed
-        for (int pass = 1; ix->overflow_host[ps.slot]; ++pass) {
-            if (pass > 40) return fail("internal error: the exhaustive schedule overflowed");
-            ix->last_overflow = 1;
-            ix->last_safe_reruns = pass;
-            if (pass == 1 && ps.nq <= OVF_ROWS) {
-                // the select kernels flagged the queries whose lists overflowed: usually a few (their neighbours are
-                // clustered in the store): only they are searched again, as a small batch on the small-batch kernels
-                std::vector<unsigned int> flags((size_t)ps.nq);
-                HIP_OK(hipMemcpy(flags.data(), ix->ovf_q + (size_t)ps.slot * OVF_ROWS, (size_t)ps.nq * sizeof(unsigned int), hipMemcpyDeviceToHost));
-                std::vector<int> rows;
-                for (int64_t q = 0; q < ps.nq; ++q)
-                    if (flags[(size_t)q]) rows.push_back((int)q);
-                ix->last_recovered_queries = rows.empty() ? ps.nq : (int64_t)rows.size();
-                if (!rows.empty() && (int64_t)rows.size() < ps.nq) {
-                    int* dmap = ix->q_map + (size_t)ps.slot * OVF_ROWS;
-                    HIP_OK(hipMemcpy(dmap, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
-                    rs.q_map = dmap;
-                    rs.nq = (int64_t)rows.size();
-                }
-            }
-            const size_t ev_first = ix->ev_used;  // behind the events of every younger search in flight
-            if (enqueue_search(ix, rs, false, pass, stream)) return -1;
+    ix->last_exact_kx = ps.kx;
+    ix->last_exact_band_queries = 0;
+    ix->last_exact_band_passes = 0;
+    if (ps.nq > 0 && ps.kx == 0) {
+        if (recover_overflow(ix, ps, stream) < 0) return -1;
+    } else if (ps.nq > 0) {
+        // exact mode.  (1) the scan's own exactness: a recovered list is re-scored again (the first re-scoring saw the incomplete one)
+        const int passes = recover_overflow(ix, exact_inner(ix, ps), stream);
+        if (passes < 0) return -1;
+        if (passes > 0) {
+            if (enqueue_exact_list(ix, ps, stream)) return -1;
             HIP_OK(hipStreamSynchronize(stream));
-            // the recovery launches are accounted separately ("last_recovery_ns"): the time they take is real
-            for (size_t e = ev_first; e + 1 < ix->ev_used; e += 2) {
-                float ms = 0.f;
-                HIP_OK(hipEventElapsedTime(&ms, ix->ev_pool[e], ix->ev_pool[e + 1]));
-                ix->last_recovery_ns += (int64_t)((double)ms * 1e6);
-                ++ix->last_recovery_launches;
+        }
+        // (2) the lists that did not prove complete: those queries run a BAND pass (every row whose scan score is within eps of
+        // the k-th exact score is re-scored); its own candidate lists may overflow, which splits the pass like any recovery
+        if (ix->x_flag_host[ps.slot]) {
+            std::vector<unsigned int> flags((size_t)ps.nq);
+            HIP_OK(hipMemcpy(flags.data(), ix->x_flag_q + (size_t)ps.slot * OVF_ROWS, (size_t)ps.nq * sizeof(unsigned int), hipMemcpyDeviceToHost));
+            std::vector<int> rows;
+            for (int64_t q = 0; q < ps.nq; ++q)
+                if (flags[(size_t)q]) rows.push_back((int)q);
+            ix->last_exact_band_queries = (int64_t)rows.size();
+            if (!rows.empty()) {
+                PendingSearch bs = ps;
+                bs.band = true;
+                bs.kx = 0;
+                int* dmap = ix->q_map + (size_t)ps.slot * OVF_ROWS;
+                if ((int64_t)rows.size() < ps.nq) {
+                    HIP_OK(hipMemcpy(dmap, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+                    bs.q_map = dmap;
+                    bs.nq = (int64_t)rows.size();
+                }
+                const size_t ev_first = ix->ev_used;
+                if (enqueue_search(ix, bs, false, 1, stream)) return -1;
+                HIP_OK(hipStreamSynchronize(stream));
+                for (size_t e = ev_first; e + 1 < ix->ev_used; e += 2) {
+                    float ms = 0.f;
+                    HIP_OK(hipEventElapsedTime(&ms, ix->ev_pool[e], ix->ev_pool[e + 1]));
+                    ix->last_recovery_ns += (int64_t)((double)ms * 1e6);
+                    ++ix->last_recovery_launches;
+                }
+                ix->ev_used = ev_first;
+                const int more = recover_overflow(ix, bs, stream);
+                if (more < 0) return -1;
+                ix->last_exact_band_passes = 1 + more;
             }
-            ix->ev_used = ev_first;
         }
     }
     ix->last_filter_launches = (int64_t)((ps.ev_end - ps.ev_begin) / 2);
@@ -761,6 +1014,9 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
     } else if (!strcmp(key, "ingest_threads")) {
         if (value < 0 || value > 256) return fail("ingest_threads must be in [0, 256] (0 = auto)");
         ix->ingest_threads = value;
+    } else if (!strcmp(key, "exact_expand")) {
+        if (value < 0 || value > 100000) return fail("exact_expand (x100) must be in [0, 100000]");
+        ix->exact_expand_x100 = value;
     } else if (!strcmp(key, "tile")) {
 #ifdef VODHIP_EXPERIMENTS
         const bool ring_ok = true;  // tiles 10 / 11 / 12: the FILTER kernels of experiment builds
@@ -794,6 +1050,14 @@ int vodhip_index_get_stat(const vodhip_index_t* ix, const char* key, int64_t* ou
         *out = ix->last_recovery_launches;
     else if (!strcmp(key, "last_recovery_ns"))
         *out = ix->last_recovery_ns;
+    else if (!strcmp(key, "exact"))
+        *out = ix->exact ? 1 : 0;
+    else if (!strcmp(key, "last_exact_kx"))
+        *out = ix->last_exact_kx;
+    else if (!strcmp(key, "last_exact_band_queries"))
+        *out = ix->last_exact_band_queries;
+    else if (!strcmp(key, "last_exact_band_passes"))
+        *out = ix->last_exact_band_passes;
     else if (!strcmp(key, "cand_cap"))
         *out = ix->cand_cap;
     else if (!strcmp(key, "dense_rows"))

@@ -85,9 +85,12 @@ hipError_t launch_convert_rows(const void* src, int src_dtype, int64_t n_rows, i
                                int64_t dst_stride, hipStream_t stream);
 // seed_scores / seed_ids ([nq, k] device, or NULL): a previous valid-but-incomplete result whose k-th score seeds the thresholds
 // q_map ([nq] device, or NULL): workspace row r is row q_map[r] of q_src / of the seed arrays
+// seed_margin ([rows of the caller's batch] device, or NULL): subtracted from the seeding score (the BAND pass of exact mode seeds
+// its scan thresholds with `k-th exact score - eps`)
 hipError_t launch_search_prepare(const SearchWorkspace& ws, const void* q_src, int q_dtype, int64_t nq, int64_t dim,
                                  int store_dtype, int64_t nq_pad, int64_t dim_pad, bool clear_overflow,
-                                 const float* seed_scores, const int64_t* seed_ids, int k, const int* q_map, hipStream_t stream);
+                                 const float* seed_scores, const int64_t* seed_ids, int k, const int* q_map, hipStream_t stream,
+                                 const float* seed_margin = nullptr);
 hipError_t launch_filter(int store_dtype, int tile, int mode, const void* store, const void* q_pad, int64_t dim_pad,
                          int64_t row_begin, int64_t row_end, int64_t n_sample_tiles, int64_t nq, int64_t nq_pad,
                          const SearchWorkspace& ws, hipStream_t stream);
@@ -112,6 +115,43 @@ inline bool filter_tile_is_persistent(int tile) { return tile >= 8 && tile <= 12
 int filter_tile_rows(int tile);  // BM of the tile config
 int filter_tile_cols(int tile);  // BN of the tile config
 int filter_group_rows(int tile); // rows per GMAX group (one lane's rows of one column block)
+
+// ---- launchers (kernels_exact.hip): the float32 plane of VODHIP_EXACT_F32 stores ----------------
+enum : int { EXACT_LIST = 0, EXACT_CAND = 1, EXACT_FIRST = 2 };
+struct ExactArgs {
+    const float* plane = nullptr;     // [rows][stride] float32 rows (zero padded columns)
+    int64_t stride = 0;
+    int dim = 0, dim_pad = 0;
+    const void* q_src = nullptr;      // the caller's queries [batch rows, dim] of q_dtype (unrounded)
+    int q_dtype = 0;
+    const int* q_map = nullptr;       // workspace row -> row of the caller's batch, or NULL
+    int store_dtype = 0;              // what the scan rounded to (the bound needs |q - q~|)
+    const unsigned int* stats = nullptr;  // [2] bit patterns of max |x|^2, max |x - x~|^2
+    int mode = EXACT_LIST;            // EXACT_LIST | EXACT_CAND [| EXACT_FIRST]
+    // LIST: the scan's top-kx list, rows of the caller's batch, LOCAL ids (pads -1)
+    const float* list_s = nullptr;
+    const int64_t* list_i = nullptr;
+    int kx = 0;
+    // CAND: a stage's candidate list (workspace rows)
+    const key_t64* cand = nullptr;
+    unsigned int* cnt = nullptr;
+    int cap = 0, dense_n = -1;
+    float* thr_s = nullptr;
+    key_t64* thr_key = nullptr;
+    int kr = 0;                       // slots of the running top-k in the key buffer (power of two >= k)
+    int P = 0;                        // key-buffer slots (power of two; LIST: >= kx, CAND: >= 2 * kr)
+    // results: rows of the caller's batch
+    int k = 0;
+    int64_t id_base = 0;
+    float* out_scores = nullptr;
+    int64_t* out_ids = nullptr;
+    float* eps = nullptr;             // [batch rows] the per-query bound (written by LIST)
+    unsigned int* flag_word = nullptr;  // LIST: some query is incomplete; CAND: some list lost candidates
+    unsigned int* flag_q = nullptr;     // LIST: [batch rows] 0 / 1 per query; CAND: [workspace rows] or NULL
+};
+hipError_t launch_ingest_exact(const void* src, int src_dtype, int64_t n_rows, int64_t dim, void* dst16, int dst_dtype, float* dst32,
+                               int64_t stride, unsigned int* stats, hipStream_t stream);
+hipError_t launch_exact_rescore(const ExactArgs& a, int64_t nq, hipStream_t stream);
 
 // ---- launchers (kernels_hybrid.hip) -----------------------------------------------------------
 struct HybridArgs {

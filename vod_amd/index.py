@@ -18,9 +18,15 @@ from vod_amd import _native
 
 
 class HipFlatIndex:
-    """Exact MIPS index: row-major fp16/bf16 rows in HBM, searched by the fused MFMA + top-k kernels."""
+    """Exact MIPS index: row-major fp16/bf16 rows in HBM, searched by the fused MFMA + top-k kernels.
 
-    def __init__(self, dim: int, capacity: int, dtype: torch.dtype = torch.float16, device: int | torch.device = 0):
+    `exact_f32=True` (VODHIP_EXACT_F32): the store also keeps the float32 rows and every search returns what a float32 brute force
+    over the UNROUNDED rows and queries returns - the reference's own arithmetic (faiss IndexFlat holds float32,
+    /root/reference/src/vod_search/faiss_search/build.py:65-73) - with the fp16 / bf16 scan as the filter.  Without it scores are
+    dot products of the values as rounded to `dtype`."""
+
+    def __init__(self, dim: int, capacity: int, dtype: torch.dtype = torch.float16, device: int | torch.device = 0,
+                 exact_f32: bool = False):
         self._lib = _native.load_library()
         if not torch.cuda.is_available():
             raise _native.NativeLibraryError("HipFlatIndex needs a ROCm device (torch.cuda.is_available() is False)")
@@ -30,10 +36,12 @@ class HipFlatIndex:
         self.dim = int(dim)
         self.capacity = int(capacity)
         self.dtype = dtype
+        self.exact_f32 = bool(exact_f32)
         handle = ctypes.c_void_p()
         _native.check(
             self._lib.vodhip_index_create(
-                self.device.index or 0, self.dim, _native.torch_dtype_code(dtype), self.capacity, ctypes.byref(handle)
+                self.device.index or 0, self.dim, _native.torch_dtype_code(dtype) | (_native.EXACT_F32 if self.exact_f32 else 0),
+                self.capacity, ctypes.byref(handle)
             )
         )
         self._h = handle
@@ -110,6 +118,17 @@ class HipFlatIndex:
             )
         return out
 
+    def stored_rows_f32(self, begin: int = 0, n: int | None = None) -> torch.Tensor:
+        """Copy of the float32 rows [begin, begin+n) of an `exact_f32` store (what was added, bit for bit)."""
+        n = self.ntotal - begin if n is None else int(n)
+        out = torch.empty((n, self.dim), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _native.check(
+                self._lib.vodhip_index_get_rows_f32(self._h, int(begin), n, out.data_ptr(), _native.DEVICE,
+                                                    _native.current_stream_ptr(self.device))
+            )
+        return out
+
     # -- subset filter (SURVEY 8f-3) ---------------------------------------------------------------
     def set_row_labels(self, labels: np.ndarray | torch.Tensor | None) -> None:
         """Attach an int32 subset label to every stored row (None clears).  Needed before `search(..., subset=...)`."""
@@ -128,11 +147,16 @@ class HipFlatIndex:
 
     # -- persistence (the store itself is the on-disk format, no faiss file round trip) -----------
     def save(self, path, chunk: int = 1 << 20) -> None:
-        """Write the stored rows (as stored: fp16, or bf16 widened to fp32) to a `.npy`, slice by slice."""
+        """Write the stored rows (as stored: fp16, or bf16 widened to fp32; the float32 rows of an `exact_f32` store - what
+        `faiss.write_index` persists for the reference, factory.py:167) to a `.npy`, slice by slice."""
         n = self.ntotal
-        np_dtype = np.float16 if self.dtype == torch.float16 else np.float32
+        np_dtype = np.float16 if (self.dtype == torch.float16 and not self.exact_f32) else np.float32
         out = np.lib.format.open_memmap(path, mode="w+", dtype=np_dtype, shape=(n, self.dim))
         for lo in range(0, n, chunk):
+            if self.exact_f32:
+                rows = self.stored_rows_f32(lo, min(chunk, n - lo))
+                out[lo : lo + rows.shape[0]] = rows.cpu().numpy()
+                continue
             rows = self.stored_rows(lo, min(chunk, n - lo))
             out[lo : lo + rows.shape[0]] = (rows if self.dtype == torch.float16 else rows.float()).cpu().numpy()
         out.flush()
@@ -140,12 +164,12 @@ class HipFlatIndex:
 
     @classmethod
     def load(cls, path, dtype: torch.dtype = torch.float16, device: int | torch.device = 0, capacity: int | None = None,
-             chunk: int = 1 << 18) -> "HipFlatIndex":
+             chunk: int = 1 << 18, exact_f32: bool = False) -> "HipFlatIndex":
         """Build an index from a 2-D float16/float32 `.npy` (memory-mapped, streamed to HBM in slices)."""
         arr = np.load(path, mmap_mode="r", allow_pickle=False)
         if arr.ndim != 2:
             raise ValueError(f"expected a 2-D vector file, got shape {arr.shape}")
-        ix = cls(arr.shape[1], max(capacity or arr.shape[0], 1), dtype=dtype, device=device)
+        ix = cls(arr.shape[1], max(capacity or arr.shape[0], 1), dtype=dtype, device=device, exact_f32=exact_f32)
         if arr.flags.c_contiguous:
             ix.add(arr)  # ONE call: the library pipelines page-cache reads, pinned staging and DMA itself (64 MB slices)
         else:
@@ -286,7 +310,7 @@ class HipNodeIndex:
     C / C++ consumer of the library gets, and what a single-process Python host can use without `torch.distributed`.
     """
 
-    def __init__(self, dim: int, capacity: int, devices: list[int], dtype: torch.dtype = torch.float16):
+    def __init__(self, dim: int, capacity: int, devices: list[int], dtype: torch.dtype = torch.float16, exact_f32: bool = False):
         self._lib = _native.load_library()
         if not torch.cuda.is_available():
             raise _native.NativeLibraryError("HipNodeIndex needs a ROCm device (torch.cuda.is_available() is False)")
@@ -296,10 +320,11 @@ class HipNodeIndex:
             raise ValueError("devices must list at least one device ordinal")
         self.dim, self.capacity, self.dtype, self.devices = int(dim), int(capacity), dtype, [int(d) for d in devices]
         self.device = torch.device("cuda", self.devices[0])
+        self.exact_f32 = bool(exact_f32)  # every shard keeps its float32 rows (HipFlatIndex): the merged result is the float32 brute force
         handle = ctypes.c_void_p()
         arr = (ctypes.c_int32 * len(self.devices))(*self.devices)
-        _native.check(self._lib.vodhip_node_index_create(len(self.devices), arr, self.dim, _native.torch_dtype_code(dtype), self.capacity,
-                                                         ctypes.byref(handle)))
+        code = _native.torch_dtype_code(dtype) | (_native.EXACT_F32 if self.exact_f32 else 0)
+        _native.check(self._lib.vodhip_node_index_create(len(self.devices), arr, self.dim, code, self.capacity, ctypes.byref(handle)))
         self._h = handle
 
     def close(self) -> None:
