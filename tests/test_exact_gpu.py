@@ -1,0 +1,296 @@
+"""GPU parity tests of the exact-fp32 mode (VODHIP_EXACT_F32): results on UNROUNDED float32 inputs.
+
+The reference stores and searches float32 (faiss IndexFlat: /root/reference/src/vod_search/faiss_search/build.py:65-73,
+server.py:71-72,81-84).  These tests feed float32 N(0, 1) rows and queries - values that are NOT representable in the fp16 / bf16
+scan dtype - and compare with the oracle fed the same float32 inputs (float64 accumulation):
+
+  * recall@k = 1.0,
+  * |score - oracle| <= 1e-3 (north_star's tolerance; measured ~2e-5: one float32 summation against float64),
+  * ids equal to the oracle's except where two rows' float64 scores are closer than TIE_TOL (a float32 brute force such as
+    faiss's own orders those either way).
+
+On integer-valued inputs (every partial sum exact in fp32) ids and scores must equal the oracle bit for bit, ties included.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 1e-3   # north_star: "scores within 1e-3 fp32"
+TIE_TOL = 1e-4     # float64 score gap below which a float32 summation may order two rows either way (|score| ~ 100-200)
+
+
+def _gauss(seed, n, d, nq):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, d, generator=g).numpy()
+    q = torch.randn(nq, d, generator=g).numpy()
+    return q, x
+
+
+def _index(x, dtype=torch.float16, exact=True, capacity=None, **params):
+    from vod_amd.index import HipFlatIndex
+
+    ix = HipFlatIndex(x.shape[1], capacity or max(len(x), 1), dtype=dtype, device=0, exact_f32=exact)
+    if len(x):
+        ix.add(x)
+    for key, v in params.items():
+        ix.set_param(key, v)
+    return ix
+
+
+def _oracle(q, x, k, id_base=0):
+    from oracle.flat_ip import flat_ip_topk
+
+    return flat_ip_topk(q, x, k, id_base=id_base)
+
+
+def _score64(q, x, ids):
+    """float64 scores of the given (query row, id) pairs"""
+    out = np.full(ids.shape, -np.inf)
+    for r in range(ids.shape[0]):
+        ok = ids[r] >= 0
+        out[r, ok] = np.asarray(x[ids[r, ok]], dtype=np.float64) @ np.asarray(q[r], dtype=np.float64)
+    return out
+
+
+def _compare(s, i, q, x, k, id_base=0):
+    """-> dict(recall, max_abs_score_diff, rows_same_order); asserts the contract stated in the module docstring"""
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    rs, ri = _oracle(q, x, k, id_base=id_base)
+    assert np.array_equal(i >= 0, ri >= 0), "pad pattern differs"
+    fin = np.isfinite(rs)
+    assert np.all(s[:, 1:][fin[:, 1:]] <= s[:, :-1][fin[:, 1:]]), "scores not sorted"
+    diff = float(np.abs(s[fin] - rs[fin]).max()) if fin.any() else 0.0
+    assert diff <= SCORE_TOL, f"max |score - oracle| = {diff}"
+    # every returned row is a legitimate member: its float64 score reaches the oracle's k-th within the tie tolerance
+    mine64 = _score64(q, x, np.where(i >= 0, i - id_base, -1))
+    kth = rs[:, -1].astype(np.float64)
+    assert np.all((mine64 >= kth[:, None] - TIE_TOL) | (i < 0)), "a returned row is not in the top-k"
+    recall = float(np.mean([len(set(a[a >= 0]) & set(b[b >= 0])) / max(1, (b >= 0).sum()) for a, b in zip(i, ri)]))
+    # where the order differs, the two rows are tied at float32 level
+    differ = i != ri
+    if differ.any():
+        gap = np.abs(mine64 - rs.astype(np.float64))[differ]
+        assert gap.max() <= TIE_TOL, f"ids differ where the float64 scores differ by {gap.max()}"
+    return {"recall": recall, "max_abs_score_diff": diff, "rows_same_order": float(np.mean((i == ri).all(1)))}
+
+
+def test_c1_full_size_float32_inputs_match_the_float32_brute_force():
+    """BASELINE config 1: 100 k x 384 float32, batch 32, top-10 - the reference's own example (examples/search/faiss.py)."""
+    q, x = _gauss(1, 100_000, 384, 32)
+    with _index(x) as ix:
+        s, i = ix.search(torch.from_numpy(q).cuda(), 10)
+        r = _compare(s, i, q, x, 10)
+        assert r["recall"] == 1.0
+        assert ix.get_stat("exact") == 1 and ix.get_stat("last_exact_kx") > 10
+        np.testing.assert_array_equal(ix.stored_rows_f32().cpu().numpy(), x)  # the float32 plane holds the input bit for bit
+    # the same store WITHOUT the mode: scores of the rounded values - the deviation this mode removes (recorded by bench.py too)
+    with _index(x, exact=False) as ix:
+        s, i = ix.search(torch.from_numpy(q).cuda(), 10)
+        rs, _ = _oracle(q, x, 10)
+        assert np.abs(s.cpu().numpy() - rs).max() > SCORE_TOL
+
+
+@pytest.mark.parametrize("dtype,n,d,nq,k", [
+    (torch.float16, 1_000_000, 768, 256, 100),   # BASELINE config 2, full size
+    (torch.bfloat16, 200_000, 1024, 512, 200),   # config 4's shape (bf16, e5-large dims, top-200) on an oracle-sized store
+    (torch.float16, 150_000, 768, 1024, 100),    # the headline's batch (four query tiles, persistent kernel)
+    (torch.bfloat16, 60_000, 96, 48, 17),        # odd dimension / k, small-batch kernels
+])
+def test_float32_inputs_match_the_float32_brute_force(dtype, n, d, nq, k):
+    q, x = _gauss(n + d, n, d, nq)
+    with _index(x, dtype=dtype) as ix:
+        s, i = ix.search(torch.from_numpy(q).cuda(), k)
+        r = _compare(s, i, q, x, k)
+        assert r["recall"] == 1.0
+        assert ix.get_stat("last_overflow") == 0
+        # the default list length proves (nearly) every query complete at once on this data
+        assert ix.get_stat("last_exact_band_queries") <= max(1, nq // 50)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_band_pass_completes_lists_that_do_not_prove_themselves(dtype):
+    """k' = k proves no list complete: every query runs the band pass; a tiny candidate capacity then overflows the band pass
+    itself, which splits it into stages and finally dense chunks.  The result must not change."""
+    q, x = _gauss(7, 120_000, 256, 96)
+    k = 64
+    with _index(x, dtype=dtype) as ix:
+        s0, i0 = ix.search(torch.from_numpy(q).cuda(), k)
+        r = _compare(s0, i0, q, x, k)
+        assert r["recall"] == 1.0
+        ix.set_param("exact_expand", 1)  # k' = max(k, k / 100 + 16) = k
+        s1, i1 = ix.search(torch.from_numpy(q).cuda(), k)
+        assert ix.get_stat("last_exact_kx") == k
+        assert ix.get_stat("last_exact_band_queries") == len(q) and ix.get_stat("last_exact_band_passes") == 1
+        assert torch.equal(i0, i1) and torch.equal(s0, s1)
+        ix.set_param("cand_cap", 256)
+        s2, i2 = ix.search(torch.from_numpy(q[:40]).cuda(), k)
+        assert torch.equal(i0[:40], i2) and torch.equal(s0[:40], s2)
+
+
+@pytest.mark.parametrize("tile", [1, 8, 9, 42, 46])
+def test_integer_inputs_are_bit_exact_ties_included(tile):
+    """Integer-valued float32 inputs: all arithmetic is exact, thousands of rows tie - ids and scores equal the oracle bit for bit
+    (the completeness check cannot tell ties apart from near-misses, so tied queries go through the band pass)."""
+    rng = np.random.default_rng(tile)
+    x = rng.integers(-3, 4, size=(30_000, 64)).astype(np.float32)
+    q = rng.integers(-3, 4, size=(70 if tile in (1, 42, 46) else 300, 64)).astype(np.float32)
+    with _index(x, tile=tile) as ix:
+        for k in (1, 25, 100):
+            s, i = ix.search(torch.from_numpy(q).cuda(), k)
+            rs, ri = _oracle(q, x, k)
+            np.testing.assert_array_equal(i.cpu().numpy(), ri)
+            np.testing.assert_array_equal(s.cpu().numpy(), rs)
+
+
+def test_duplicated_rows_at_the_top():
+    """5,000 copies of the best row: the scan's list holds only copies, the check fails, the band pass finds > cap candidates and
+    splits; the answer is the k smallest ids among the copies."""
+    q, x = _gauss(11, 40_000, 128, 8)
+    x[5_000:10_000] = 3.0 * q[0]  # (float32 products, not representable in fp16)
+    with _index(x, cand_cap=1024) as ix:
+        s, i = ix.search(torch.from_numpy(q).cuda(), 50)
+        r = _compare(s, i, q, x, 50)
+        assert r["recall"] == 1.0
+        np.testing.assert_array_equal(i[0].cpu().numpy(), np.arange(5_000, 5_050))
+
+
+def test_incremental_add_reset_id_base_and_fewer_rows_than_k():
+    q, x = _gauss(3, 5_000, 200, 20)
+    with _index(x[:10], capacity=6_000) as ix:
+        s, i = ix.search(torch.from_numpy(q).cuda(), 32)  # 10 rows, k = 32: pads
+        r = _compare(s, i, q, x[:10], 32)
+        assert r["recall"] == 1.0 and (i[:, 10:] == -1).all()
+        ix.add(x[10:3_000])
+        ix.add(torch.from_numpy(x[3_000:]).cuda())  # device source
+        s, i = ix.search(torch.from_numpy(q).cuda(), 32, id_base=1_000_000)
+        assert _compare(s, i, q, x, 32, id_base=1_000_000)["recall"] == 1.0
+        ix.reset()
+        assert ix.ntotal == 0
+        big = 100.0 * x[:700]  # larger norms than before the reset: the bound follows the rows actually stored
+        ix.add(big)
+        s, i = ix.search(torch.from_numpy(q).cuda(), 5)
+        rs, ri = _oracle(q, big, 5)
+        assert np.mean([len(set(a) & set(b)) / 5 for a, b in zip(i.cpu().numpy(), ri)]) == 1.0
+        np.testing.assert_allclose(s.cpu().numpy(), rs, rtol=1e-5, atol=1e-2)  # scores ~ 1e4 here: the 1e-3 absolute bar is for |score| <~ 1e3
+
+
+def test_half_precision_queries_and_rows_are_taken_as_exact_values():
+    q, x = _gauss(5, 20_000, 128, 16)
+    q16, x16 = q.astype(np.float16), x.astype(np.float16)
+    with _index(x16) as ix:  # nothing to round: the bound shrinks to the summation slack
+        s, i = ix.search(torch.from_numpy(q16).cuda(), 20)
+        assert _compare(s, i, q16.astype(np.float32), x16.astype(np.float32), 20)["recall"] == 1.0
+    with _index(x, dtype=torch.bfloat16) as ix:  # fp16 queries against a bf16 scan: the query rounding is part of the bound
+        s, i = ix.search(torch.from_numpy(q16).cuda(), 20)
+        assert _compare(s, i, q16.astype(np.float32), x, 20)["recall"] == 1.0
+
+
+def test_subset_filter_in_exact_mode():
+    q, x = _gauss(9, 30_000, 64, 40)
+    rng = np.random.default_rng(9)
+    labels = rng.integers(0, 5, size=len(x)).astype(np.int32)
+    allowed = np.full((len(q), 2), -1, dtype=np.int32)
+    allowed[::2, 0] = 3
+    allowed[1::4, 0], allowed[1::4, 1] = 0, 4
+    with _index(x) as ix:
+        ix.set_row_labels(labels)
+        s, i = ix.search(torch.from_numpy(q).cuda(), 30, subset=allowed)
+        s, i = s.cpu().numpy(), i.cpu().numpy()
+        for r in range(len(q)):
+            lab = allowed[r][allowed[r] >= 0]
+            rows = np.arange(len(x)) if lab.size == 0 else np.nonzero(np.isin(labels, lab))[0]
+            rs, ri = _oracle(q[r : r + 1], x[rows], 30)
+            np.testing.assert_array_equal(i[r], rows[ri[0]])
+            assert np.abs(s[r] - rs[0]).max() <= SCORE_TOL
+
+
+def test_shard_merge_equals_the_whole_index_bit_for_bit():
+    """The exact score is one function of (query, row): two shards merged = one index, scores included (H3)."""
+    from vod_amd.index import merge_topk
+
+    q, x = _gauss(13, 90_000, 320, 130)
+    k = 40
+    qd = torch.from_numpy(q).cuda()
+    with _index(x) as whole, _index(x[:50_000]) as a, _index(x[50_000:]) as b:
+        sw, iw = whole.search(qd, k)
+        sa, ia = a.search(qd, k)
+        sb, ib = b.search(qd, k, id_base=50_000)
+        sm, im = merge_topk(torch.stack([sa, sb]), torch.stack([ia, ib]))
+        assert torch.equal(im, iw) and torch.equal(sm, sw)
+        # ... and the answer does not depend on who else is in the batch
+        s1, i1 = whole.search(qd[17:18], k)
+        assert torch.equal(i1[0], iw[17]) and torch.equal(s1[0], sw[17])
+
+
+def test_node_index_and_pipelined_searches():
+    from vod_amd.index import HipNodeIndex
+
+    q, x = _gauss(17, 70_000, 256, 64)
+    k = 30
+    rs, ri = _oracle(q, x, k)
+    with HipNodeIndex(256, len(x), devices=[0, 0, 0], exact_f32=True) as nx:
+        nx.add(x)
+        s, i = nx.search(q, k)
+        assert np.abs(s - rs).max() <= SCORE_TOL
+        assert np.mean([len(set(a) & set(b)) / k for a, b in zip(i, ri)]) == 1.0
+    with _index(x) as ix:
+        qd = [torch.from_numpy(q[j::4]).cuda() for j in range(4)]
+        outs = [(torch.empty((len(t), k), dtype=torch.float32, device="cuda"), torch.empty((len(t), k), dtype=torch.int64, device="cuda")) for t in qd]
+        for t, o in zip(qd, outs):
+            ix.search_async(t, k, out=o)  # four searches in flight, each with its own list buffers
+        for _ in qd:
+            ix.finish()
+        for j, (so, io) in enumerate(outs):
+            assert _compare(so, io, q[j::4], x, k)["recall"] == 1.0
+        np.testing.assert_array_equal(np.sort(outs[0][1].cpu().numpy(), axis=1), np.sort(ri[0::4], axis=1))
+
+
+def test_save_load_round_trip_keeps_the_float32_rows(tmp_path):
+    from vod_amd.index import HipFlatIndex
+
+    q, x = _gauss(19, 12_000, 96, 10)
+    with _index(x) as ix:
+        s0, i0 = ix.search(torch.from_numpy(q).cuda(), 15)
+        ix.save(tmp_path / "v.npy")
+    on_disk = np.load(tmp_path / "v.npy")
+    assert on_disk.dtype == np.float32
+    np.testing.assert_array_equal(on_disk, x)
+    with HipFlatIndex.load(tmp_path / "v.npy", exact_f32=True) as ix:
+        s1, i1 = ix.search(torch.from_numpy(q).cuda(), 15)
+        assert torch.equal(i0, i1) and torch.equal(s0, s1)
+
+
+def test_c_abi_refuses_float32_views_of_a_plain_store():
+    from vod_amd import _native
+
+    q, x = _gauss(23, 1_000, 64, 4)
+    with _index(x, exact=False) as ix:
+        assert ix.get_stat("exact") == 0
+        with pytest.raises(_native.NativeLibraryError, match="VODHIP_EXACT_F32"):
+            ix.stored_rows_f32()
+
+
+def test_config1_through_the_spawned_server_with_float32_vectors(tmp_path, monkeypatch):
+    """BASELINE config 1 end to end (examples/search/faiss.py: float32 N(0, 1) vectors, batch 32, top-10) with `exact_f32`: the
+    factory writes a float32 vector file, the server keeps both planes, the HTTP clients get the float32 brute-force result - over
+    both wire routes, and through the 3-worker group (per-shard exact lists merged)."""
+    from vod_amd import factory
+
+    monkeypatch.chdir(tmp_path)
+    q, x = _gauss(29, 100_000, 384, 32)
+    rs, ri = _oracle(q, x, 10)
+    for extra in ({}, {"devices": (0, 0, 0), "group_backend": "gloo"}):
+        cfg = {"port": -1, "logging_level": "warning", "exact_f32": True, **extra}
+        master = factory.build_hip_mips_index(x, config=cfg, cache_dir=tmp_path)
+        assert np.load(master.vectors_path, mmap_mode="r").dtype == np.float32
+        with master:
+            for binary in (False, True):
+                c = type(master.get_client())(host=master.host, port=master.port, binary=binary)
+                res = c.search(vector=q, top_k=10)
+                assert np.abs(res.scores - rs).max() <= SCORE_TOL
+                assert np.mean([len(set(a) & set(b)) / 10 for a, b in zip(res.indices, ri)]) == 1.0
+                differ = res.indices != ri
+                if differ.any():
+                    assert np.abs(_score64(q, x, res.indices) - rs.astype(np.float64))[differ].max() <= TIE_TOL

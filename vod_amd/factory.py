@@ -24,7 +24,10 @@ class HipMipsFactoryConfig:
 
     factory: str = "Flat"           # only the exact index exists here
     metric: str = "inner_product"   # src/vod_configs/search.py:130
-    dtype: str = "float16"          # HBM storage type (float16 | bfloat16)
+    dtype: str = "float16"          # HBM storage type of the SCAN copy (float16 | bfloat16)
+    exact_f32: bool = False         # also keep the float32 rows and return the float32 brute-force result on the unrounded vectors and
+                                    # queries - what the reference's faiss IndexFlat computes (build.py:65-73); the vector file handed
+                                    # to the server is float32 then.  Off: scores are dot products of the values rounded to `dtype`
     host: str = "http://localhost"
     port: int = -1                  # the reference config's default (src/vod_configs/search.py:134): < 0 = pick a free port, so two
                                     # default-config indexes on one host (hybrid set-ups, shards, two jobs) never collide; ONE
@@ -43,7 +46,10 @@ class HipMipsFactoryConfig:
                                     # expected company, (("max_queries", 1024),) = smaller fused batches
 
     def fingerprint(self) -> dict:
-        return {"factory": self.factory, "metric": self.metric, "dtype": self.dtype}
+        fp = {"factory": self.factory, "metric": self.metric, "dtype": self.dtype}
+        if self.exact_f32:  # (absent when off: the cache names of existing stores do not change)
+            fp["exact_f32"] = True
+        return fp
 
 
 def resolve_port(config: HipMipsFactoryConfig, broadcast_fn: None | typ.Callable[[int], int] = None) -> HipMipsFactoryConfig:
@@ -99,7 +105,7 @@ def build_hip_mips_index(
         path.parent.mkdir(parents=True, exist_ok=True)
     if not isinstance(vectors, ZarrVectors) and not skip_setup and not path.exists():
         tmp = path.with_suffix(".tmp.npy")
-        store.save_vectors(tmp, vectors, dtype=np.float16 if config.dtype == "float16" else np.float32)
+        store.save_vectors(tmp, vectors, dtype=np.float16 if (config.dtype == "float16" and not config.exact_f32) else np.float32)
         tmp.rename(path)
     if barrier_fn is not None:
         barrier_fn(f"hip mips store: `{path.name}`")
@@ -113,6 +119,7 @@ def build_hip_mips_index(
         skip_setup=skip_setup,
         free_resources=free_resources,
         dtype=config.dtype,
+        exact_f32=config.exact_f32,
         device=config.device,
         devices=None if devices is None else list(devices),
         group_backend=config.group_backend,

@@ -456,7 +456,8 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         micro_batch_wait_ms: float = 0.0,  # > 0: every batch additionally waits this long for company (concurrent requests are fused by default)
         http: str = "native",  # the server's HTTP shell: "native" (libvodhip's front, default) or "uvicorn" (FastAPI fallback)
         batcher_params: None | dict[str, int] = None,  # vodhip_batcher_set_param on the server (max_queries, grace_us, grace_pct, flat_queries, depth)
-        uds: bool | str = False,  # also listen on a Unix-domain socket (True = a path under the temp dir); `get_client()` then uses it
+        uds: bool | str = False,  # also listen on a Unix-domain socket (True = a path in a private directory); `get_client()` then uses it
+        exact_f32: bool = False,  # the server keeps the float32 rows and answers with the float32 brute-force result (HipFlatIndex)
     ):
         super().__init__(skip_setup=skip_setup, free_resources=free_resources)
         self.vectors_path = vectors_path if str(vectors_path).startswith("synthetic:") else pathlib.Path(vectors_path)
@@ -464,6 +465,7 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
         self.host = host
         self.port = find_available_port() if port < 0 else port
         self.dtype = dtype
+        self.exact_f32 = bool(exact_f32)
         self.device = device
         # `devices=[...]`: the store is row-sharded over these GPUs behind the SAME host:port (one worker process per
         # GPU on an RCCL group; what `FaissMaster(serve_on_gpu=True)` gets from faiss's index_cpu_to_all_gpus,
@@ -495,6 +497,7 @@ class HipMipsMaster(base.SearchMaster[HipMipsClient]):
             "--port", str(self.port),
             "--logging-level", str(self.logging_level),
             "--dtype", self.dtype,
+            *(["--exact-f32"] if self.exact_f32 else []),
             "--http", self.http,
             *(["--micro-batch-wait-ms", str(self.micro_batch_wait_ms)] if self.micro_batch_wait_ms > 0 else []),
             *(["--uds", str(self.uds)] if self.uds else []),

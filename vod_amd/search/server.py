@@ -256,8 +256,10 @@ class HipEngine:
     `row_range=(lo, hi)`: hold only rows [lo, hi) of the store (one shard of a multi-GPU group); ids stay global."""
 
     def __init__(self, vectors_path: str, dtype: str = "float16", device: int = 0, subset_ids_path: str | None = None,
-                 row_range: tuple[int, int] | None = None):
+                 row_range: tuple[int, int] | None = None, exact_f32: bool = False):
         import torch
+
+        self.exact_f32 = bool(exact_f32)  # keep the float32 rows too: results of a float32 brute force (HipFlatIndex)
 
         from vod_amd import store
         from vod_amd.index import HipFlatIndex
@@ -271,7 +273,7 @@ class HipEngine:
         n, d = vectors.shape
         lo, hi = (0, n) if row_range is None else (int(row_range[0]), int(row_range[1]))
         self.n_store, self.row_lo, self.row_hi = n, lo, hi
-        self.index = HipFlatIndex(d, max(hi - lo, 1), dtype=getattr(torch, dtype), device=device)
+        self.index = HipFlatIndex(d, max(hi - lo, 1), dtype=getattr(torch, dtype), device=device, exact_f32=self.exact_f32)
         step = 262144
         if hasattr(vectors, "iter_row_blocks") and row_range is None:
             # zarr store: blocks aligned to its chunk grid, each chunk decoded once, on a thread pool running ahead of the ingest
@@ -303,10 +305,10 @@ class HipEngine:
         n, d = (int(v) for v in shape.lower().split("x"))
         lo, hi = (0, n) if row_range is None else (int(row_range[0]), int(row_range[1]))
         self.n_store, self.row_lo, self.row_hi = n, lo, hi
-        self.index = HipFlatIndex(d, max(hi - lo, 1), dtype=getattr(torch, dtype), device=device)
+        self.index = HipFlatIndex(d, max(hi - lo, 1), dtype=getattr(torch, dtype), device=device, exact_f32=self.exact_f32)
         self.vocab = {}
         for rows in synthetic_rows(torch, torch.device("cuda", device), lo, hi, d, int(seed or 0)):
-            self.index.add(rows.to(getattr(torch, dtype)))
+            self.index.add(rows if self.exact_f32 else rows.to(getattr(torch, dtype)))
 
     @property
     def ntotal(self) -> int:
@@ -370,7 +372,8 @@ class NodeHipEngine:
     `faiss.index_cpu_to_all_gpus(index, co)` with `co.shard = True` (/root/reference/src/vod_search/faiss_search/server.py:51-54).
     Same `.ntotal` / `.search` as `HipEngine`."""
 
-    def __init__(self, vectors_path: str, devices: list[int], dtype: str = "float16", subset_ids_path: str | None = None):
+    def __init__(self, vectors_path: str, devices: list[int], dtype: str = "float16", subset_ids_path: str | None = None,
+                 exact_f32: bool = False):
         import torch
 
         from vod_amd import store
@@ -380,16 +383,16 @@ class NodeHipEngine:
         if str(vectors_path).startswith("synthetic:"):
             shape, _, seed = str(vectors_path)[len("synthetic:"):].partition(":")
             n, d = (int(v) for v in shape.lower().split("x"))
-            self.index = HipNodeIndex(d, max(n, 1), devices, dtype=getattr(torch, dtype))
+            self.index = HipNodeIndex(d, max(n, 1), devices, dtype=getattr(torch, dtype), exact_f32=exact_f32)
             for rows in synthetic_rows(torch, torch.device("cuda", devices[0]), 0, n, d, int(seed or 0)):
-                self.index.add(rows.to(torch.float16).cpu().numpy())
+                self.index.add((rows if exact_f32 else rows.to(torch.float16)).cpu().numpy())
             self.n_store = n
             self._log_topology()
             return
         vectors = store.open_vectors(vectors_path)
         n, d = vectors.shape
         self.n_store = n
-        self.index = HipNodeIndex(d, max(n, 1), devices, dtype=getattr(torch, dtype))
+        self.index = HipNodeIndex(d, max(n, 1), devices, dtype=getattr(torch, dtype), exact_f32=exact_f32)
         if hasattr(vectors, "iter_row_blocks"):
             for _lo, rows in vectors.iter_row_blocks():
                 self.index.add(rows)
@@ -487,6 +490,10 @@ def parse_args(argv=None) -> argparse.Namespace:
     p.add_argument("--port", type=int, default=7678)
     p.add_argument("--logging-level", type=str, default="INFO")
     p.add_argument("--dtype", type=str, default="float16", choices=["float16", "bfloat16"])
+    p.add_argument("--exact-f32", action="store_true",
+                   help="keep the float32 rows next to the fp16 / bf16 scan copy and answer with the float32 brute-force result on the "
+                        "unrounded vectors and queries - the reference's arithmetic (faiss IndexFlat holds float32, build.py:65-73); "
+                        "+4 bytes per element of HBM, ~1-3 %% of search time")
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--devices", type=str, default=None,
                    help="comma-separated GPU ids: the store is row-sharded over them, one worker process per GPU on an RCCL "
@@ -593,7 +600,7 @@ def run_worker(args: argparse.Namespace) -> None:
         n = store.open_vectors(args.vectors_path).shape[0]
     bounds = shard_bounds(n, world, align=256)
     local = HipEngine(args.vectors_path, dtype=args.dtype, device=devices[rank], subset_ids_path=args.subset_ids_path,
-                      row_range=(bounds[rank], bounds[rank + 1]))
+                      row_range=(bounds[rank], bounds[rank + 1]), exact_f32=args.exact_f32)
     sharded = ShardedFlatIndex(local.index, row_offset=bounds[rank], always_exchange=True)
     dispatcher = GroupDispatcher(sharded, rank, world, dev if args.group_backend == "nccl" else torch.device("cpu"), search_device=dev,
                                  dim=local.index.dim)
@@ -661,13 +668,13 @@ def main(argv=None) -> None:
         limit_cpu_threads(max(1, usable_cpus() // max(1, n_workers)))  # the workers of a group share the grant
     if args.devices is not None and args.group_backend == "node":
         devices = [int(x) for x in args.devices.split(",") if x.strip() != ""]
-        engine = NodeHipEngine(args.vectors_path, devices, dtype=args.dtype, subset_ids_path=args.subset_ids_path)
+        engine = NodeHipEngine(args.vectors_path, devices, dtype=args.dtype, subset_ids_path=args.subset_ids_path, exact_f32=args.exact_f32)
         return _serve(engine, args, re.sub(r"^(http|https)://", "", args.host))
     if args.devices is not None and args.rank is None:
         raise SystemExit(run_owner(args, argv))
     if args.devices is not None:
         return run_worker(args)
-    engine = HipEngine(args.vectors_path, dtype=args.dtype, device=args.device, subset_ids_path=args.subset_ids_path)
+    engine = HipEngine(args.vectors_path, dtype=args.dtype, device=args.device, subset_ids_path=args.subset_ids_path, exact_f32=args.exact_f32)
     host = re.sub(r"^(http|https)://", "", args.host)
     _serve(engine, args, host)
 
