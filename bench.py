@@ -46,6 +46,12 @@ def parse_args() -> argparse.Namespace:
     p.add_argument("--nq", type=int, default=1024)
     p.add_argument("--k", type=int, default=100)
     p.add_argument("--dtype", choices=["f16", "bf16"], default="f16")
+    p.add_argument("--config", choices=["c3", "c4"], default=None,
+                   help="BASELINE presets: c3 = the default (10 M x 768 fp16, batch 1024, top-100); c4 = configs[3] (40 M x 1024 bf16, batch 512, "
+                        "top-200: 82 GB on one GPU, 10 GB per GPU at --gpus 8) - sets --rows / --dim / --nq / --k / --dtype")
+    p.add_argument("--exact-f32", action="store_true",
+                   help="VODHIP_EXACT_F32 store: float32 rows kept next to the scan copy, float32 queries, results of the float32 brute force "
+                        "on the UNROUNDED inputs (what the reference's faiss IndexFlat computes)")
     p.add_argument("--data", choices=["iid", "clustered", "duplicates", "normalized"], default="iid")
     p.add_argument("--tile", type=int, default=0)
     p.add_argument("--growth", type=int, default=0, help="stage growth factor x100 (0 = library default)")
@@ -66,6 +72,9 @@ def parse_args() -> argparse.Namespace:
                    help="seconds a rank waits for the process-group rendezvous + the first collective before it exits non-zero (code 75)")
     p.add_argument("--launch-check", action="store_true",
                    help="CPU-only check of the launcher: every rank joins a gloo group, all-reduces its rank, rank 0 prints one JSON line")
+    pre, _ = p.parse_known_args()
+    if pre.config == "c4":  # a preset = new defaults: explicit --rows / --nq ... still win
+        p.set_defaults(rows=40_000_000, dim=1024, nq=512, k=200, dtype="bf16")
     return p.parse_args()
 
 
@@ -347,7 +356,7 @@ class Rig:
         return float(t.item())
 
 
-def build_index(rig: Rig, *, rows: int, dim: int, dtype: str, data: str, tile: int = 0, growth: int = 0, params=()):
+def build_index(rig: Rig, *, rows: int, dim: int, dtype: str, data: str, tile: int = 0, growth: int = 0, params=(), exact: bool = False):
     """This rank's contiguous row shard (generation-chunk boundaries) of the synthetic corpus, resident in HBM."""
     from vod_amd.index import HipFlatIndex
 
@@ -358,7 +367,7 @@ def build_index(rig: Rig, *, rows: int, dim: int, dtype: str, data: str, tile: i
     c_hi = (n_chunks * (rig.rank + 1)) // rig.world
     row_lo = min(rows, c_lo * GEN_CHUNK)
     row_hi = min(rows, c_hi * GEN_CHUNK)
-    index = HipFlatIndex(dim, max(row_hi - row_lo, 1), dtype=tdt, device=dev.index)
+    index = HipFlatIndex(dim, max(row_hi - row_lo, 1), dtype=tdt, device=dev.index, exact_f32=exact)
     if tile:
         index.set_param("tile", tile)
     if growth:
@@ -370,14 +379,109 @@ def build_index(rig: Rig, *, rows: int, dim: int, dtype: str, data: str, tile: i
             index.set_param(key, int(val))
     t0 = time.perf_counter()
     for c in range(c_lo, c_hi):
-        index.add(make_rows(torch, dev, tdt, data, c, min(GEN_CHUNK, rows - c * GEN_CHUNK), dim, rows))
+        # (an exact-f32 store ingests the UNROUNDED float32 rows: it rounds its scan copy itself)
+        index.add(make_rows(torch, dev, torch.float32 if exact else tdt, data, c, min(GEN_CHUNK, rows - c * GEN_CHUNK), dim, rows))
     torch.cuda.synchronize()
     assert index.ntotal == row_hi - row_lo
     return index, row_lo, time.perf_counter() - t0
 
 
+def _brute_force_f64(rig: Rig, qs, row_block, n_local: int, row_lo: int, k: int, multi: bool):
+    """Exact top-k of the sampled queries `qs` (float64 [S, d]) over this rank's rows by a chunked FLOAT64 product, merged over the
+    ranks when `multi`: the comparator of `verify`.  `row_block(lo, n)` -> rows [lo, lo + n) of the shard (any float dtype).
+    Stable sorts keep ties in ascending id order, like the product.  Returns (scores f64 [S, k'], ids i64 [S, k']) on the CPU."""
+    torch, dev, world = rig.torch, rig.dev, rig.world
+    n_s = qs.shape[0]
+    kk = min(k, n_local)
+    ls = torch.full((n_s, kk), float("-inf"), device=dev, dtype=torch.float64)
+    li = torch.full((n_s, kk), -1, dtype=torch.int64, device=dev)
+    for lo in range(0, n_local, GEN_CHUNK):
+        blk = row_block(lo, min(GEN_CHUNK, n_local - lo)).double()
+        sc = qs @ blk.T
+        kb = min(kk, sc.shape[1])
+        ts, ti = torch.sort(sc, dim=1, descending=True, stable=True)
+        ts, ti = ts[:, :kb], ti[:, :kb]
+        cs, ci = torch.cat([ls, ts], dim=1), torch.cat([li, ti + (lo + row_lo)], dim=1)
+        top = torch.sort(cs, dim=1, descending=True, stable=True)
+        ls, li = top.values[:, :kk], torch.gather(ci, 1, top.indices[:, :kk])
+        del blk, sc
+    if multi:
+        pad_s = torch.full((n_s, k), float("-inf"), device=dev, dtype=torch.float64)
+        pad_i = torch.full((n_s, k), -1, dtype=torch.int64, device=dev)
+        pad_s[:, : ls.shape[1]] = ls
+        pad_i[:, : li.shape[1]] = li
+        as_ = torch.empty((world * n_s, k), device=dev, dtype=torch.float64)
+        ai_ = torch.empty((world * n_s, k), dtype=torch.int64, device=dev)
+        rig.all_gather(as_, pad_s)
+        rig.all_gather(ai_, pad_i)
+        # merge of the per-rank reference lists in fp64 (rank-major = ascending ids: the stable sort keeps the tie-break)
+        cs = as_.view(world, n_s, k).permute(1, 0, 2).reshape(n_s, world * k)
+        ci = ai_.view(world, n_s, k).permute(1, 0, 2).reshape(n_s, world * k)
+        top = torch.sort(cs, dim=1, descending=True, stable=True)
+        ls, li = top.values[:, :k], torch.gather(ci, 1, top.indices[:, :k])
+    return ls.cpu(), li.cpu()
+
+
+def _compare_with(torch, fs, fi, sample, ref_s, ref_i, comparator: str) -> dict:
+    got_i = fi[sample].cpu()
+    hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got_i, ref_i))
+    got_s = fs[sample][:, : ref_s.shape[1]].double().cpu()
+    fin = torch.isfinite(ref_s) & torch.isfinite(got_s)
+    diff = (got_s - ref_s).abs()[fin]
+    scale = float(ref_s[fin].abs().max()) if bool(fin.any()) else 0.0
+    return {
+        "comparator": comparator,
+        "recall_at_k": hits / float(ref_i.numel()),
+        "rows_with_identical_id_order": float((got_i[:, : ref_i.shape[1]] == ref_i).all(dim=1).float().mean()),
+        "max_abs_score_diff": float(diff.max()) if diff.numel() else 0.0,
+        "max_rel_score_diff": float((diff / ref_s[fin].abs().clamp_min(1e-30)).max()) if diff.numel() else 0.0,
+        "score_scale": scale,  # largest |score| among the checked hits: the 1e-3 absolute tolerance is a statement about |score| <~ 200 (DESIGN.md 2)
+        "queries_checked": len(sample),
+    }
+
+
+def integer_twin_check(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, k: int, dtype: str, multi: bool, verify_queries: int) -> dict:
+    """"Indices bit-exact" asserted at FULL size by the bench line itself (outside every timed region): the store is refilled with
+    integer-valued rows of the same shape (every partial sum exact in fp32, thousands of exact ties), ONE batch of integer-valued
+    queries runs through the same search, and the sampled queries' ids AND scores must equal a float64 brute force bit for bit under
+    the (score desc, id asc) tie-break.  Leaves the index holding the twin."""
+    from vod_amd.index import PackedTopk
+
+    torch, dev, world = rig.torch, rig.dev, rig.world
+    tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+    n_local = index.ntotal
+    index.reset()
+
+    def twin_rows(lo, n):
+        g = torch.Generator(device=dev).manual_seed(777 + (row_lo + lo) // GEN_CHUNK)
+        return torch.randint(-8, 9, (n, dim), generator=g, device=dev, dtype=torch.int32).to(torch.float32)
+
+    for lo in range(0, n_local, GEN_CHUNK):
+        index.add(twin_rows(lo, min(GEN_CHUNK, n_local - lo)).to(torch.float32 if index.exact_f32 else tdt))
+    g = torch.Generator(device=dev).manual_seed(778)
+    q = torch.randint(-8, 9, (nq, dim), generator=g, device=dev, dtype=torch.int32).to(torch.float32 if index.exact_f32 else tdt)
+    p = PackedTopk(nq, k, dev)
+    index.search(q, k, id_base=row_lo, out=(p.scores, p.ids))
+    fs, fi = p.scores, p.ids
+    if multi:
+        gathered = torch.empty((world * p.nbytes,), dtype=torch.uint8, device=dev)
+        rig.all_gather(gathered, p.buffer)
+        fs, fi = p.merge_gathered(gathered, world)
+    n_v = min(nq, max(1, verify_queries))
+    sample = sorted(set(int(round(j * (nq - 1) / max(1, n_v - 1))) for j in range(n_v))) if n_v > 1 else [0]
+    ref_s, ref_i = _brute_force_f64(rig, q[sample].double(), twin_rows, n_local, row_lo, k, multi)
+    got_s, got_i = fs[sample].cpu(), fi[sample].cpu()
+    ties = int(sum((r[1:] == r[:-1]).sum() for r in ref_s))
+    return {
+        "ids_bit_exact": bool(torch.equal(got_i[:, : ref_i.shape[1]], ref_i)),
+        "scores_bit_exact": bool(torch.equal(got_s[:, : ref_s.shape[1]].double(), ref_s)),
+        "queries_checked": len(sample), "rows": rows, "tied_neighbours_in_the_reference_lists": ties,
+        "data": "integer-valued rows and queries in [-8, 8] (exact fp32 arithmetic), same shape, one batch, outside the timed region",
+    }
+
+
 def run_workload(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, k: int, dtype: str, data: str, multi: bool,
-                 steps: int, warmup: int, verify_queries: int, tile: int = 0) -> dict:
+                 steps: int, warmup: int, verify_queries: int, tile: int = 0, exact: bool = False) -> dict:
     """W untimed + K timed steps of one workload on an index already resident in HBM; returns the measurements.
 
     One step = one batch through the hot path.  The host runs ONE step ahead of the device: step i+1 is enqueued before
@@ -392,16 +496,16 @@ def run_workload(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, 
     (Overlapping the all-gather with the next search on RCCL's own stream was measured and dropped in round 2: the
     persistent filter kernel owns every CU, the collective's workgroups wait for one anyway: +11 % on the stage kernels.)
     """
-    from vod_amd.index import PackedTopk, merge_topk
+    from vod_amd.index import PackedTopk
 
     torch, dev, world = rig.torch, rig.dev, rig.world
     dist = rig.ensure_group() if multi else None
     tdt = torch.float16 if dtype == "f16" else torch.bfloat16
     n_local = index.ntotal
-    queries = make_queries(torch, dev, tdt, data, nq, dim, rows)
+    queries = make_queries(torch, dev, torch.float32 if exact else tdt, data, nq, dim, rows)  # (exact-f32: the unrounded float32 queries)
     packed = [PackedTopk(nq, k, dev) for _ in range(2)]  # [scores | ids] records: the exchange is ONE all-gather of 12*nq*k bytes
     gathered = torch.empty((world * packed[0].nbytes,), dtype=torch.uint8, device=dev) if multi else None
-    state = {"pending": [], "n": 0, "ns": 0, "launches": 0, "recovery_passes": 0, "recovery_ns": 0, "res": None}
+    state = {"pending": [], "n": 0, "ns": 0, "launches": 0, "recovery_passes": 0, "recovery_ns": 0, "res": None, "band_queries": 0, "xev": []}
 
     def step():
         p = packed[state["n"] % 2]
@@ -418,9 +522,16 @@ def run_workload(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, 
         state["launches"] += index.get_stat("last_filter_launches")
         state["recovery_passes"] += index.get_stat("last_safe_reruns")
         state["recovery_ns"] += index.get_stat("last_recovery_ns")
+        if exact:
+            state["band_queries"] += index.get_stat("last_exact_band_queries")
         if multi:
+            # the exchange step, bracketed by HIP events on the stream it is ordered on (the collective's own stream joins it)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             rig.all_gather(gathered, p.buffer)
             state["res"] = p.merge_gathered(gathered, world)
+            e1.record()
+            state["xev"].append((e0, e1))
         else:
             state["res"] = (p.scores, p.ids)
 
@@ -437,8 +548,9 @@ def run_workload(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, 
         step()
     drain()
     index.set_param("profile", 1)
-    for key in ("ns", "launches", "recovery_passes", "recovery_ns"):
+    for key in ("ns", "launches", "recovery_passes", "recovery_ns", "band_queries"):
         state[key] = 0
+    state["xev"] = []
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -447,9 +559,17 @@ def run_workload(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, 
     fence()
     elapsed = time.perf_counter() - t0
     index.set_param("profile", 0)
+    per_rank = None
     if multi:
         elapsed = rig.all_reduce_scalar(elapsed, "MAX")
         state["recovery_passes"] = int(rig.all_reduce_scalar(state["recovery_passes"], "SUM"))  # over all ranks
+        # what every rank spent, from its own HIP events: the filter launches (+ recovery) and the exchange (all-gather + merge)
+        exch_us = sum(a.elapsed_time(b) for a, b in state["xev"]) * 1e3 / max(1, len(state["xev"]))
+        mine = torch.tensor([(state["ns"] + state["recovery_ns"]) * 1e-6 / steps, exch_us, float(n_local)], dtype=torch.float64, device=dev)
+        allr = torch.empty((world * 3,), dtype=torch.float64, device=dev)
+        rig.all_gather(allr, mine)
+        per_rank = [{"rank": r, "kernel_ms": float(allr[3 * r]), "exchange_us": float(allr[3 * r + 1]), "rows": int(allr[3 * r + 2])}
+                    for r in range(world)]
 
     # ---- post-run verification (outside the timed region): exactness on a query sample ----
     verify = None
@@ -458,58 +578,27 @@ def run_workload(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, 
         n_v = min(nq, max(1, verify_queries))
         sample = [int(round(j * (nq - 1) / max(1, n_v - 1))) for j in range(n_v)] if n_v > 1 else [0]
         sample = sorted(set(sample))
-        # local brute force on this rank's shard: a chunked FLOAT64 product over the STORED (rounded) rows - every fp16 x fp16
-        # product is exact in fp64 and the 768-1024-term sums carry ~1e-13 relative error, so `max_abs_score_diff` is the
-        # kernel's own fp32-accumulation error, not a mix of two fp32 summation orders (round 3 compared with an fp32 matmul)
-        kk = min(k, n_local)
-        ls = torch.full((len(sample), kk), float("-inf"), device=dev, dtype=torch.float64)
-        li = torch.full((len(sample), kk), -1, dtype=torch.int64, device=dev)
-        qs = queries[sample].double()
-        step_rows = 250_000
-        for lo in range(0, n_local, step_rows):  # stable sorts: ties keep the smaller id first, like the product
-            blk = index.stored_rows(lo, min(step_rows, n_local - lo)).double()
-            sc = qs @ blk.T
-            kb = min(kk, sc.shape[1])
-            ts, ti = torch.sort(sc, dim=1, descending=True, stable=True)
-            ts, ti = ts[:, :kb], ti[:, :kb]
-            cs, ci = torch.cat([ls, ts], dim=1), torch.cat([li, ti + (lo + row_lo)], dim=1)
-            top = torch.sort(cs, dim=1, descending=True, stable=True)
-            ls, li = top.values[:, :kk], torch.gather(ci, 1, top.indices[:, :kk])
-            del blk, sc
-        if multi:
-            pad_s = torch.full((len(sample), k), float("-inf"), device=dev, dtype=torch.float64)
-            pad_i = torch.full((len(sample), k), -1, dtype=torch.int64, device=dev)
-            pad_s[:, : ls.shape[1]] = ls
-            pad_i[:, : li.shape[1]] = li
-            as_ = torch.empty((world * len(sample), k), device=dev, dtype=torch.float64)
-            ai_ = torch.empty((world * len(sample), k), dtype=torch.int64, device=dev)
-            rig.all_gather(as_, pad_s)
-            rig.all_gather(ai_, pad_i)
-            # merge of the per-rank reference lists in fp64 (rank-major = ascending ids: the stable sort keeps the tie-break)
-            cs = as_.view(world, len(sample), k).permute(1, 0, 2).reshape(len(sample), world * k)
-            ci = ai_.view(world, len(sample), k).permute(1, 0, 2).reshape(len(sample), world * k)
-            top = torch.sort(cs, dim=1, descending=True, stable=True)
-            ls, li = top.values[:, :k], torch.gather(ci, 1, top.indices[:, :k])
-        got_i = fi[sample].cpu()
-        ref_i = li.cpu()
-        hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got_i, ref_i))
-        got_s = fs[sample][:, : ls.shape[1]].double().cpu()
-        ref_s = ls.cpu()
-        fin = torch.isfinite(ref_s) & torch.isfinite(got_s)
-        diff = (got_s - ref_s).abs()[fin]
-        scale = float(ref_s[fin].abs().max()) if bool(fin.any()) else 0.0
-        verify = {
-            "comparator": "float64 chunked product over the stored rows (ties -> smaller id)",
-            "recall_at_k": hits / float(ref_i.numel()),
-            "rows_with_identical_id_order": float((got_i[:, : ref_i.shape[1]] == ref_i).all(dim=1).float().mean()),
-            "max_abs_score_diff": float(diff.max()) if diff.numel() else 0.0,
-            "max_rel_score_diff": float((diff / ref_s[fin].abs().clamp_min(1e-30)).max()) if diff.numel() else 0.0,
-            "score_scale": scale,  # largest |score| among the checked hits: the 1e-3 absolute tolerance is a statement about |score| <~ 200
-            "queries_checked": len(sample),
-        }
+        # (1) against the STORED (rounded) rows and queries: every fp16 x fp16 product is exact in fp64 and the 768-1024-term sums
+        # carry ~1e-13 relative error, so `max_abs_score_diff` is the kernel's own fp32-accumulation error
+        q_stored = queries[sample].to(tdt).double()
+        ref_s, ref_i = _brute_force_f64(rig, q_stored, lambda lo, n: index.stored_rows(lo, n), n_local, row_lo, k, multi)
+        stored = _compare_with(torch, fs, fi, sample, ref_s, ref_i, "float64 chunked product over the stored (rounded) rows and queries (ties -> smaller id)")
+        # (2) against the UNROUNDED float32 inputs the synthetic corpus was generated as - what the reference's float32 faiss index
+        # would be searched with (build.py:65-73): the deviation a rounded store carries, and what the exact-f32 mode removes
+        q32 = make_queries(torch, dev, torch.float32, data, nq, dim, rows)[sample].double()
+        c0 = row_lo // GEN_CHUNK
+        ref_s, ref_i = _brute_force_f64(
+            rig, q32, lambda lo, n: make_rows(torch, dev, torch.float32, data, c0 + lo // GEN_CHUNK, n, dim, rows), n_local, row_lo, k, multi)
+        unrounded = _compare_with(torch, fs, fi, sample, ref_s, ref_i, "float64 chunked product over the UNROUNDED float32 rows and queries")
+        verify = dict(unrounded if exact else stored)
+        verify["vs_unrounded_inputs"] = {key: unrounded[key] for key in ("recall_at_k", "max_abs_score_diff", "rows_with_identical_id_order", "score_scale")}
+        if exact:
+            verify["vs_stored_rounded_rows"] = {key: stored[key] for key in ("recall_at_k", "max_abs_score_diff")}
+            verify["exact_f32"] = {"band_queries_per_step": state["band_queries"] / steps, "list_rows_k_prime": index.get_stat("last_exact_kx")}
     return {"elapsed": elapsed, "filter_ns": state["ns"], "filter_launches": state["launches"], "recovery_passes": state["recovery_passes"],
             "recovery_ns": state["recovery_ns"], "verify": verify, "n_local": n_local, "steps": steps, "warmup": warmup,
-            "rows": rows, "dim": dim, "nq": nq, "k": k, "dtype": dtype, "data": data, "multi": multi, "tile": tile}
+            "rows": rows, "dim": dim, "nq": nq, "k": k, "dtype": dtype, "data": data, "multi": multi, "tile": tile, "exact": exact,
+            "per_rank": per_rank}
 
 
 def _m(v: int) -> str:
@@ -573,16 +662,21 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
     the headline fields."""
     out = []
 
-    def one(name, *, rows, nq, data="iid", multi=False, steps, warmup, index=None, row_lo=0, dim=None, k=None, dtype=None):
+    def one(name, *, rows, nq, data="iid", multi=False, steps, warmup, index=None, row_lo=0, dim=None, k=None, dtype=None, exact=False,
+            twin=False):
         dim, k, dtype = dim or args.dim, k or args.k, dtype or args.dtype
         try:
             own = index is None
             t_build = None
+            twin_rec = None
             if own:
-                index, row_lo, t_build = build_index(rig, rows=rows, dim=dim, dtype=dtype, data=data)
+                index, row_lo, t_build = build_index(rig, rows=rows, dim=dim, dtype=dtype, data=data, exact=exact)
             try:
                 m = run_workload(rig, index, row_lo, rows=rows, dim=dim, nq=nq, k=k, dtype=dtype, data=data,
-                                 multi=multi, steps=steps, warmup=warmup, verify_queries=args.verify_queries)
+                                 multi=multi, steps=steps, warmup=warmup, verify_queries=args.verify_queries, exact=exact)
+                if twin and own and args.verify_queries > 0:
+                    twin_rec = integer_twin_check(rig, index, row_lo, rows=rows, dim=dim, nq=nq, k=k, dtype=dtype, multi=multi,
+                                                  verify_queries=args.verify_queries)
             finally:
                 if own:
                     index.close()
@@ -590,7 +684,8 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
             out.append({
                 "name": name,
                 "workload": f"{rows} sections x {dim} {dtype}, batch {nq} queries, top-{k}" + ("" if data == "iid" else ", rows sorted by topic cluster")
-                            + (", + RCCL all-gather (1 rank) + merge" if multi else ""),
+                            + (", + RCCL all-gather (1 rank) + merge" if multi else "")
+                            + (", exact-f32 store: float32 rows + queries in, float32 brute-force result out" if exact else ""),
                 "steps": steps, "warmup": warmup,
                 "ms_per_step": m["elapsed"] / steps * 1e3,
                 "value": nq * steps / m["elapsed"],
@@ -600,6 +695,8 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
                 "roofline": roofline_of(m, rig.world),
                 "verify": m["verify"],
             })
+            if twin_rec is not None:
+                out[-1]["verify"]["ids_bit_exact_on_integer_twin"] = twin_rec
         except Exception as exc:  # noqa: BLE001 - a side line must never take the headline down
             out.append({"name": name, "error": f"{type(exc).__name__}: {exc}"[:400]})
 
@@ -610,9 +707,14 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
     one("C3_shard_of_8_with_exchange", rows=args.rows // 8, nq=args.nq, multi=True, steps=100, warmup=10)
     # BASELINE configs[3] (C4: 40 M x 1024 bf16, batch 512, top-200): what each of its 8 GPUs holds, and the whole store on this ONE GPU (82 GB)
     one("C4_shard_of_8", rows=5_000_000, dim=1024, nq=512, k=200, dtype="bf16", steps=40, warmup=5)
+    # the exact-f32 mode (float32 rows and queries in, the float32 brute-force result out) on the same shapes: what it costs, and that
+    # `vs_unrounded_inputs` reads recall 1.0 / < 1e-3 there while the lines above carry the rounding of their store dtype
+    one("C2_exact_f32", rows=1_000_000, nq=256, steps=200, warmup=20, exact=True)
+    one("C3_exact_f32", rows=args.rows, nq=args.nq, steps=max(5, args.steps), warmup=3, exact=True)
+    one("C4_shard_of_8_exact_f32", rows=5_000_000, dim=1024, nq=512, k=200, dtype="bf16", steps=40, warmup=5, exact=True)
     free_b = rig.torch.cuda.mem_get_info(rig.dev)[0]
     if free_b > 110e9:
-        one("C4_one_gpu", rows=40_000_000, dim=1024, nq=512, k=200, dtype="bf16", steps=10, warmup=3)
+        one("C4_one_gpu", rows=40_000_000, dim=1024, nq=512, k=200, dtype="bf16", steps=10, warmup=3, twin=True)
     else:
         out.append({"name": "C4_one_gpu", "skipped": f"{free_b / 1e9:.0f} GB of HBM free: the 82 GB store + workspace do not fit next to the headline store"})
     # BASELINE configs[4] (C5: hybrid merge + priority sampling + in-batch retrieval loss, batch 64 x 32 sections)
@@ -669,13 +771,17 @@ def main() -> None:
 
     n_total, d, nq, k = args.rows, args.dim, args.nq, args.k
     index, row_lo, t_build = build_index(rig, rows=n_total, dim=d, dtype=args.dtype, data=args.data, tile=args.tile, growth=args.growth,
-                                         params=args.param)
+                                         params=args.param, exact=args.exact_f32)
     m = run_workload(rig, index, row_lo, rows=n_total, dim=d, nq=nq, k=k, dtype=args.dtype, data=args.data, multi=multi,
-                     steps=args.steps, warmup=args.warmup, verify_queries=0 if args.no_verify else args.verify_queries, tile=args.tile)
-    default_workload = (n_total, d, nq, k, args.dtype, args.data, args.tile, args.growth, tuple(args.param)) == (10_000_000, 768, 1024, 100, "f16", "iid", 0, 0, ())
+                     steps=args.steps, warmup=args.warmup, verify_queries=0 if args.no_verify else args.verify_queries, tile=args.tile,
+                     exact=args.exact_f32)
+    default_workload = (n_total, d, nq, k, args.dtype, args.data, args.tile, args.growth, tuple(args.param), args.exact_f32) == (10_000_000, 768, 1024, 100, "f16", "iid", 0, 0, (), False)
     side = None
     if world == 1 and not args.force_collective and not args.no_side and default_workload:
         side = side_workloads(rig, args, index, row_lo)
+    if m["verify"] is not None:  # (last use of the headline store: it is refilled with the integer twin)
+        m["verify"]["ids_bit_exact_on_integer_twin"] = integer_twin_check(
+            rig, index, row_lo, rows=n_total, dim=d, nq=nq, k=k, dtype=args.dtype, multi=multi, verify_queries=args.verify_queries)
     index.close()
 
     line = None
@@ -698,7 +804,8 @@ def main() -> None:
                      "duplicates": "synthetic, one section repeated over the last tenth of the store, every query aimed at it",
                      "normalized": "synthetic, rows and queries L2-normalised x 10 (scaled-cosine embeddings)"}[args.data],
             "config": {
-                "workload": f"{n_total} sections x {d} {args.dtype}, batch {nq} queries, top-{k}, exact brute force",
+                "workload": f"{n_total} sections x {d} {args.dtype}, batch {nq} queries, top-{k}, exact brute force"
+                            + (", exact-f32 store (float32 rows + queries, float32 brute-force result)" if args.exact_f32 else ""),
                 "rows_per_gpu": m["n_local"],
                 "parallelism": (f"row-sharded x{world} + {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} all-gather of per-shard top-k") if multi else "single GPU",
                 "index_build_s": round(t_build, 3),
@@ -708,6 +815,12 @@ def main() -> None:
         }
         if rig.comm is not None:  # did the collective library see N ranks?  (answerable from the record alone)
             line["comm"] = rig.comm
+        if m.get("per_rank"):  # every rank's own HIP-event figures: filter kernel ms / step, exchange (all-gather + merge) us / step
+            peak_flops = 2.5e15
+            for r in m["per_rank"]:
+                r["mfma_frac_of_2.5PF"] = (2.0 * nq * r["rows"] * d / (r["kernel_ms"] * 1e-3) / peak_flops) if r["kernel_ms"] > 0 else None
+            line["per_rank"] = m["per_rank"]
+            line["exchange_us_per_step_max"] = max(r["exchange_us"] for r in m["per_rank"])
         if m["verify"] is not None:
             line["verify"] = m["verify"]
         if side is not None:

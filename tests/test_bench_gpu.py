@@ -162,6 +162,24 @@ def test_bench_eight_ranks_sharing_the_gpu_headline_shape():
     assert rec["comm"]["world_size"] == 8 and rec["comm"]["ranks_in_first_all_reduce"] == 8 and rec["comm"]["backend"] == "gloo"
     assert rec["verify"]["recall_at_k"] == 1.0 and rec["verify"]["max_abs_score_diff"] < 1e-3
     assert "all-gather" in rec["config"]["parallelism"]
+    # round 5: one SCALE pass yields, per rank, the filter-kernel time, its roofline fraction and the exchange cost (HIP events)
+    assert [r["rank"] for r in rec["per_rank"]] == list(range(8))
+    for r in rec["per_rank"]:
+        assert r["rows"] == 250_000 and r["kernel_ms"] > 0 and r["exchange_us"] > 0 and 0 < r["mfma_frac_of_2.5PF"] < 1
+    assert rec["exchange_us_per_step_max"] == max(r["exchange_us"] for r in rec["per_rank"])
+    twin = rec["verify"]["ids_bit_exact_on_integer_twin"]  # merged over the eight ranks
+    assert twin["ids_bit_exact"] is True and twin["scores_bit_exact"] is True
+
+
+def test_bench_c4_preset_and_exact_mode_across_two_ranks():
+    """`--config c4` selects BASELINE configs[3]'s shape (bf16, dim 1024, batch 512, top-200; fewer rows here), and `--exact-f32` makes
+    every rank keep float32 rows: the merged result must match the UNROUNDED float32 inputs (per-shard exact lists merge exactly)."""
+    rec = _run_bench("--gpus", "2", "--backend", "gloo", "--config", "c4", "--rows", "500000", "--exact-f32", "--steps", "3", "--warmup", "1",
+                     "--no-cpu-baseline", "--verify-queries", "32")
+    assert "x 1024 bf16, batch 512 queries, top-200" in rec["config"]["workload"] and "exact-f32" in rec["config"]["workload"]
+    assert rec["verify"]["recall_at_k"] == 1.0 and rec["verify"]["max_abs_score_diff"] < 1e-3 and "UNROUNDED" in rec["verify"]["comparator"]
+    assert rec["verify"]["vs_stored_rounded_rows"]["max_abs_score_diff"] > 1e-3  # (the bf16 scan alone would be this far off)
+    assert len(rec["per_rank"]) == 2
 
 
 def test_bench_default_line_carries_the_side_workloads():
@@ -171,12 +189,26 @@ def test_bench_default_line_carries_the_side_workloads():
     assert rec["config"]["workload"].startswith("10000000 sections x 768")
     names = [s_["name"] for s_ in rec["side"]]
     # round 4: every BASELINE config is driver-timed - C4 (its per-GPU shard and the whole 82 GB store on this one GPU) and C5
-    assert names == ["C2", "C3_nq256", "C3_clustered", "C3_shard_of_8", "C3_shard_of_8_with_exchange", "C4_shard_of_8", "C4_one_gpu", "C5"]
-    for s_ in rec["side"][:7]:
+    assert names == ["C2", "C3_nq256", "C3_clustered", "C3_shard_of_8", "C3_shard_of_8_with_exchange", "C4_shard_of_8",
+                     "C2_exact_f32", "C3_exact_f32", "C4_shard_of_8_exact_f32", "C4_one_gpu", "C5"]
+    for s_ in rec["side"][:10]:
         assert "error" not in s_ and "skipped" not in s_, s_
         assert s_["verify"]["recall_at_k"] == 1.0 and s_["roofline"]["frac"] > 0.05
         assert s_["verify"]["comparator"].startswith("float64") and s_["verify"]["max_abs_score_diff"] < 1e-3
-    c5 = rec["side"][7]
+        # round 5: every line also says how its result compares with the UNROUNDED float32 inputs (the reference's input type) ...
+        vu = s_["verify"]["vs_unrounded_inputs"]
+        assert 0.9 < vu["recall_at_k"] <= 1.0 and vu["max_abs_score_diff"] >= 0
+        if s_["name"].endswith("exact_f32"):  # ... and the exact-f32 lines match them: float32 brute-force results
+            assert "UNROUNDED" in s_["verify"]["comparator"] and vu["recall_at_k"] == 1.0 and vu["max_abs_score_diff"] < 1e-3
+            assert s_["verify"]["exact_f32"]["list_rows_k_prime"] > 100
+        else:  # a rounded store carries its rounding (fp16: ~1e-2, bf16: ~0.2): on the record, not hidden
+            assert vu["max_abs_score_diff"] > 1e-3
+    twin = rec["side"][9]["verify"]["ids_bit_exact_on_integer_twin"]  # C4 at full size
+    assert twin["ids_bit_exact"] is True and twin["scores_bit_exact"] is True and twin["rows"] == 40_000_000
+    twin = rec["verify"]["ids_bit_exact_on_integer_twin"]              # the headline at full size
+    assert twin["ids_bit_exact"] is True and twin["scores_bit_exact"] is True and twin["rows"] == 10_000_000 and twin["queries_checked"] >= 32
+    assert rec["verify"]["vs_unrounded_inputs"]["max_abs_score_diff"] > 1e-3
+    c5 = rec["side"][10]
     assert "error" not in c5, c5
     assert c5["verify"]["ok"] is True and c5["verify"]["collate_cases"] >= 4 and c5["verify"]["gradient_cases"] == 5
     assert c5["collate_merge_sample"]["host_syncs"] == 0 and c5["collate_merge_sample_flatten"]["host_syncs"] == 0
