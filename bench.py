@@ -33,6 +33,21 @@ ROOT = pathlib.Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
+_T0 = time.perf_counter()
+
+
+def _trace(msg: str) -> None:
+    """BENCH_TRACE=1: phase stamps on stderr (seconds since import) - where a slow run spends its wall time"""
+    dst = os.environ.get("BENCH_TRACE")
+    if dst:
+        line = f"[bench +{time.perf_counter() - _T0:7.2f}s rank {os.environ.get('RANK', '0')}] {msg}"
+        if dst == "1":
+            print(line, file=sys.stderr, flush=True)
+        else:  # a path prefix: one file per rank (the launcher keeps the ranks' stderr to itself)
+            with open(f"{dst}.rank{os.environ.get('RANK', '0')}.log", "a") as f:
+                f.write(line + "\n")
+
+
 GEN_CHUNK = 250_000  # rows per generation chunk; shard boundaries are multiples of it so the corpus is the same for every N
 
 
@@ -386,6 +401,25 @@ def build_index(rig: Rig, *, rows: int, dim: int, dtype: str, data: str, tile: i
     return index, row_lo, time.perf_counter() - t0
 
 
+def _topk_ties_by_id(torch, sc, kb: int):
+    """Row-wise top-kb of `sc` ordered (score desc, column asc) WITHOUT sorting the rows (a stable full sort of [S, 250 k] float64
+    took minutes when eight ranks shared one GPU): the kb-th largest value t by radix select; every entry above t is in; of the entries
+    equal to t the smallest columns fill the rest.  Returns (values [S, kb], columns [S, kb])."""
+    n = sc.shape[1]
+    sc = torch.nan_to_num(sc, nan=float("-inf"))
+    top_v, top_c = torch.topk(sc, kb, dim=1)
+    t = top_v[:, -1:]
+    cols = torch.arange(n, device=sc.device, dtype=torch.int64)[None, :]
+    tie_c = torch.topk(torch.where(sc == t, cols, n), kb, dim=1, largest=False).values  # ascending columns of the ties; n = none
+    above = top_v > t
+    cand_v = torch.cat([torch.where(above, top_v, float("-inf")), torch.where(tie_c < n, t.expand(-1, kb), float("-inf"))], dim=1)
+    cand_c = torch.cat([torch.where(above, top_c, n), tie_c], dim=1)
+    order = torch.sort(cand_c, dim=1, stable=True)                      # small [S, 2 kb] sorts: columns ascending ...
+    cand_v, cand_c = torch.gather(cand_v, 1, order.indices), order.values
+    order = torch.sort(cand_v, dim=1, descending=True, stable=True)     # ... then scores descending, ties keep the column order
+    return order.values[:, :kb], torch.gather(cand_c, 1, order.indices)[:, :kb]
+
+
 def _brute_force_f64(rig: Rig, qs, row_block, n_local: int, row_lo: int, k: int, multi: bool):
     """Exact top-k of the sampled queries `qs` (float64 [S, d]) over this rank's rows by a chunked FLOAT64 product, merged over the
     ranks when `multi`: the comparator of `verify`.  `row_block(lo, n)` -> rows [lo, lo + n) of the shard (any float dtype).
@@ -397,14 +431,21 @@ def _brute_force_f64(rig: Rig, qs, row_block, n_local: int, row_lo: int, k: int,
     li = torch.full((n_s, kk), -1, dtype=torch.int64, device=dev)
     for lo in range(0, n_local, GEN_CHUNK):
         blk = row_block(lo, min(GEN_CHUNK, n_local - lo)).double()
+        if os.environ.get("BENCH_TRACE"):
+            torch.cuda.synchronize(); _trace(f"bf: rows {lo} fetched")
         sc = qs @ blk.T
+        if os.environ.get("BENCH_TRACE"):
+            torch.cuda.synchronize(); _trace("bf: product")
         kb = min(kk, sc.shape[1])
-        ts, ti = torch.sort(sc, dim=1, descending=True, stable=True)
-        ts, ti = ts[:, :kb], ti[:, :kb]
+        ts, ti = _topk_ties_by_id(torch, sc, kb)
+        if os.environ.get("BENCH_TRACE"):
+            torch.cuda.synchronize(); _trace("bf: top-k")
         cs, ci = torch.cat([ls, ts], dim=1), torch.cat([li, ti + (lo + row_lo)], dim=1)
         top = torch.sort(cs, dim=1, descending=True, stable=True)
         ls, li = top.values[:, :kk], torch.gather(ci, 1, top.indices[:, :kk])
         del blk, sc
+    if os.environ.get("BENCH_TRACE"):
+        torch.cuda.synchronize(); _trace("bf: local done")
     if multi:
         pad_s = torch.full((n_s, k), float("-inf"), device=dev, dtype=torch.float64)
         pad_i = torch.full((n_s, k), -1, dtype=torch.int64, device=dev)
@@ -450,6 +491,7 @@ def integer_twin_check(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq:
     torch, dev, world = rig.torch, rig.dev, rig.world
     tdt = torch.float16 if dtype == "f16" else torch.bfloat16
     n_local = index.ntotal
+    _trace("twin: refill")
     index.reset()
 
     def twin_rows(lo, n):
@@ -461,7 +503,9 @@ def integer_twin_check(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq:
     g = torch.Generator(device=dev).manual_seed(778)
     q = torch.randint(-8, 9, (nq, dim), generator=g, device=dev, dtype=torch.int32).to(torch.float32 if index.exact_f32 else tdt)
     p = PackedTopk(nq, k, dev)
+    _trace("twin: search")
     index.search(q, k, id_base=row_lo, out=(p.scores, p.ids))
+    _trace("twin: brute force")
     fs, fi = p.scores, p.ids
     if multi:
         gathered = torch.empty((world * p.nbytes,), dtype=torch.uint8, device=dev)
@@ -471,6 +515,7 @@ def integer_twin_check(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq:
     sample = sorted(set(int(round(j * (nq - 1) / max(1, n_v - 1))) for j in range(n_v))) if n_v > 1 else [0]
     ref_s, ref_i = _brute_force_f64(rig, q[sample].double(), twin_rows, n_local, row_lo, k, multi)
     got_s, got_i = fs[sample].cpu(), fi[sample].cpu()
+    _trace("twin: compare")
     ties = int(sum((r[1:] == r[:-1]).sum() for r in ref_s))
     return {
         "ids_bit_exact": bool(torch.equal(got_i[:, : ref_i.shape[1]], ref_i)),
@@ -559,6 +604,7 @@ def run_workload(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, 
     fence()
     elapsed = time.perf_counter() - t0
     index.set_param("profile", 0)
+    _trace(f"timed region done: {elapsed:.3f} s")
     per_rank = None
     if multi:
         elapsed = rig.all_reduce_scalar(elapsed, "MAX")
@@ -578,11 +624,13 @@ def run_workload(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, 
         n_v = min(nq, max(1, verify_queries))
         sample = [int(round(j * (nq - 1) / max(1, n_v - 1))) for j in range(n_v)] if n_v > 1 else [0]
         sample = sorted(set(sample))
+        _trace("verify: stored rows")
         # (1) against the STORED (rounded) rows and queries: every fp16 x fp16 product is exact in fp64 and the 768-1024-term sums
         # carry ~1e-13 relative error, so `max_abs_score_diff` is the kernel's own fp32-accumulation error
         q_stored = queries[sample].to(tdt).double()
         ref_s, ref_i = _brute_force_f64(rig, q_stored, lambda lo, n: index.stored_rows(lo, n), n_local, row_lo, k, multi)
         stored = _compare_with(torch, fs, fi, sample, ref_s, ref_i, "float64 chunked product over the stored (rounded) rows and queries (ties -> smaller id)")
+        _trace("verify: unrounded rows")
         # (2) against the UNROUNDED float32 inputs the synthetic corpus was generated as - what the reference's float32 faiss index
         # would be searched with (build.py:65-73): the deviation a rounded store carries, and what the exact-f32 mode removes
         q32 = make_queries(torch, dev, torch.float32, data, nq, dim, rows)[sample].double()
@@ -590,6 +638,7 @@ def run_workload(rig: Rig, index, row_lo: int, *, rows: int, dim: int, nq: int, 
         ref_s, ref_i = _brute_force_f64(
             rig, q32, lambda lo, n: make_rows(torch, dev, torch.float32, data, c0 + lo // GEN_CHUNK, n, dim, rows), n_local, row_lo, k, multi)
         unrounded = _compare_with(torch, fs, fi, sample, ref_s, ref_i, "float64 chunked product over the UNROUNDED float32 rows and queries")
+        _trace("verify: done")
         verify = dict(unrounded if exact else stored)
         verify["vs_unrounded_inputs"] = {key: unrounded[key] for key in ("recall_at_k", "max_abs_score_diff", "rows_with_identical_id_order", "score_scale")}
         if exact:
@@ -770,6 +819,7 @@ def main() -> None:
         rig.ensure_group()
 
     n_total, d, nq, k = args.rows, args.dim, args.nq, args.k
+    _trace("group up; building the index")
     index, row_lo, t_build = build_index(rig, rows=n_total, dim=d, dtype=args.dtype, data=args.data, tile=args.tile, growth=args.growth,
                                          params=args.param, exact=args.exact_f32)
     m = run_workload(rig, index, row_lo, rows=n_total, dim=d, nq=nq, k=k, dtype=args.dtype, data=args.data, multi=multi,

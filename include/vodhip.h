@@ -133,7 +133,7 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
  *   rings, 8 / 9 = persistent 256x256 without / with the wave stagger), "small_chunk_tiles", "profile" (1 = HIP events around
  *   every filter launch), "ingest_threads" (CPU threads staging pageable host rows, 0 = auto), "kflags" (timing knobs of
  *   diagnostic builds), "exact_expand" (x100, VODHIP_EXACT_F32 stores: the scan lists k' = k * exact_expand / 100 + 16 rows per
- *   query; 0 = default: 125 for an fp16 store, 200 for bf16; speed only - results are exact for any value).
+ *   query; 0 = default: 110 for an fp16 store, 200 for bf16; speed only - results are exact for any value).
  * stats (of the search completed by the last vodhip_index_search_finish): "last_overflow" (a candidate list overflowed),
  *   "last_safe_reruns" (recovery passes run), "last_recovered_queries" (queries the first recovery pass re-searched),
  *   "last_chunks" (stages), "last_filter_launches", "last_filter_ns" (with "profile"), "last_recovery_launches",

@@ -45,7 +45,30 @@ def draw(rng):
     c["rng_seed"] = int(rng.integers(0, 2**31))
     # one trial in six goes through the one-process node index (`vodhip_node_index_*`): 1-5 shards, all on device 0
     c["node_shards"] = int(rng.choice([0, 0, 0, 0, 0, 1, 2, 3, 5])) if rng.random() < 0.5 else 0
+    # one trial in three runs a VODHIP_EXACT_F32 store; two thirds of those on inputs the scan dtype CANNOT represent ("lossy": rows or
+    # queries with more significant bits than fp16 / bf16 keep, sized so that every float32 partial sum is still exact) - the result must
+    # equal the float64 oracle on the UNROUNDED values bit for bit; "exact_expand" 1 = the scan lists only k rows (band pass every time)
+    c["exact"] = bool(rng.random() < 0.34)
+    c["lossy"] = str(rng.choice(["none", "rows", "queries"])) if c["exact"] else "none"
+    c["exact_expand"] = int(rng.choice([0, 0, 1, 100, 300])) if c["exact"] else 0
+    if c["lossy"] != "none" and c["dtype"] == "f16":
+        c["d"] = min(c["d"], 128)  # wide values x 3-bit values x d terms must stay below 2^24
     return c
+
+
+def lossy_inputs(rng, c, x, q):
+    """Integer inputs whose products and partial sums are exact in float32 but which the scan dtype rounds: the wide side has 13 (fp16
+    store, d <= 128) or 10 (bf16) significant bits, the other side 3."""
+    wide = 4096 if c["dtype"] == "f16" else 512
+    if c["lossy"] == "rows":
+        scale = rng.integers(1, wide // 8 + 1, size=(x.shape[0], 1)).astype(np.float32)  # keeps the trial's row structure (ties, duplicates, order)
+        x = np.clip(x, -8, 8) * scale + rng.integers(-3, 4, size=x.shape).astype(np.float32)
+        x = np.clip(x, -wide, wide)
+        q = np.clip(q, -4, 4)
+    elif c["lossy"] == "queries":
+        q = rng.integers(-wide, wide + 1, size=q.shape).astype(np.float32)
+        x = np.clip(x, -4, 4)
+    return x, q
 
 
 def make_rows(rng, kind, n, d):
@@ -71,10 +94,13 @@ def run_node_trial(c):
     lim = 4 if c["dtype"] == "bf16" else 8
     x = np.clip(make_rows(rng, c["data"], n, d), -lim, lim)
     q = rng.integers(-lim, lim + 1, size=(nq, d)).astype(np.float32)
+    x, q = lossy_inputs(rng, c, x, q)
     labels = subset = None
-    with HipNodeIndex(d, n, [0] * c["node_shards"], dtype=tdt) as nx:
+    with HipNodeIndex(d, n, [0] * c["node_shards"], dtype=tdt, exact_f32=c["exact"]) as nx:
         if c["cand_cap"] and c["cand_cap"] >= k:
             nx.set_param("cand_cap", c["cand_cap"])
+        if c["exact_expand"]:
+            nx.set_param("exact_expand", c["exact_expand"])
         for key in ("dense_rows", "sample_div", "growth"):
             if c[key]:
                 nx.set_param(key, c[key])
@@ -114,7 +140,7 @@ def run_node_trial(c):
     assert np.array_equal(gi, ri), f"node index ({c['node_shards']} shards): ids differ: first bad row {np.argwhere((gi != ri).any(axis=1))[:3].ravel().tolist()}"
     assert np.array_equal(gs, rs), "node index: scores differ"
     assert np.array_equal(gi2, gi) and np.array_equal(gs2, gs), "node index: second search differs"
-    return {"last_chunks": 0, "last_safe_reruns": 0, "last_recovered_queries": 0}
+    return {"last_chunks": 0, "last_safe_reruns": 0, "last_recovered_queries": 0, "last_exact_band_queries": 0}
 
 
 def run_trial(c):
@@ -126,10 +152,13 @@ def run_trial(c):
     lim = 4 if c["dtype"] == "bf16" else 8  # bf16 keeps 8 significant bits: stay exact
     x = np.clip(make_rows(rng, c["data"], n, d), -lim, lim)
     q = rng.integers(-lim, lim + 1, size=(nq, d)).astype(np.float32)
+    x, q = lossy_inputs(rng, c, x, q)
     labels = subset = None
-    with HipFlatIndex(d, n, dtype=tdt, device=0) as ix:
+    with HipFlatIndex(d, n, dtype=tdt, device=0, exact_f32=c["exact"]) as ix:
         if c["cand_cap"] and c["cand_cap"] >= k:
             ix.set_param("cand_cap", c["cand_cap"])
+        if c["exact_expand"]:
+            ix.set_param("exact_expand", c["exact_expand"])
         for key in ("dense_rows", "sample_div", "growth"):
             if c[key]:
                 ix.set_param(key, c[key])
@@ -158,7 +187,7 @@ def run_trial(c):
         tq = torch.from_numpy(q).cuda()
         s, i = ix.search(tq, k, id_base=c["id_base"], subset=subset)
         s2, i2 = ix.search(tq, k, id_base=c["id_base"], subset=subset)  # determinism / stale workspace state
-        stats = {key: ix.get_stat(key) for key in ("last_chunks", "last_safe_reruns", "last_recovered_queries")}
+        stats = {key: ix.get_stat(key) for key in ("last_chunks", "last_safe_reruns", "last_recovered_queries", "last_exact_band_queries")}
     full = q.astype(np.float64) @ x.astype(np.float64).T
     if subset is not None:
         for r in range(nq):
@@ -185,6 +214,7 @@ def main():
     fails = 0
     done = 0
     recovered = 0
+    n_exact = n_band = 0
     for t in range(a.trials):
         if time.time() - t0 > a.seconds:
             break
@@ -192,13 +222,16 @@ def main():
         try:
             st = run_trial(c)
             recovered += 1 if st["last_safe_reruns"] else 0
+            n_exact += 1 if c["exact"] else 0
+            n_band += 1 if st["last_exact_band_queries"] else 0
         except Exception as e:  # noqa: BLE001
             fails += 1
             print(f"FAIL trial {t}: {c}\n  {type(e).__name__}: {e}", flush=True)
             if not isinstance(e, AssertionError):
                 traceback.print_exc()
         done += 1
-    print(f"fuzz: {done} trials, {fails} failures, {recovered} trials needed a recovery pass, {time.time() - t0:.0f} s, seed {a.seed}")
+    print(f"fuzz: {done} trials, {fails} failures, {recovered} trials needed a recovery pass, {n_exact} on exact-f32 stores "
+          f"({n_band} of them through a band pass), {time.time() - t0:.0f} s, seed {a.seed}")
     sys.exit(1 if fails else 0)
 
 

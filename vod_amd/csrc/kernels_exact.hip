@@ -68,13 +68,15 @@ __device__ __forceinline__ float round_to_store(float f, int store_dtype) {
     return (float)(__bf16)f;
 }
 
-// descending bitonic sort of P (power of two, >= 2) keys in LDS by 256 threads
+constexpr int XT = 512;  // threads of the re-scoring workgroup: 8 waves x 4 rows = 32 float32 rows in flight per query
+
+// descending bitonic sort of P (power of two, >= 2) keys in LDS by XT threads
 __device__ __forceinline__ void sort_desc_lds(key_t64* keys, int P, int tid) {
     const int half = P >> 1;
     for (int size = 2; size <= P; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (int t = tid; t < half; t += 256) {
+            for (int t = tid; t < half; t += XT) {
                 const int pos = 2 * t - (t & (stride - 1));
                 const key_t64 a = keys[pos], b = keys[pos + stride];
                 const bool desc = (pos & size) == 0;
@@ -102,18 +104,41 @@ __global__ __launch_bounds__(256) void ingest_exact_kernel(const void* __restric
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
     float n2 = 0.f, d2 = 0.f;
+    const bool vec = (dim & 7) == 0 && ((uintptr_t)src & 31) == 0;  // whole 8-element groups, 16/32-byte aligned: vector loads
     for (int64_t c0 = (int64_t)lane * 8; c0 < stride; c0 += 512) {
         uint16_t h[8];
         float f[8];
+        float in[8];
+        if (vec && c0 < dim) {
+            if constexpr (SRC == 2) {
+                const float4 a = *reinterpret_cast<const float4*>((const float*)src + row * dim + c0);
+                const float4 b = *reinterpret_cast<const float4*>((const float*)src + row * dim + c0 + 4);
+                in[0] = a.x, in[1] = a.y, in[2] = a.z, in[3] = a.w, in[4] = b.x, in[5] = b.y, in[6] = b.z, in[7] = b.w;
+            } else {
+                const uint4 raw = *reinterpret_cast<const uint4*>((const uint16_t*)src + row * dim + c0);
+                const uint16_t* hw = reinterpret_cast<const uint16_t*>(&raw);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (SRC == 0) in[e] = (float)__builtin_bit_cast(_Float16, hw[e]);
+                    else in[e] = (float)__builtin_bit_cast(__bf16, hw[e]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int64_t c = c0 + e;
+                float v = 0.f;
+                if (c < dim) {
+                    if constexpr (SRC == 2) v = ((const float*)src)[row * dim + c];
+                    else if constexpr (SRC == 0) v = (float)(((const _Float16*)src)[row * dim + c]);
+                    else v = (float)(((const __bf16*)src)[row * dim + c]);
+                }
+                in[e] = v;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int64_t c = c0 + e;
-            float v = 0.f;
-            if (c < dim) {
-                if constexpr (SRC == 2) v = ((const float*)src)[row * dim + c];
-                else if constexpr (SRC == 0) v = (float)(((const _Float16*)src)[row * dim + c]);
-                else v = (float)(((const __bf16*)src)[row * dim + c]);
-            }
+            const float v = in[e];
             f[e] = v;
             float r;
             if constexpr (DST == 0) {
@@ -134,9 +159,12 @@ __global__ __launch_bounds__(256) void ingest_exact_kernel(const void* __restric
     }
     n2 = wave_sum_fixed(n2);
     d2 = wave_sum_fixed(d2);
+    // (atomics on ONE address execute one after the other, ~3 ns each: only a row that would raise a maximum issues one - after the
+    // first few hundred rows almost none does)
     if (lane == 0 && n2 < __builtin_inff()) {  // (false for NaN too)
-        atomicMax(stats + 0, __float_as_uint(n2));
-        if (d2 < __builtin_inff()) atomicMax(stats + 1, __float_as_uint(d2));
+        if (__float_as_uint(n2) > __hip_atomic_load(stats + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(stats + 0, __float_as_uint(n2));
+        if (d2 < __builtin_inff() && __float_as_uint(d2) > __hip_atomic_load(stats + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(stats + 1, __float_as_uint(d2));
     }
 }
 
@@ -163,11 +191,11 @@ hipError_t launch_ingest_exact(const void* src, int src_dtype, int64_t n_rows, i
 //         folded into the running exact top-k kept in the caller's output rows (EXACT_FIRST: the rows are taken as empty); the
 //         scan threshold of the next stages rises to (k-th exact score - eps) when that is higher; a list that lost
 //         candidates flags the query (the host splits the pass).
-__global__ __launch_bounds__(256) void exact_rescore_kernel(ExactArgs a) {
+__global__ __launch_bounds__(XT) void exact_rescore_kernel(ExactArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qs = reinterpret_cast<float*>(smem);
     key_t64* kb = reinterpret_cast<key_t64*>(smem + (size_t)a.dim_pad * sizeof(float));
-    __shared__ float red[8];
+    __shared__ float red[2 * (XT / 64)];
     const int r = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t qo = a.q_map ? (int64_t)a.q_map[r] : (int64_t)r;
@@ -177,7 +205,7 @@ __global__ __launch_bounds__(256) void exact_rescore_kernel(ExactArgs a) {
 
     // 1. the query, unrounded, and the two norms of the bound
     float n2 = 0.f, d2 = 0.f;
-    for (int c = tid; c < a.dim_pad; c += 256) {
+    for (int c = tid; c < a.dim_pad; c += XT) {
         float f = 0.f;
         if (c < a.dim) {
             if (a.q_dtype == 2) f = ((const float*)a.q_src)[qo * a.dim + c];
@@ -193,11 +221,15 @@ __global__ __launch_bounds__(256) void exact_rescore_kernel(ExactArgs a) {
     d2 = wave_sum_fixed(d2);
     if (lane == 0) {
         red[wave] = n2;
-        red[4 + wave] = d2;
+        red[XT / 64 + wave] = d2;
     }
     __syncthreads();
-    n2 = (red[0] + red[1]) + (red[2] + red[3]);
-    d2 = (red[4] + red[5]) + (red[6] + red[7]);
+    n2 = d2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < XT / 64; ++w) {
+        n2 += red[w];
+        d2 += red[XT / 64 + w];
+    }
     // |s - s~| <= |q - q~| |x| + |q~| |x - x~|, plus the rounding of the two fp32 summations (each below dim_pad * 2^-23 * |q| |x|
     // whatever the order), everything inflated by 2^-9 for the float arithmetic of the norms themselves
     const float xn = __builtin_sqrtf(__uint_as_float(a.stats[0])), dxn = __builtin_sqrtf(__uint_as_float(a.stats[1]));
@@ -207,7 +239,7 @@ __global__ __launch_bounds__(256) void exact_rescore_kernel(ExactArgs a) {
     // 2. candidates, P - KR at a time behind the running top-k (KR slots)
     const int KR = cand_mode ? a.kr : 0;
     if (cand_mode)
-        for (int c = tid; c < KR; c += 256) {
+        for (int c = tid; c < KR; c += XT) {
             key_t64 key = 0ull;
             if (!first && c < k) {
                 const int64_t id = a.out_ids[qo * k + c];
@@ -231,7 +263,7 @@ __global__ __launch_bounds__(256) void exact_rescore_kernel(ExactArgs a) {
     int done = 0;
     do {
         const int take = min(CH, n_total - done);
-        for (int j0 = wave * 4; j0 < take; j0 += 16) {
+        for (int j0 = wave * 4; j0 < take; j0 += 4 * (XT / 64)) {
             int rows[4];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -258,7 +290,7 @@ __global__ __launch_bounds__(256) void exact_rescore_kernel(ExactArgs a) {
         }
         int P_eff = 2;
         while (P_eff < KR + take) P_eff <<= 1;
-        for (int c = KR + take + tid; c < P_eff; c += 256) kb[c] = 0ull;
+        for (int c = KR + take + tid; c < P_eff; c += XT) kb[c] = 0ull;
         sort_desc_lds(kb, P_eff, tid);  // (starts and ends with a barrier)
         done += take;
     } while (done < n_total);
@@ -266,7 +298,7 @@ __global__ __launch_bounds__(256) void exact_rescore_kernel(ExactArgs a) {
     // 3. results
     const key_t64 kth = kb[k - 1];  // (k <= KR in CAND mode, k <= kx <= P in LIST mode; slots behind the candidates are zero)
     const float s_k = kth ? unflip_f32((unsigned)(kth >> 32)) : -__builtin_inff();
-    for (int c = tid; c < k; c += 256) {
+    for (int c = tid; c < k; c += XT) {
         const key_t64 key = kb[c];
         a.out_scores[qo * k + c] = key ? unflip_f32((unsigned)(key >> 32)) : -__builtin_inff();
         a.out_ids[qo * k + c] = key ? a.id_base + (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : -1;
@@ -300,7 +332,7 @@ hipError_t launch_exact_rescore(const ExactArgs& a, int64_t nq, hipStream_t stre
     if (nq <= 0) return hipSuccess;
     const int bytes = (int)((size_t)a.dim_pad * sizeof(float) + (size_t)a.P * sizeof(key_t64));
     if (hipError_t e = allow_dynamic_lds((const void*)exact_rescore_kernel, bytes); e != hipSuccess) return e;
-    hipLaunchKernelGGL(exact_rescore_kernel, dim3((unsigned)nq), dim3(256), bytes, stream, a);
+    hipLaunchKernelGGL(exact_rescore_kernel, dim3((unsigned)nq), dim3(XT), bytes, stream, a);
     return hipGetLastError();
 }
 

@@ -1082,7 +1082,10 @@ __global__ void mips_prepare_kernel(const void* __restrict__ q_src, int q_dtype,
         thr_s[i] = ts;
         thr_key[i] = tk;
     }
-    if (i == 0 && clear_overflow) *overflow = 0u;
+    if (i == 0 && clear_overflow) {
+        overflow[0] = 0u;
+        overflow[1] = 0u;  // exact mode's "some list did not prove complete" word (kernels_exact.hip)
+    }
 }
 
 hipError_t launch_search_prepare(const SearchWorkspace& ws, const void* q_src, int q_dtype, int64_t nq, int64_t dim,

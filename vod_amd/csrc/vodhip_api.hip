@@ -70,6 +70,7 @@ struct PendingSearch {
     size_t ev_begin = 0, ev_end = 0;  // profile events of this search in ev_pool
     int kx = 0;                    // exact mode: the scan's list length k' (> k; 0 = not an exact-mode search)
     bool band = false;             // exact mode: a BAND pass - candidates are re-scored into the caller's rows (kernels_exact.hip)
+    bool defer_flags = false;      // exact mode: the flag words are fetched (and the slot's event recorded) behind the re-scoring launch
 };
 
 constexpr int MAX_IN_FLIGHT = 4;  // searches that may be enqueued before the oldest is finished
@@ -102,12 +103,10 @@ struct vodhip_index {
     size_t x_list_cap[4] = {0, 0, 0, 0};     // elements
     float* x_eps = nullptr;                  // device [MAX_IN_FLIGHT][OVF_ROWS]: the per-query bound of a slot's search
     unsigned int* x_flag_q = nullptr;        // device [MAX_IN_FLIGHT][OVF_ROWS]: the queries whose list did not prove complete
-    unsigned int* x_flag_word = nullptr;     // device [MAX_IN_FLIGHT]
-    unsigned int* x_flag_host = nullptr;     // pinned [MAX_IN_FLIGHT]
-    int64_t exact_expand_x100 = 0;           // k' = k * this / 100 (+ 16); 0 = by store dtype (fp16: 125, bf16: 200)
+    int64_t exact_expand_x100 = 0;           // k' = k * this / 100 (+ 16); 0 = by store dtype (fp16: 110, bf16: 200)
     int64_t last_exact_kx = 0, last_exact_band_queries = 0, last_exact_band_passes = 0;
     SearchWorkspace ws;
-    unsigned int* overflow_host = nullptr;  // pinned, one word per in-flight slot
+    unsigned int* overflow_host = nullptr;  // pinned, two words per in-flight slot: [0] a candidate list overflowed, [1] exact mode: some list did not prove complete
     unsigned int* ovf_q = nullptr;          // device [MAX_IN_FLIGHT][OVF_ROWS]: which queries of a slot's search overflowed
     int* q_map = nullptr;                   // device [MAX_IN_FLIGHT][OVF_ROWS]: the rows a slot's recovery pass re-searches
     hipEvent_t done[MAX_IN_FLIGHT] = {};    // recorded after a search's overflow word is copied back
@@ -167,7 +166,7 @@ int ensure_workspace(vodhip_index* ix, int64_t nq_pad, int64_t cap, int64_t kp) 
     HIP_OK(hipMalloc((void**)&w.cnt, (size_t)nq_cap * CNT_STRIDE * sizeof(unsigned int)));
     HIP_OK(hipMalloc((void**)&w.thr_s, (size_t)nq_cap * sizeof(float)));
     HIP_OK(hipMalloc((void**)&w.thr_key, (size_t)nq_cap * sizeof(key_t64)));
-    HIP_OK(hipMalloc((void**)&w.overflow, sizeof(unsigned int)));
+    HIP_OK(hipMalloc((void**)&w.overflow, 2 * sizeof(unsigned int)));  // [0] overflow, [1] exact mode's "incomplete" word
     w.nq_cap = nq_cap;
     w.cap = cap;
     w.kp = kp;
@@ -414,7 +413,8 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
         if (stages.empty())  // empty index: nothing was selected, the cleared top-k leaves as pads
             HIP_OK(launch_output(ws, nq, k, ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k, stream));
     }
-    HIP_OK(hipMemcpyAsync(ix->overflow_host + ps.slot, ws.overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    if (ps.defer_flags) return 0;
+    HIP_OK(hipMemcpyAsync(ix->overflow_host + 2 * ps.slot, ws.overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipEventRecord(ix->done[ps.slot], stream));
     return 0;
 }
@@ -431,9 +431,10 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, int rec
 // k-th score: ~5 % more than k for an fp16 store of N(0, 1) x 768 rows, ~70 % more for bf16 x 1024 - profiles/r05_exact_*.json);
 // a query whose list does not is searched again as a band pass, so this is a speed knob, never a correctness one
 int exact_kx(const vodhip_index* ix, int k) {
-    const int64_t x100 = ix->exact_expand_x100 > 0 ? ix->exact_expand_x100 : (ix->dtype == VODHIP_F16 ? 125 : 200);
+    const int64_t x100 = ix->exact_expand_x100 > 0 ? ix->exact_expand_x100 : (ix->dtype == VODHIP_F16 ? 110 : 200);
     const int64_t kx = ((int64_t)k * x100 + 99) / 100 + 16;
-    return (int)std::min<int64_t>(VODHIP_MAX_K, std::max<int64_t>(kx, k));
+    const int64_t fits = std::max<int64_t>(k, ix->cand_cap / ROW_ALIGN * ROW_ALIGN);  // the scan needs cand_cap >= its list length
+    return (int)std::min<int64_t>(std::min<int64_t>(VODHIP_MAX_K, fits), std::max<int64_t>(kx, k));
 }
 
 // the scan behind an exact-mode search: same queries, k' results into the slot's list buffers, LOCAL ids
@@ -444,10 +445,12 @@ PendingSearch exact_inner(const vodhip_index* ix, const PendingSearch& ps) {
     in.id_base = 0;
     in.out_scores = ix->x_list_s[ps.slot];
     in.out_ids = ix->x_list_i[ps.slot];
+    in.defer_flags = false;
     return in;
 }
 
-// re-score the list of every query of `ps` (LIST mode), then fetch the "some query is incomplete" word and re-arm the slot's event
+// re-score the list of every query of `ps` (LIST mode), then fetch BOTH flag words (the scan's overflow word and the "some query is
+// incomplete" word the re-scoring sets: the head of every search pass clears both) and record the slot's event
 int enqueue_exact_list(vodhip_index* ix, const PendingSearch& ps, hipStream_t stream) {
     ExactArgs xa;
     xa.plane = ix->data32;
@@ -469,11 +472,10 @@ int enqueue_exact_list(vodhip_index* ix, const PendingSearch& ps, hipStream_t st
     xa.out_scores = ps.out_scores;
     xa.out_ids = ps.out_ids;
     xa.eps = ix->x_eps + (size_t)ps.slot * OVF_ROWS;
-    xa.flag_word = ix->x_flag_word + ps.slot;
+    xa.flag_word = ix->ws.overflow + 1;
     xa.flag_q = ix->x_flag_q + (size_t)ps.slot * OVF_ROWS;
-    HIP_OK(hipMemsetAsync(ix->x_flag_word + ps.slot, 0, sizeof(unsigned int), stream));
     HIP_OK(launch_exact_rescore(xa, ps.nq, stream));
-    HIP_OK(hipMemcpyAsync(ix->x_flag_host + ps.slot, ix->x_flag_word + ps.slot, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(ix->overflow_host + 2 * ps.slot, ix->ws.overflow, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipEventRecord(ix->done[ps.slot], stream));
     return 0;
 }
@@ -529,7 +531,7 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->ovf_q, MAX_IN_FLIGHT * OVF_ROWS * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc((void**)&ix->q_map, MAX_IN_FLIGHT * OVF_ROWS * sizeof(int));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ix->overflow_host, MAX_IN_FLIGHT * sizeof(unsigned int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ix->overflow_host, 2 * MAX_IN_FLIGHT * sizeof(unsigned int), hipHostMallocDefault);
     for (int i = 0; i < MAX_IN_FLIGHT && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ix->done[i], hipEventDisableTiming);
     if (exact && e == hipSuccess) {
         // the float32 plane (rows are written whole, zero padded columns included: no fill needed) + the bound's bookkeeping
@@ -548,11 +550,7 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
         if (e == hipSuccess) e = hipMemset(ix->norm_stats, 0, 2 * sizeof(unsigned int));
         if (e == hipSuccess) e = hipMalloc((void**)&ix->x_eps, MAX_IN_FLIGHT * OVF_ROWS * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&ix->x_flag_q, MAX_IN_FLIGHT * OVF_ROWS * sizeof(unsigned int));
-        if (e == hipSuccess) e = hipMalloc((void**)&ix->x_flag_word, MAX_IN_FLIGHT * sizeof(unsigned int));
-        if (e == hipSuccess) e = hipHostMalloc((void**)&ix->x_flag_host, MAX_IN_FLIGHT * sizeof(unsigned int), hipHostMallocDefault);
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-        if (e == hipSuccess)
-            for (int i = 0; i < MAX_IN_FLIGHT; ++i) ix->x_flag_host[i] = 0;
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -561,7 +559,7 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
         delete ix;
         return fail("store initialisation failed: %s", hipGetErrorString(e));
     }
-    for (int i = 0; i < MAX_IN_FLIGHT; ++i) ix->overflow_host[i] = 0;
+    for (int i = 0; i < 2 * MAX_IN_FLIGHT; ++i) ix->overflow_host[i] = 0;
     *out = ix;
     return 0;
 }
@@ -584,8 +582,6 @@ int vodhip_index_destroy(vodhip_index_t* ix) {
     (void)hipFree(ix->norm_stats);
     (void)hipFree(ix->x_eps);
     (void)hipFree(ix->x_flag_q);
-    (void)hipFree(ix->x_flag_word);
-    (void)hipHostFree(ix->x_flag_host);
     for (int i = 0; i < MAX_IN_FLIGHT; ++i) {
         (void)hipFree(ix->x_list_s[i]);
         (void)hipFree(ix->x_list_i[i]);
@@ -813,9 +809,10 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
         // exact mode: the scan fills the slot's top-k' list, the re-scoring kernel behind it writes the caller's rows (no host round
         // trip in between: the list is re-scored even if it later turns out that a candidate list overflowed - finish repeats it then)
         ps.kx = exact_kx(ix, k);
-        if (ix->cand_cap < ps.kx) return fail("cand_cap too small for the exact-mode list of %d rows", ps.kx);
         if (exact_reserve_lists(ix, ps.slot, (size_t)nq * ps.kx)) return -1;
-        if (enqueue_search(ix, exact_inner(ix, ps), ix->force_safe != 0, 0, (hipStream_t)stream_)) return -1;
+        PendingSearch in = exact_inner(ix, ps);
+        in.defer_flags = true;  // ONE copy of both flag words, behind the re-scoring launch
+        if (enqueue_search(ix, in, ix->force_safe != 0, 0, (hipStream_t)stream_)) return -1;
         if (enqueue_exact_list(ix, ps, (hipStream_t)stream_)) {
             (void)hipStreamSynchronize((hipStream_t)stream_);
             return -1;
@@ -838,7 +835,7 @@ namespace {
 int recover_overflow(vodhip_index* ix, const PendingSearch& ps, hipStream_t stream) {
     PendingSearch rs = ps;  // what the recovery passes search: the whole batch, or only the queries that overflowed
     int pass = 0;
-    while (ix->overflow_host[ps.slot]) {
+    while (ix->overflow_host[2 * ps.slot]) {
         if (++pass > 40) return fail("internal error: the exhaustive schedule overflowed");
         ix->last_overflow = 1;
         ix->last_safe_reruns += 1;
@@ -915,7 +912,7 @@ int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
         }
         // (2) the lists that did not prove complete: those queries run a BAND pass (every row whose scan score is within eps of
         // the k-th exact score is re-scored); its own candidate lists may overflow, which splits the pass like any recovery
-        if (ix->x_flag_host[ps.slot]) {
+        if (ix->overflow_host[2 * ps.slot + 1]) {
             std::vector<unsigned int> flags((size_t)ps.nq);
             HIP_OK(hipMemcpy(flags.data(), ix->x_flag_q + (size_t)ps.slot * OVF_ROWS, (size_t)ps.nq * sizeof(unsigned int), hipMemcpyDeviceToHost));
             std::vector<int> rows;
