@@ -188,8 +188,14 @@ static int serving_case(vodhip_index_t* ix, const float* q, int64_t nq, int64_t 
             return 1;
         }
     }
-    if (vodhip_client_search(cli, q, VODHIP_F32, nq, d, 0, 0, 30.0, s, id) < 400 || !strstr(vodhip_client_last_body(cli), "detail")) {
-        fprintf(stderr, "client: top_k = 0 did not come back as an error reply\n");
+    /* top_k outside [1, VODHIP_MAX_K] never leaves the client (a reply of that width would not fit the caller's [nq, k] buffers) ... */
+    if (vodhip_client_search(cli, q, VODHIP_F32, nq, d, 0, 0, 30.0, s, id) != -1 || !strstr(vodhip_last_error(), "out of range")) {
+        fprintf(stderr, "client: top_k = 0 was not refused\n");
+        return 1;
+    }
+    /* ... and a request the SERVER refuses (a dimension the store does not have) comes back as its HTTP status + {"detail": ...} */
+    if (vodhip_client_search(cli, q, VODHIP_F32, nq - 1, d + 1, k, 0, 30.0, s, id) < 400 || !strstr(vodhip_client_last_body(cli), "detail")) {
+        fprintf(stderr, "client: a wrong dimension did not come back as an error reply\n");
         return 1;
     }
     CHECK(vodhip_client_destroy(cli));
