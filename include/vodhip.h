@@ -132,7 +132,9 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
  *   "force_safe" (1 = exhaustive schedule: dense chunks of <= cand_cap rows), "tile" (0 = auto; 1 = 128x128, 42 / 46 = small-batch
  *   rings, 8 / 9 = persistent 256x256 without / with the wave stagger), "small_chunk_tiles", "profile" (1 = HIP events around
  *   every filter launch), "ingest_threads" (CPU threads staging pageable host rows, 0 = auto), "kflags" (timing knobs of
- *   diagnostic builds), "exact_expand" (x100, VODHIP_EXACT_F32 stores: the scan lists k' = k * exact_expand / 100 + 16 rows per
+ *   diagnostic builds), "tile_order" (0 = default: the FILTER stages of a search walk the store's 256-row tiles in a low-discrepancy
+ *   order, so that every stage samples the whole store whatever order the rows were added in; 1 = in row order; results are identical),
+ *   "exact_expand" (x100, VODHIP_EXACT_F32 stores: the scan lists k' = k * exact_expand / 100 + 16 rows per
  *   query; 0 = default: 110 for an fp16 store, 200 for bf16; speed only - results are exact for any value).
  * stats (of the search completed by the last vodhip_index_search_finish): "last_overflow" (a candidate list overflowed),
  *   "last_safe_reruns" (recovery passes run), "last_recovered_queries" (queries the first recovery pass re-searched),

@@ -158,9 +158,13 @@ def test_overflow_recovery_stays_exact(nq):
     q[:, 0] = 1
     q[1::4, 0] = -1
     q[2::4, 1] = 3
-    with _index(x, cand_cap=512, dense_rows=256) as ix:
+    # (stages in ROW order: on this score-sorted store every row beats the threshold its stage starts with - the overflow this test is
+    # about; the default low-discrepancy stage order calibrates every stage on the whole store and does not overflow here)
+    with _index(x, cand_cap=512, dense_rows=256, tile_order=1) as ix:
         _assert_exact(ix, q, x, 40)
         assert ix.get_stat("last_overflow") == 1 and ix.get_stat("last_safe_reruns") >= 1
+    with _index(x, cand_cap=512, dense_rows=256) as ix:
+        _assert_exact(ix, q, x, 40)
     with _index(x) as ix:  # default capacity: same answer, and the strided bootstrap sample needs no recovery
         _assert_exact(ix, q, x, 40)
         assert ix.get_stat("last_overflow") == 0
@@ -757,3 +761,32 @@ def test_merge_of_more_than_8192_entries_runs_in_levels():
         rs, ri = merge_shard_topk(list(scores), list(ids), k_out)
         np.testing.assert_array_equal(gi.cpu().numpy(), ri)
         np.testing.assert_array_equal(gs.cpu().numpy(), rs)
+
+
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("n", [70_001, 131_072, 2_303])
+def test_stage_tile_order_does_not_change_the_result(n, tile):
+    """FILTER stages walk the store's 256-row tiles in a low-discrepancy order by default (`tile_order` 0) or in row order (1): ids and
+    scores are identical, on a score-sorted store (where the ORDER decides how many survivors a stage emits), with a partly filled
+    last tile, an id base, a subset filter and rows added in pieces - and equal to the oracle."""
+    rng = np.random.default_rng(n + tile)
+    d, nq, k = 96, (60 if tile in (1, 42, 46) else 290), 33
+    x = rng.integers(-8, 9, size=(n, d)).astype(np.float16)
+    w = rng.integers(-8, 9, size=(d,)).astype(np.float32)
+    x = x[np.argsort(x.astype(np.float32) @ w, kind="stable")]  # rows sorted by their score against one direction
+    q = np.clip(w[None, :] + rng.integers(-2, 3, size=(nq, d)), -8, 8).astype(np.float16)  # ... which the queries look along
+    labels = rng.integers(0, 4, size=n).astype(np.int32)
+    subset = np.full((nq, 1), -1, dtype=np.int32)
+    subset[::3, 0] = 2
+    res = []
+    for order in (0, 1):
+        with _index(x[:1000], capacity=n, tile=tile, tile_order=order) as ix:
+            ix.add(x[1000:])
+            ix.set_row_labels(labels)
+            res.append([t.cpu().numpy() for t in ix.search(torch.from_numpy(q).cuda(), k, id_base=7)]
+                       + [t.cpu().numpy() for t in ix.search(torch.from_numpy(q).cuda(), k, subset=subset)])
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a, b)
+    rs, ri = _oracle(q, x, k, id_base=7)
+    np.testing.assert_array_equal(res[0][1], ri)
+    np.testing.assert_array_equal(res[0][0], rs)

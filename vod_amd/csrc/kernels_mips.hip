@@ -78,7 +78,8 @@ void mips_filter_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    const int x0 = row_begin + xt * BM;  // first corpus row of the tile (FILTER / DENSE)
+    // first corpus row of the tile (FILTER: through the stage order of FilterExtra; DENSE: contiguous)
+    const int x0 = MODE == MODE_FILTER ? filter_tile_row0(ex, row_begin, xt, BM) : row_begin + xt * BM;
     const int q0 = qt * BN;              // first query of the tile
 
     // per-lane LDS-DMA source pointers: lane -> (row = base + lane/8, 16-B slot = lane%8).  Slot s of row r holds
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
 #pragma unroll
     for (int t = 0; t < NA; ++t) {
         const int r = (wave * NA + t) * RPI + st_row;
-        size_t grow = (size_t)row_begin + (size_t)(abl_l2hot ? (xt0 & 15) : xt0) * BM + r;
+        size_t grow = (size_t)filter_tile_row0(ex, row_begin, abl_l2hot ? (xt0 & 15) : xt0, BM) + r;
         if constexpr (MODE == MODE_GMAX) {
             // tile row r = wm'*128 + i*16 + 4*fq' + rr is member (i, rr) of lane group (wm', fq'): sample index =
             // member * n_groups + group id, i.e. every group holds ONE row of each of 32 strata of the store
@@ -534,19 +535,39 @@ __global__ __launch_bounds__(512, 2) void mips_filter16p_kernel(
     };
 
     // what slice g+1 is (fetched during slice g): the next slice of this tile, or slice 0 of the next tile
+    int super_cur = 0, super_epi = 0, perm_inc = 0;  // permuted stage order: super-tile being fetched / multiplied, position step mod T
+    if (MODE == MODE_FILTER && ex.perm_mod > 0) {
+        super_cur = filter_tile_row0(ex, row_begin, xt0, BM) / BM;
+        perm_inc = (int)(((unsigned long long)xt_step * (unsigned long long)ex.perm_mul) % (unsigned long long)ex.perm_mod);
+    }
     auto next_fetch = [&](int it, int t, bool& pre, int& kbyte) {
         pre = true;
         kbyte = (t + 1) * ROW_BYTES;
         if (t + 1 == nk) {
             kbyte = 0;
+            super_epi = super_cur;
             pre = it + 1 < n_my;
             if (pre) {
+                long long step = (long long)tile_step_bytes;
+                if (MODE == MODE_FILTER && ex.perm_mod > 0 && !abl_l2hot) {
+                    // the next position's super-tile lies anywhere in the store: (p + xt_step) * P mod T = current + perm_inc (mod T)
+                    int nxt = super_cur + perm_inc;
+                    if (nxt >= ex.perm_mod) nxt -= ex.perm_mod;
+                    step = (long long)(nxt - super_cur) * (long long)BM * (long long)dim_pad * 2;
+                    super_cur = nxt;
+                }
 #pragma unroll
-                for (int u = 0; u < NA; ++u) a_src[u] += tile_step_bytes;
+                for (int u = 0; u < NA; ++u) a_src[u] += step;
             }
         }
     };
-    auto tile_row0 = [&](int it) { return row_begin + (xt0 + it * xt_step) * BM; };
+    // first row of tile `it` of this workgroup.  With the permuted stage order the non-staggered loop keeps it incrementally (the epilogue
+    // of tile `it` runs right after the fetch stream moved on to tile it + 1: `super_epi` is the value before that step); the staggered
+    // variant, whose epilogue is deferred by a slice, recomputes it
+    auto tile_row0 = [&](int it) {
+        if (MODE == MODE_FILTER && ex.perm_mod > 0) return STAGGER ? filter_tile_row0(ex, row_begin, xt0 + it * xt_step, BM) : super_epi * BM;
+        return row_begin + (xt0 + it * xt_step) * BM;
+    };
     int g = 0;  // global slice counter of this workgroup: LDS slot = g & 1
     // waves 0..3 (all waves without STAGGER), per slice:  R(ks0) M(ks0) R(ks1) M(ks1)
     // no zero fill (128 v_mov per tile): the first k32 step of the tile's first slice multiplies into a constant-0 C
@@ -1212,8 +1233,13 @@ hipError_t launch_filter(int store_dtype, int tile, int mode, const void* store,
         tile = 8;  // the bootstrap (group maxima of a row sample) runs on the two-slot kernel
     }
     const int bm = filter_tile_rows(tile);
-    FilterLaunch L{store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad,
-                   mode == MODE_GMAX ? (int)n_sample_tiles : (int)((row_end - row_begin + bm - 1) / bm), &ws, stream};
+    int n_xtiles = mode == MODE_GMAX ? (int)n_sample_tiles : (int)((row_end - row_begin + bm - 1) / bm);
+    if (mode == MODE_FILTER && ws.extra.perm_mod > 0) {
+        // permuted stage order: whole 256-row positions (the partly filled super-tile may sit at any of them), rows masked at ntotal
+        n_xtiles = (int)((row_end - row_begin + 255) / 256) * (256 / bm);
+        row_end = ws.extra.row_bound;
+    }
+    FilterLaunch L{store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, n_xtiles, &ws, stream};
     return store_dtype == 0 ? launch_filter_dt<0>(tile, mode, subset, L) : launch_filter_dt<1>(tile, mode, subset, L);
 }
 

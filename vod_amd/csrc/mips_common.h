@@ -68,6 +68,16 @@ __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "add the literal");
 }
 
+// First corpus row of x-tile `xt` (BM rows each; 256 % BM == 0) of a FILTER launch that starts at row `row_begin` (a multiple of 256):
+// stage positions -> super-tiles through FilterExtra's low-discrepancy order, sub-tiles of a super-tile stay together.
+__device__ __forceinline__ int filter_tile_row0(const FilterExtra& ex, int row_begin, int xt, int BM) {
+    if (ex.perm_mod <= 0) return row_begin + xt * BM;
+    const int per = 256 / BM;
+    const unsigned long long pos = (unsigned long long)(row_begin / 256 + xt / per);
+    const int super = (int)((pos * (unsigned long long)ex.perm_mul) % (unsigned long long)ex.perm_mod);
+    return super * 256 + (xt % per) * BM;
+}
+
 // Subset filter (the `subset_ids` of the reference's SearchClient.search, honoured by its Elasticsearch / Qdrant engines,
 // src/vod_search/es_search/client.py:185-191, qdrant_search/client.py:124-136, and ignored by its faiss client,
 // faiss_search/client.py:67-72): a row is eligible for query q when q lists no label or lists the row's label.

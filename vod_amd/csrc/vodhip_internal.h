@@ -59,6 +59,12 @@ struct FilterExtra {
     int sample_offset = 0;            // GMAX launches: first sampled row (centres the sample: the unsampled rows split between head and tail)
     int sample_groups = 0;            // GMAX launches: number of lane groups of the sample (= candidate slots per query)
     const int* q_map = nullptr;       // recovery of a few queries: workspace row -> row of the caller's batch (q_label is indexed by the latter)
+    // FILTER launches: the order in which a search's stages walk the store's 256-row super-tiles.  perm_mod = T > 0: position p of the
+    // sequence is super-tile (p * perm_mul) % T (perm_mul ~ 0.618 T, coprime to T: a low-discrepancy order - ANY run of consecutive
+    // positions, i.e. any stage, is spread evenly over the whole store, so its threshold is calibrated on every topic of a
+    // document-ordered corpus and a hot topic's tiles are not all scanned at once); 0 = positions are tiles.  row_bound = ntotal (the
+    // partly filled last super-tile can sit at any position: every launch masks rows >= row_bound).
+    int perm_mul = 0, perm_mod = 0, row_bound = 0;
 };
 
 struct SearchWorkspace {
