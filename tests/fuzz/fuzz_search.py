@@ -30,7 +30,7 @@ def draw(rng):
         c["nq"] = max(1, 250_000_000 // c["n"])
     c["k"] = int(rng.choice([1, 2, 7, 10, 63, 64, 65, 100, 128, 129, 200, 256, 500, 1000, 2048]))
     c["dtype"] = str(rng.choice(["f16", "bf16"]))
-    c["tile"] = int(rng.choice([0, 0, 0, 1, 8, 9, 42, 46]))
+    c["tile"] = int(rng.choice([0, 0, 0, 1, 8, 9, 14, 42, 46]))
     if c["tile"] == 42 and c["nq"] > 2300:
         c["tile"] = 0
     c["data"] = str(rng.choice(["uniform", "uniform", "few_values", "sorted", "duplicates", "constant"]))

@@ -1223,14 +1223,18 @@ hipError_t launch_filter(int store_dtype, int tile, int mode, const void* store,
     if (mode == MODE_GMAX && n_sample_tiles <= 0) return hipSuccess;
     const bool subset = ws.extra.row_label != nullptr;
     if (filter_tile_is_persistent(tile) && mode == MODE_DENSE) tile = 1;  // nq_pad is a multiple of 256, which the 128-wide tile divides
-    if (tile >= 10 && tile <= 12) {  // experiment FILTER kernels: `make ABLATION=1 EXPERIMENTS=1` builds only (vodhip_index_set_param refuses the ids otherwise)
+    if (tile == 14 && mode == MODE_FILTER)  // the 8-phase K loop (kernels_mips_8phase.hip): FILTER stages of batches with >= 2 query tiles
+        return launch_filter_8phase(store_dtype, true, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+    if (tile >= 10 && tile <= 14) {  // 10 - 13: experiment FILTER kernels, `make ABLATION=1 EXPERIMENTS=1` builds only (vodhip_index_set_param refuses the ids otherwise)
 #ifdef VODHIP_EXPERIMENTS
+        if (mode == MODE_FILTER && tile == 13)  // the guide's 8-phase K loop with B0 re-read in phase 4
+            return launch_filter_8phase(store_dtype, false, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
         if (mode == MODE_FILTER && tile == 12)  // 384 x 256 workgroup tile
             return launch_filter_wide(store_dtype, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
         if (mode == MODE_FILTER)  // deep ring (10), with fragments read a k-step ahead (11)
             return launch_filter_ring(store_dtype, tile == 11, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
 #endif
-        tile = 8;  // the bootstrap (group maxima of a row sample) runs on the two-slot kernel
+        tile = 8;  // the bootstrap (group maxima of a row sample) and dense chunks run on the two-slot kernel's family
     }
     const int bm = filter_tile_rows(tile);
     int n_xtiles = mode == MODE_GMAX ? (int)n_sample_tiles : (int)((row_end - row_begin + bm - 1) / bm);

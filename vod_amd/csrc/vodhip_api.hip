@@ -294,6 +294,9 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
     // ring (few query bytes per corpus byte through the LDS-DMA path); above, the persistent 256x256 tile on
     // v_mfma_f32_16x16x32 (8; variant 9 staggers the two waves of every SIMD by one k-step: measured equal or 1-2 % slower)
     if (tile == 0) tile = ps.nq > 128 ? 8 : (ps.nq > 64 ? 46 : 42);
+    // ... and with two or more query tiles the FILTER stages run the 8-phase K loop (tile 14: C3 -2.4 %, C4 shard -4.0 %, the 1.25 M-row
+    // shard +0.1 %; with ONE query tile it loses 2.9 % - C2 -, and its subset instantiation spills: both stay on tile 8)
+    const bool auto_8phase = ix->tile == 0 && ps.nq > 256 && !(ix->row_label && ps.q_label);  // (per pass: nq_pad >= 512, below)
     const bool persistent = filter_tile_is_persistent(tile);
     const int64_t bn = filter_tile_cols(tile);
 
@@ -385,7 +388,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
                 return 0;
             };
             const bool last = c + 1 == stages.size();
-            int tile_c = tile;
+            int tile_c = (auto_8phase && nq_pad >= 512 && sg.kind == ST_FILTER) ? 14 : tile;
             if (persistent && ix->tile == 0 && sg.kind == ST_FILTER) {  // (nq_pad is a multiple of 256 there, which the 128-wide tile divides)
                 const int64_t q_tiles = nq_pad / 256;
                 const int64_t x_tiles = (sg.e - sg.b + 255) / 256;
@@ -1046,8 +1049,8 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
 #else
         const bool ring_ok = false;
 #endif
-        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 42 && value != 46 && !(ring_ok && value >= 10 && value <= 12))
-            return fail("tile must be 0 (auto) or a filter-kernel variant id: 1, 8, 9, 42, 46 (DESIGN.md 4.1)");
+        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 14 && value != 42 && value != 46 && !(ring_ok && value >= 10 && value <= 13))
+            return fail("tile must be 0 (auto) or a filter-kernel variant id: 1, 8, 9, 14, 42, 46 (DESIGN.md 4.1)");
         ix->tile = value;
     } else {
         return fail("unknown parameter '%s'", key);
