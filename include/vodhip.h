@@ -134,6 +134,10 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
  *   every filter launch), "ingest_threads" (CPU threads staging pageable host rows, 0 = auto), "kflags" (timing knobs of
  *   diagnostic builds), "tile_order" (0 = default: the FILTER stages of a search walk the store's 256-row tiles in a low-discrepancy
  *   order, so that every stage samples the whole store whatever order the rows were added in; 1 = in row order; results are identical),
+ *   "lanes" (0 = auto, 1, 2: with 2 lanes consecutive searches alternate between two workspaces, the second on a stream of the index's
+ *   own that starts behind the work the caller's stream holds at enqueue - two searches of a caller that runs one search ahead overlap
+ *   on the device; auto = 2 for batches of up to 256 queries, where a search's select / prepare launches and partly filled last
+ *   rounds leave ~12 % of the device idle; results and the finish contract are unchanged),
  *   "exact_expand" (x100, VODHIP_EXACT_F32 stores: the scan lists k' = k * exact_expand / 100 + 16 rows per
  *   query; 0 = default: 110 for an fp16 store, 200 for bf16; speed only - results are exact for any value).
  * stats (of the search completed by the last vodhip_index_search_finish): "last_overflow" (a candidate list overflowed),

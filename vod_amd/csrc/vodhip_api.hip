@@ -71,6 +71,7 @@ struct PendingSearch {
     int kx = 0;                    // exact mode: the scan's list length k' (> k; 0 = not an exact-mode search)
     bool band = false;             // exact mode: a BAND pass - candidates are re-scored into the caller's rows (kernels_exact.hip)
     bool defer_flags = false;      // exact mode: the flag words are fetched (and the slot's event recorded) behind the re-scoring launch
+    int lane = 0;                  // which of the index's two workspaces / streams this search runs on (1 = the index's own stream)
 };
 
 constexpr int MAX_IN_FLIGHT = 4;  // searches that may be enqueued before the oldest is finished
@@ -105,7 +106,14 @@ struct vodhip_index {
     unsigned int* x_flag_q = nullptr;        // device [MAX_IN_FLIGHT][OVF_ROWS]: the queries whose list did not prove complete
     int64_t exact_expand_x100 = 0;           // k' = k * this / 100 (+ 16); 0 = by store dtype (fp16: 110, bf16: 200)
     int64_t last_exact_kx = 0, last_exact_band_queries = 0, last_exact_band_passes = 0;
-    SearchWorkspace ws;
+    // Two LANES: workspace 0 is used on the caller's stream; workspace 1 on a stream of the index's own, so that two consecutive searches
+    // of a caller that runs one search ahead (the bench, the batcher) overlap on the device: while one search's select / prepare launches
+    // and the partly filled last round of its stage leave CUs idle, the other search's FILTER workgroups take them.  Used for batches of
+    // one query tile (param "lanes": 0 = auto, 1, 2), where those gaps are ~12 % of a 1 M-row search (profiles/r05_ab_lanes.txt).
+    SearchWorkspace ws_lane[2];
+    hipStream_t lane_stream = nullptr;
+    hipEvent_t lane_in[4] = {};              // recorded on the caller's stream at enqueue: lane 1 starts behind the caller's pending work
+    int64_t lanes = 0;
     unsigned int* overflow_host = nullptr;  // pinned, two words per in-flight slot: [0] a candidate list overflowed, [1] exact mode: some list did not prove complete
     unsigned int* ovf_q = nullptr;          // device [MAX_IN_FLIGHT][OVF_ROWS]: which queries of a slot's search overflowed
     int* q_map = nullptr;                   // device [MAX_IN_FLIGHT][OVF_ROWS]: the rows a slot's recovery pass re-searches
@@ -141,8 +149,8 @@ namespace {
 
 int elem_size(int dtype) { return dtype == VODHIP_F32 ? 4 : 2; }
 
-int free_workspace(vodhip_index* ix) {
-    SearchWorkspace& w = ix->ws;
+int free_workspace(vodhip_index* ix, int lane) {
+    SearchWorkspace& w = ix->ws_lane[lane];
     (void)hipFree(w.q_pad);
     (void)hipFree(w.topk);
     (void)hipFree(w.cand);
@@ -156,11 +164,11 @@ int free_workspace(vodhip_index* ix) {
     return 0;
 }
 
-int ensure_workspace(vodhip_index* ix, int64_t nq_pad, int64_t cap, int64_t kp) {
-    SearchWorkspace& w = ix->ws;
+int ensure_workspace(vodhip_index* ix, int lane, int64_t nq_pad, int64_t cap, int64_t kp) {
+    SearchWorkspace& w = ix->ws_lane[lane];
     if (w.nq_cap >= nq_pad && w.cap == cap && w.kp == kp && w.q_pad) return 0;
     const int64_t nq_cap = std::max(nq_pad, w.nq_cap);
-    free_workspace(ix);
+    free_workspace(ix, lane);
     HIP_OK(hipMalloc((void**)&w.q_pad, (size_t)nq_cap * ix->dim_pad * 2));
     HIP_OK(hipMalloc((void**)&w.topk, (size_t)nq_cap * kp * sizeof(key_t64)));
     HIP_OK(hipMalloc((void**)&w.cand, (size_t)nq_cap * cap * sizeof(key_t64)));
@@ -283,6 +291,7 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad,
 }
 
 int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, int recovery, hipStream_t stream) {
+    SearchWorkspace& W = ix->ws_lane[ps.lane];  // this search's lane
     const int k = ps.k;
     int64_t kp = 64;
     while (kp < k) kp <<= 1;
@@ -308,16 +317,16 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
     ix->last_chunks = (int64_t)stages.size();
 
     const int q_es = elem_size(ps.q_dtype);
-    if (ensure_workspace(ix, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
-    ix->ws.extra.flags = (int)ix->kflags << 8;  // timing knobs of diagnostic builds (ignored by production kernels)
+    if (ensure_workspace(ix, ps.lane, round_up(std::min(MAX_NQ_PER_PASS, ps.nq), 256), cap, kp)) return -1;
+    W.extra.flags = (int)ix->kflags << 8;  // timing knobs of diagnostic builds (ignored by production kernels)
     // ONE q-tile: every corpus line is read by exactly one workgroup, once - fetch it with the `nt` policy so it does not
     // push the query tile out of L2 (measured -2 % at nq = 256 on 10 M rows; +8 % with 4 q-tiles sharing the lines, so only here)
-    if (persistent && round_up(std::min(MAX_NQ_PER_PASS, ps.nq), bn) == 256) ix->ws.extra.flags |= FILTER_FLAG_CORPUS_NT;
+    if (persistent && round_up(std::min(MAX_NQ_PER_PASS, ps.nq), bn) == 256) W.extra.flags |= FILTER_FLAG_CORPUS_NT;
     // the subset labels in force when THIS search was enqueued (a recovery pass may run after younger searches changed them)
-    ix->ws.extra.row_label = (ix->row_label && ps.q_label) ? ix->row_label : nullptr;
-    ix->ws.extra.n_qlab = ps.n_qlab;
+    W.extra.row_label = (ix->row_label && ps.q_label) ? ix->row_label : nullptr;
+    W.extra.n_qlab = ps.n_qlab;
     const bool track_ovf = ps.nq <= OVF_ROWS;  // per-query overflow flags of this search's slot
-    const bool subset = ix->ws.extra.row_label != nullptr;
+    const bool subset = W.extra.row_label != nullptr;
     if (subset && !safe && recovery == 0) {
         // group maxima would include ineligible rows: a subset search runs the exhaustive-free geometric schedule instead
         // (dense head of <= cap rows, then FILTER stages growing by `growth`)
@@ -331,8 +340,8 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
     // only the LAST stage contains meets a threshold calibrated without it, and all its tiles are scanned at the same moment
     // (bench.py --data clustered: 1.22x the i.i.d. time, L2-miss traffic 1.9x).  Only when every stage after the bootstrap is a FILTER
     // stage (they must tile the store together); results do not depend on the order.
-    ix->ws.extra.perm_mul = ix->ws.extra.perm_mod = 0;
-    ix->ws.extra.row_bound = (int)ix->ntotal;
+    W.extra.perm_mul = W.extra.perm_mod = 0;
+    W.extra.row_bound = (int)ix->ntotal;
     {
         bool all_filter = !stages.empty();
         for (const Stage& sg : stages) all_filter = all_filter && (sg.kind == ST_FILTER || sg.kind == ST_GMAX);
@@ -342,12 +351,12 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
             auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
             while (P > 1 && gcd(P, T) != 1) --P;
             if (P > 1) {
-                ix->ws.extra.perm_mul = (int)P;
-                ix->ws.extra.perm_mod = (int)T;
+                W.extra.perm_mul = (int)P;
+                W.extra.perm_mod = (int)T;
             }
         }
     }
-    const SearchWorkspace& ws = ix->ws;
+    const SearchWorkspace& ws = W;
     for (int64_t qb = 0; qb < ps.nq; qb += MAX_NQ_PER_PASS) {
         const int64_t nq = std::min(MAX_NQ_PER_PASS, ps.nq - qb);
         const int64_t nq_pad = round_up(nq, bn);
@@ -356,13 +365,13 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
         // with a query map (recovery of a few queries) workspace row r is row q_map[qb + r] of the caller's arrays
         const int* q_map = ps.q_map ? ps.q_map + qb : nullptr;
         const int64_t row0 = ps.q_map ? 0 : qb;
-        ix->ws.ovf_q = track_ovf ? ix->ovf_q + (size_t)ps.slot * OVF_ROWS + qb : nullptr;
+        W.ovf_q = track_ovf ? ix->ovf_q + (size_t)ps.slot * OVF_ROWS + qb : nullptr;
         const float* margin = ps.band ? ix->x_eps + (size_t)ps.slot * OVF_ROWS + row0 : nullptr;  // BAND pass: seeded k-th exact score - eps
         HIP_OK(launch_search_prepare(ws, (const char*)ps.queries + (size_t)row0 * ix->dim * q_es, ps.q_dtype, nq, ix->dim,
                                      ix->dtype, nq_pad, ix->dim_pad, qb == 0, recovery > 0 ? ps.out_scores + row0 * k : nullptr,
                                      recovery > 0 ? ps.out_ids + row0 * k : nullptr, k, q_map, stream, margin));
-        ix->ws.extra.q_label = ps.q_label ? ps.q_label + (size_t)row0 * ps.n_qlab : nullptr;
-        ix->ws.extra.q_map = q_map;
+        W.extra.q_label = ps.q_label ? ps.q_label + (size_t)row0 * ps.n_qlab : nullptr;
+        W.extra.q_map = q_map;
         for (size_t c = 0; c < stages.size(); ++c) {
             const Stage& sg = stages[c];
             // one filter launch, bracketed by profile events (bench / roofline accounting)
@@ -378,11 +387,11 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
                     ev1 = ix->ev_pool[ix->ev_used++];
                     HIP_OK(hipEventRecord(ev0, stream));
                 }
-                ix->ws.extra.sample_rstride = (int)sg.rstride;
+                W.extra.sample_rstride = (int)sg.rstride;
                 // S sampled rows at offset + i * rstride, i < S: the (ntotal - 1) % rstride-ish rows the integer stride leaves out
                 // are split between the head and the tail of the store
-                ix->ws.extra.sample_offset = sg.kind == ST_GMAX ? (int)(((ix->ntotal - 1) - (sg.n_tiles * filter_tile_rows(tile_c) - 1) * sg.rstride) / 2) : 0;
-                ix->ws.extra.sample_groups = (int)sg.n_groups;
+                W.extra.sample_offset = sg.kind == ST_GMAX ? (int)(((ix->ntotal - 1) - (sg.n_tiles * filter_tile_rows(tile_c) - 1) * sg.rstride) / 2) : 0;
+                W.extra.sample_groups = (int)sg.n_groups;
                 HIP_OK(launch_filter(ix->dtype, tile_c, sg.kind, ix->data, ws.q_pad, ix->dim_pad, b, e, sg.n_tiles, nq, nq_pad, ws, stream));
                 if (ix->profile) HIP_OK(hipEventRecord(ev1, stream));
                 return 0;
@@ -498,10 +507,10 @@ int enqueue_exact_list(vodhip_index* ix, const PendingSearch& ps, hipStream_t st
     xa.out_scores = ps.out_scores;
     xa.out_ids = ps.out_ids;
     xa.eps = ix->x_eps + (size_t)ps.slot * OVF_ROWS;
-    xa.flag_word = ix->ws.overflow + 1;
+    xa.flag_word = ix->ws_lane[ps.lane].overflow + 1;
     xa.flag_q = ix->x_flag_q + (size_t)ps.slot * OVF_ROWS;
     HIP_OK(launch_exact_rescore(xa, ps.nq, stream));
-    HIP_OK(hipMemcpyAsync(ix->overflow_host + 2 * ps.slot, ix->ws.overflow, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(ix->overflow_host + 2 * ps.slot, ix->ws_lane[ps.lane].overflow, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipEventRecord(ix->done[ps.slot], stream));
     return 0;
 }
@@ -544,7 +553,7 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
     ix->dtype = store_dtype;
     ix->exact = exact;
     if (hipDeviceGetAttribute(&ix->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ix->n_cu < 1) ix->n_cu = 256;
-    ix->ws.n_cu = ix->n_cu;
+    ix->ws_lane[0].n_cu = ix->ws_lane[1].n_cu = ix->n_cu;
     const size_t bytes = (size_t)ix->capacity_pad * ix->dim_pad * 2;
     hipError_t e = hipMalloc((void**)&ix->data, bytes);
     if (e != hipSuccess) {
@@ -559,6 +568,8 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
     if (e == hipSuccess) e = hipMalloc((void**)&ix->q_map, MAX_IN_FLIGHT * OVF_ROWS * sizeof(int));
     if (e == hipSuccess) e = hipHostMalloc((void**)&ix->overflow_host, 2 * MAX_IN_FLIGHT * sizeof(unsigned int), hipHostMallocDefault);
     for (int i = 0; i < MAX_IN_FLIGHT && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ix->done[i], hipEventDisableTiming);
+    for (int i = 0; i < MAX_IN_FLIGHT && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ix->lane_in[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->lane_stream, hipStreamNonBlocking);
     if (exact && e == hipSuccess) {
         // the float32 plane (rows are written whole, zero padded columns included: no fill needed) + the bound's bookkeeping
         const size_t bytes32 = ((size_t)capacity_rows + 1) * ix->dim_pad * sizeof(float);
@@ -594,7 +605,11 @@ int vodhip_index_destroy(vodhip_index_t* ix) {
     if (!ix) return 0;
     (void)hipSetDevice(ix->device);
     if (!ix->inflight.empty()) (void)hipDeviceSynchronize();  // enqueued searches still use the store and the workspace
-    free_workspace(ix);
+    free_workspace(ix, 0);
+    free_workspace(ix, 1);
+    if (ix->lane_stream) (void)hipStreamDestroy(ix->lane_stream);
+    for (int i = 0; i < MAX_IN_FLIGHT; ++i)
+        if (ix->lane_in[i]) (void)hipEventDestroy(ix->lane_in[i]);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < MAX_IN_FLIGHT; ++i)
         if (ix->done[i]) (void)hipEventDestroy(ix->done[i]);
@@ -829,6 +844,20 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
     ps.q_label = ix->q_label;
     ps.n_qlab = ix->n_qlab;
     ps.slot = ix->next_slot;
+    // lane: batches of one query tile alternate between the two workspaces (auto), so that a caller running one search ahead has two
+    // searches on the device at once; lane 1 runs on the index's own stream, behind what the caller's stream holds now (the queries)
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t lanes_eff = ix->lanes > 0 ? ix->lanes : (nq <= 256 ? 2 : 1);
+    if (lanes_eff == 2 && nq > 0) {
+        // the lane the youngest search in flight does NOT use; a caller that finishes every search before the next (nothing in flight)
+        // stays on lane 0 = its own stream, with no event hop
+        ps.lane = ix->inflight.empty() ? 0 : 1 - ix->inflight.back().lane;
+        if (ps.lane == 1) {
+            HIP_OK(hipEventRecord(ix->lane_in[ps.slot], stream));
+            HIP_OK(hipStreamWaitEvent(ix->lane_stream, ix->lane_in[ps.slot], 0));
+            stream = ix->lane_stream;
+        }
+    }
     if (ix->inflight.empty() && ix->unfinished == 0) ix->ev_used = 0;  // profile events are recycled once nothing refers to them
     ps.ev_begin = ix->ev_used;
     if (ix->exact && nq > 0) {
@@ -838,12 +867,12 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
         if (exact_reserve_lists(ix, ps.slot, (size_t)nq * ps.kx)) return -1;
         PendingSearch in = exact_inner(ix, ps);
         in.defer_flags = true;  // ONE copy of both flag words, behind the re-scoring launch
-        if (enqueue_search(ix, in, ix->force_safe != 0, 0, (hipStream_t)stream_)) return -1;
-        if (enqueue_exact_list(ix, ps, (hipStream_t)stream_)) {
-            (void)hipStreamSynchronize((hipStream_t)stream_);
+        if (enqueue_search(ix, in, ix->force_safe != 0, 0, stream)) return -1;
+        if (enqueue_exact_list(ix, ps, stream)) {
+            (void)hipStreamSynchronize(stream);
             return -1;
         }
-    } else if (nq > 0 && enqueue_search(ix, ps, ix->force_safe != 0, 0, (hipStream_t)stream_)) {
+    } else if (nq > 0 && enqueue_search(ix, ps, ix->force_safe != 0, 0, stream)) {
         return -1;
     }
     ps.ev_end = ix->ev_used;
@@ -907,6 +936,7 @@ int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
     HIP_OK(hipSetDevice(ix->device));
     PendingSearch ps = ix->inflight.front();
     ix->inflight.pop_front();
+    if (ps.lane == 1) stream = ix->lane_stream;  // recovery / band passes of a lane-1 search run where the search ran
     if (ps.nq > 0) {
         // this search only: younger ones keep the device busy - and other threads may enqueue more meanwhile (the slot and its
         // event are not reused before MAX_IN_FLIGHT further searches, which cannot be accepted while this one counts as unfinished:
@@ -1037,6 +1067,10 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
     } else if (!strcmp(key, "ingest_threads")) {
         if (value < 0 || value > 256) return fail("ingest_threads must be in [0, 256] (0 = auto)");
         ix->ingest_threads = value;
+    } else if (!strcmp(key, "lanes")) {
+        if (value < 0 || value > 2) return fail("lanes must be 0 (auto: 2 for batches of one query tile), 1 or 2");
+        if (!ix->inflight.empty()) return fail("searches are in flight: finish them before changing the lanes");
+        ix->lanes = value;
     } else if (!strcmp(key, "tile_order")) {
         if (value != 0 && value != 1) return fail("tile_order must be 0 (low-discrepancy stage order) or 1 (row order)");
         ix->tile_order = value;
