@@ -1224,11 +1224,11 @@ hipError_t launch_filter(int store_dtype, int tile, int mode, const void* store,
     const bool subset = ws.extra.row_label != nullptr;
     if (filter_tile_is_persistent(tile) && mode == MODE_DENSE) tile = 1;  // nq_pad is a multiple of 256, which the 128-wide tile divides
     if (tile == 14 && mode == MODE_FILTER)  // the 8-phase K loop (kernels_mips_8phase.hip): FILTER stages of batches with >= 2 query tiles
-        return launch_filter_8phase(store_dtype, true, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
-    if (tile >= 10 && tile <= 14) {  // 10 - 13: experiment FILTER kernels, `make ABLATION=1 EXPERIMENTS=1` builds only (vodhip_index_set_param refuses the ids otherwise)
+        return launch_filter_8phase(store_dtype, 14, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+    if (tile >= 10 && tile <= 16) {  // 10 - 13: experiment FILTER kernels, `make ABLATION=1 EXPERIMENTS=1` builds only (vodhip_index_set_param refuses the ids otherwise)
 #ifdef VODHIP_EXPERIMENTS
-        if (mode == MODE_FILTER && tile == 13)  // the guide's 8-phase K loop with B0 re-read in phase 4
-            return launch_filter_8phase(store_dtype, false, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+        if (mode == MODE_FILTER && (tile == 13 || tile >= 15))  // 8-phase K loop variants: B0 re-read in phase 4 (13), LDS-DMA lead 6 / 5 (15 / 16)
+            return launch_filter_8phase(store_dtype, tile, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
         if (mode == MODE_FILTER && tile == 12)  // 384 x 256 workgroup tile
             return launch_filter_wide(store_dtype, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
         if (mode == MODE_FILTER)  // deep ring (10), with fragments read a k-step ahead (11)

@@ -41,7 +41,8 @@ static_assert(P8_LDS <= 160 * 1024, "LDS budget");
 }  // namespace
 
 // KEEPB0 (tile 14): the B0 fragments stay in registers from phase qd 0 to qd 3 (16 more VGPRs, 4 fewer ds_read_b128 per K-tile)
-template <int DT, bool SUBSET, bool KEEPB0>
+// LEAD = half-tiles the LDS-DMA stream runs ahead of the phase that issues it (7 = the guide's; 6 / 5: experiment builds, tiles 15 / 16)
+template <int DT, bool SUBSET, bool KEEPB0, int LEAD = 7>
 __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
     const uint16_t* __restrict__ X, const uint16_t* __restrict__ Q, int dim_pad, int row_begin, int row_end, int n_xtiles,
     int n_qtiles, int nq, const float* __restrict__ thr_s, const key_t64* __restrict__ thr_key, key_t64* __restrict__ cand,
@@ -335,7 +336,13 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
 
     // ---- prologue: 7 half-tiles in flight, the first K-tile landed and visible -----------------------
     stage(K0{}); stage(K1{}); stage(K2{}); stage(K3{});
-    stage(K0{}); stage(K1{}); stage(K2{});
+    stage(K0{});
+    if constexpr (LEAD >= 6) stage(K1{});
+    if constexpr (LEAD >= 7) stage(K2{});
+    using S0 = std::integral_constant<int, (0 + LEAD) & 3>;  // the kind phase qd stages: (qd + LEAD) & 3
+    using S1 = std::integral_constant<int, (1 + LEAD) & 3>;
+    using S2 = std::integral_constant<int, (2 + LEAD) & 3>;
+    using S3 = std::integral_constant<int, (3 + LEAD) & 3>;
     auto wait_next_ktile = [&](int done_ktiles) {
         // everything but the half-tiles staged beyond K-tile `done_ktiles` (0-based: that one must be complete) may stay in flight
         const int ahead = issued - 4 * (done_ktiles + 1);
@@ -357,28 +364,28 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
             // qd 0: (m0, n0)
             read_a(kb + 0 * P8_HALF);
             read_b(kb + 3 * P8_HALF);
-            stage(K3{});
+            stage(S0{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (first) mma_quadrant(0, 0, true); else mma_quadrant(0, 0, false);
             __builtin_amdgcn_s_barrier();
             // qd 1: (m0, n1)
             read_b1(kb + 1 * P8_HALF);
-            stage(K0{});
+            stage(S1{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (first) mma_quadrant(0, 1, true); else mma_quadrant(0, 1, false);
             __builtin_amdgcn_s_barrier();
             // qd 2: (m1, n1)
             read_a(kb + 2 * P8_HALF);
-            stage(K1{});
+            stage(S2{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (first) mma_quadrant(1, 1, true); else mma_quadrant(1, 1, false);
             __builtin_amdgcn_s_barrier();
             // qd 3: (m1, n0); the next K-tile's half-tiles must have landed before this phase's first barrier
             if constexpr (!KEEPB0) read_b(kb + 3 * P8_HALF);
-            stage(K2{});
+            stage(S3{});
             wait_next_ktile(kt + 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
     wl_flush();
 }
 
-template <int DT, bool KEEPB0>
+template <int DT, bool KEEPB0, int LEAD = 7>
 static hipError_t launch_8phase_dt(const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin, int64_t row_end, int n_xtiles,
                                    int64_t nq, int64_t nq_pad, const SearchWorkspace& ws, hipStream_t stream) {
     const bool subset = ws.extra.row_label != nullptr;
@@ -415,14 +422,22 @@ static hipError_t launch_8phase_dt(const void* store, const void* q_pad, int64_t
                            ws.overflow, ws.extra);
         return hipGetLastError();
     };
-    return subset ? launch(mips_filter8ph_kernel<DT, true, KEEPB0>) : launch(mips_filter8ph_kernel<DT, false, KEEPB0>);
+    if constexpr (LEAD != 7) return launch(mips_filter8ph_kernel<DT, false, KEEPB0, LEAD>);  // (experiment builds: no subset instantiation)
+    else return subset ? launch(mips_filter8ph_kernel<DT, true, KEEPB0>) : launch(mips_filter8ph_kernel<DT, false, KEEPB0>);
 }
 
-hipError_t launch_filter_8phase(int store_dtype, bool keep_b0, const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin, int64_t row_end,
+hipError_t launch_filter_8phase(int store_dtype, int variant, const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin, int64_t row_end,
                                 int64_t nq, int64_t nq_pad, const SearchWorkspace& ws, hipStream_t stream) {
     int n_xtiles = (int)((row_end - row_begin + 255) / 256);
     if (ws.extra.perm_mod > 0) row_end = ws.extra.row_bound;  // permuted stage order: whole positions, rows masked at ntotal
+    const bool keep_b0 = variant != 13;
 #ifdef VODHIP_EXPERIMENTS
+    if (variant == 15)
+        return store_dtype == 0 ? launch_8phase_dt<0, true, 6>(store, q_pad, dim_pad, row_begin, row_end, n_xtiles, nq, nq_pad, ws, stream)
+                                : launch_8phase_dt<1, true, 6>(store, q_pad, dim_pad, row_begin, row_end, n_xtiles, nq, nq_pad, ws, stream);
+    if (variant == 16)
+        return store_dtype == 0 ? launch_8phase_dt<0, true, 5>(store, q_pad, dim_pad, row_begin, row_end, n_xtiles, nq, nq_pad, ws, stream)
+                                : launch_8phase_dt<1, true, 5>(store, q_pad, dim_pad, row_begin, row_end, n_xtiles, nq, nq_pad, ws, stream);
     if (!keep_b0)
         return store_dtype == 0 ? launch_8phase_dt<0, false>(store, q_pad, dim_pad, row_begin, row_end, n_xtiles, nq, nq_pad, ws, stream)
                                 : launch_8phase_dt<1, false>(store, q_pad, dim_pad, row_begin, row_end, n_xtiles, nq, nq_pad, ws, stream);
