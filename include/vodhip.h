@@ -155,6 +155,9 @@ int vodhip_index_set_param(vodhip_index_t* index, const char* key, int64_t value
 int vodhip_debug_schedule(int64_t ntotal, int k, int64_t nq, int64_t cand_cap, int64_t dense_rows, int64_t sample_div,
                           int64_t growth_x100, int tile, int recovery_pass, int n_cu, int64_t* out, int max_stages);
 int vodhip_index_get_stat(const vodhip_index_t* index, const char* key, int64_t* out);
+/* Host-side planning only: the order in which a search's FILTER stages walk the 256-row tiles of a store of `ntotal` rows - position p
+ * (stages are runs of consecutive positions) is tile (p * perm_mul) mod perm_mod; perm_mul <= 1 = positions are tiles (small stores). */
+int vodhip_debug_tile_order(int64_t ntotal, int64_t* perm_mul, int64_t* perm_mod);
 /* Diagnostic builds only (make ABLATION=1; production returns -1): phase stamps of workgroup 0 of the last launch of a
  * kernel (which: 0 = hybrid merge, 1 = priority sampling, 2 = in-batch flattening, 3 = the search's select kernel) as 64 pairs
  * (shader-clock cycles, 10 ns ticks of the constant 100 MHz counter), then the (begin, end) ticks of workgroups 0..63;

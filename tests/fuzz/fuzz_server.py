@@ -28,13 +28,20 @@ def main():
     ap.add_argument("--http", default="native", choices=["native", "uvicorn"])
     ap.add_argument("--churn", action="store_true", help="a NEW client object (new connections) every 25 requests per route: connection churn for soak runs")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--exact-f32", action="store_true",
+                    help="serve an exact-f32 store of rows the fp16 scan cannot represent (13-bit integers; queries 3-bit: float32 sums stay exact): "
+                         "every answer must still equal the float64 oracle on the unrounded values bit for bit")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     n, d = 60_000, 96
     x = rng.integers(-6, 7, size=(n, d)).astype(np.float32)
+    q_lim = 6
+    if a.exact_f32:
+        x = np.clip(x * rng.integers(1, 513, size=(n, 1)).astype(np.float32) + rng.integers(-3, 4, size=(n, d)).astype(np.float32), -4096, 4096)
+        q_lim = 4
     names = np.array([f"doc{v}" for v in rng.integers(0, 7, size=n)])
     tmp = tempfile.mkdtemp()
-    store.save_vectors(f"{tmp}/v.npy", x, dtype=np.float16)
+    store.save_vectors(f"{tmp}/v.npy", x, dtype=np.float32 if a.exact_f32 else np.float16)
     np.save(f"{tmp}/subsets.npy", names)
     x64 = x.astype(np.float64)
 
@@ -43,7 +50,7 @@ def main():
             return super()._make_cmd() + ["--subset-ids-path", f"{tmp}/subsets.npy"]
 
     kw = dict(devices=[0, 0], group_backend="gloo") if a.group else (dict(devices=[0, 0], group_backend="node") if a.node else {})
-    kw.update(http=a.http, micro_batch_wait_ms=a.wait_ms)
+    kw.update(http=a.http, micro_batch_wait_ms=a.wait_ms, exact_f32=a.exact_f32)
     jobs = []
     for j in range(a.requests):
         nq = int(rng.choice([1, 1, 2, 5, 17, 64, 130, 300]))
@@ -52,7 +59,7 @@ def main():
         subset = None
         if route == "fast" and rng.random() < 0.4:
             subset = [[f"doc{int(v)}" for v in rng.choice(8, size=int(rng.integers(0, 3)), replace=False)] for _ in range(nq)]
-        q = rng.integers(-6, 7, size=(nq, d)).astype(np.float32)
+        q = rng.integers(-q_lim, q_lim + 1, size=(nq, d)).astype(np.float32)
         jobs.append((j, route, q, k, subset))
 
     def expected(q, k, subset):

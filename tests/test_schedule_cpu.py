@@ -158,3 +158,32 @@ def test_large_k_uses_the_bootstrap_with_bounded_stages_not_hundreds_of_dense_ch
     assert st_[0, 0] == GMAX and st_[0, 5] >= 2 * 2048 and len(st_) < 40
     tiny_cap = _check(1_048_577, 200, 1, cap=256)  # cap too small for 2k groups: dense head + geometric stages
     assert tiny_cap[0, 0] == DENSE and np.all(tiny_cap[1:, 0] == FILTER) and len(tiny_cap) < 40
+
+
+def test_stage_tile_order_is_a_low_discrepancy_bijection():
+    """The order in which FILTER stages walk the store's 256-row tiles (`vodhip_debug_tile_order`, host arithmetic only): position p ->
+    tile (p * P) mod T must be a bijection, and ANY run of consecutive positions - any stage - must be spread over the whole store:
+    the largest gap it leaves is a small multiple of T / L (what makes every stage a sample of a document-ordered corpus)."""
+    import ctypes
+
+    from vod_amd import _native
+
+    lib = _native.load_library()
+    rng = np.random.default_rng(0)
+    sizes = [1, 2047, 2048, 100_000, 1_000_000, 1_250_000, 5_000_000, 10_000_000, 40_000_000] + [int(v) for v in rng.integers(2_000, 30_000_000, size=12)]
+    for n in sizes:
+        mul, mod = ctypes.c_int64(), ctypes.c_int64()
+        assert lib.vodhip_debug_tile_order(n, ctypes.byref(mul), ctypes.byref(mod)) == 0
+        T, P = mod.value, mul.value
+        assert T == (n + 255) // 256
+        if T < 8:
+            assert P <= 1
+            continue
+        assert 1 < P < T and np.gcd(P, T) == 1
+        tiles = (np.arange(T, dtype=np.int64) * P) % T
+        assert np.array_equal(np.sort(tiles), np.arange(T))  # a bijection
+        for L in (max(8, T // 96), max(8, T // 12), max(8, T // 2)):  # a bootstrap-sized, a first-stage-sized, a last-stage-sized run
+            for start in (0, int(rng.integers(0, T - L + 1)), T - L):
+                run = np.sort(tiles[start : start + L])
+                gaps = np.diff(np.concatenate([[-1], run, [T]]))
+                assert gaps.max() <= 4 * (T / L) + 2, (n, L, start, gaps.max())

@@ -59,6 +59,7 @@ SIGNATURES: dict[str, tuple] = {
     "vodhip_index_set_param": (_i32, [_vp, _c.c_char_p, _i64]),
     "vodhip_debug_schedule": (_i32, [_i64, _i32, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _c.POINTER(_i64), _i32]),
     "vodhip_index_get_stat": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i64)]),
+    "vodhip_debug_tile_order": (_i32, [_i64, _c.POINTER(_i64), _c.POINTER(_i64)]),
     "vodhip_debug_read_probe": (_i32, [_i32, _c.POINTER(_i64), _i32]),
     "vodhip_node_index_create": (_i32, [_i32, _c.POINTER(_i32), _i64, _i32, _i64, _c.POINTER(_vp)]),
     "vodhip_node_index_destroy": (_i32, [_vp]),

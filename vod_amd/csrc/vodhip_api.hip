@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
 #include <string>
 #include <deque>
@@ -219,6 +220,40 @@ void make_geometric_schedule(int64_t n, int k, int64_t cap, std::vector<Stage>& 
     }
 }
 
+// The multiplier of the low-discrepancy stage order over T super-tiles: position p -> super-tile (p * P) mod T with P the largest
+// integer <= T / golden ratio that is coprime to T (a bijection of [0, T); consecutive positions land ~0.618 T apart, so any run of L
+// positions leaves gaps of O(T / L) - three-distance theorem).  <= 1: no permutation.
+int64_t tile_order_multiplier(int64_t T) {
+    if (T < 8) return 0;
+    // Candidates around T / golden ratio; among those coprime to T the one whose continued fraction P / T has the smallest largest
+    // partial quotient: a run of L consecutive multiples of P (mod T) then leaves gaps within a small factor of T / L at EVERY scale L
+    // (three-distance theorem; a candidate that merely is coprime can sit next to a fraction with a small denominator and leave gaps
+    // 12x the mean - seen at T = 99,684).
+    const int64_t P0 = (int64_t)((double)T * 0.6180339887498949);
+    int64_t best = 0, best_q = INT64_MAX;
+    for (int64_t d = 0; d <= 64; ++d) {
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const int64_t P = sgn ? P0 - d : P0 + d;
+            if (P <= 1 || P >= T || (d == 0 && sgn)) continue;
+            int64_t a = T, b = P, worst = 0;
+            bool first = true;
+            while (b) {  // Euclid: the partial quotients of T / P
+                const int64_t quo = a / b, rem = a % b;
+                if (!first) worst = std::max(worst, quo);  // (the first is floor(T / P) = 1 by construction)
+                first = false;
+                a = b;
+                b = rem;
+            }
+            if (a != 1) continue;  // not coprime
+            if (worst < best_q) {
+                best_q = worst;
+                best = P;
+            }
+        }
+    }
+    return best;
+}
+
 // `recovery` > 0: pass number after a candidate-list overflow - no bootstrap (the thresholds are seeded from the previous
 // result), 2^(recovery-1) equal FILTER stages, and the exhaustive schedule once a stage would be <= cap rows.
 void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad, bool safe, int recovery, std::vector<Stage>& st) {
@@ -347,9 +382,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
         for (const Stage& sg : stages) all_filter = all_filter && (sg.kind == ST_FILTER || sg.kind == ST_GMAX);
         const int64_t T = (ix->ntotal + ROW_ALIGN - 1) / ROW_ALIGN;
         if (all_filter && ix->tile_order == 0 && T >= 8 && !(tile >= 10 && tile <= 12)) {
-            int64_t P = (int64_t)((double)T * 0.6180339887498949);
-            auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
-            while (P > 1 && gcd(P, T) != 1) --P;
+            const int64_t P = tile_order_multiplier(T);
             if (P > 1) {
                 W.extra.perm_mul = (int)P;
                 W.extra.perm_mod = (int)T;
@@ -1041,6 +1074,13 @@ int vodhip_debug_schedule(int64_t ntotal, int k, int64_t nq, int64_t cand_cap, i
         o[5] = st[i].n_groups;
     }
     return (int)st.size();
+}
+
+int vodhip_debug_tile_order(int64_t ntotal, int64_t* perm_mul, int64_t* perm_mod) {
+    if (!perm_mul || !perm_mod || ntotal < 0) return fail("invalid arguments");
+    *perm_mod = (ntotal + ROW_ALIGN - 1) / ROW_ALIGN;
+    *perm_mul = tile_order_multiplier(*perm_mod);
+    return 0;
 }
 
 int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
