@@ -691,7 +691,7 @@ def roofline_of(m: dict, world: int) -> dict:
     return {
         "bound": "mfma" if mfma_bound else "hbm",
         "bound_basis": "practical ceilings: 1.24 PFLOP/s streaming fp16 MFMA (power-limited), 6.29 TB/s streaming HBM read",
-        "kernel": ("mips_filter8ph_kernel" if (m["tile"] == 14 or (m["tile"] == 0 and nq > 256)) else "mips_filter16p_kernel")
+        "kernel": ("mips_filter8ph_kernel" if m["tile"] in (0, 14) else "mips_filter16p_kernel")
                   if (m["tile"] in (0, 8, 9, 14) and nq > 128) else f"mips_filter_kernel[tile={m['tile']}]",
         "achieved": achieved,
         "peak": peak,

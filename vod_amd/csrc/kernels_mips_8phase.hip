@@ -87,6 +87,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
     // the issue stream: half-tile n = 4 * (stream K-tile) + kind, kinds in staging order [A0, B1, A1, B0]; LDS buffer = n & 7.
     // The kind is a COMPILE-TIME argument (phase qd stages kind (qd + 3) & 3): the four source pointers stay in registers (indexed
     // by a run-time kind the compiler keeps them in scratch and puts a vmcnt(0) in front of every LDS-DMA).
+    const bool corpus_nt = (ex.flags & FILTER_FLAG_CORPUS_NT) != 0;
     int s_t = 0, s_it = 0, s_par = 0;  // stream K-tile: index inside its corpus tile, corpus tile, buffer parity
     int issued = 0;                     // half-tiles staged so far
     bool s_active = n_my > 0;
@@ -95,12 +96,15 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
         if (s_active) {
             char* dst = smem + (s_par * 4 + KIND) * P8_HALF + wave * 16 * ROW_BYTES;
             const int kbyte = s_t * ROW_BYTES;
-            if constexpr (KIND == 0) {
-                glds16(a_src[0] + kbyte, dst);
-                glds16(a_src[1] + kbyte, dst + 8 * ROW_BYTES);
-            } else if constexpr (KIND == 2) {
-                glds16(a_src[0] + a_half_step + kbyte, dst);
-                glds16(a_src[1] + a_half_step + kbyte, dst + 8 * ROW_BYTES);
+            if constexpr (KIND == 0 || KIND == 2) {
+                const size_t off = (KIND == 2 ? a_half_step : 0) + kbyte;
+                if (corpus_nt) {  // ONE query tile: every corpus line is read once, by one workgroup (as in the two-slot kernel)
+                    glds16_aux<2>(a_src[0] + off, dst);
+                    glds16_aux<2>(a_src[1] + off, dst + 8 * ROW_BYTES);
+                } else {
+                    glds16(a_src[0] + off, dst);
+                    glds16(a_src[1] + off, dst + 8 * ROW_BYTES);
+                }
             } else if constexpr (KIND == 1) {
                 glds16(b_src[0] + b_half_step + kbyte, dst);
                 glds16(b_src[1] + b_half_step + kbyte, dst + 8 * ROW_BYTES);

@@ -338,9 +338,10 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
     // ring (few query bytes per corpus byte through the LDS-DMA path); above, the persistent 256x256 tile on
     // v_mfma_f32_16x16x32 (8; variant 9 staggers the two waves of every SIMD by one k-step: measured equal or 1-2 % slower)
     if (tile == 0) tile = ps.nq > 128 ? 8 : (ps.nq > 64 ? 46 : 42);
-    // ... and with two or more query tiles the FILTER stages run the 8-phase K loop (tile 14: C3 -2.4 %, C4 shard -4.0 %, the 1.25 M-row
-    // shard +0.1 %; with ONE query tile it loses 2.9 % - C2 -, and its subset instantiation spills: both stay on tile 8)
-    const bool auto_8phase = ix->tile == 0 && ps.nq > 256 && !(ix->row_label && ps.q_label);  // (per pass: nq_pad >= 512, below)
+    // ... and the FILTER stages of those batches run the 8-phase K loop (tile 14: C3 -2.4 %, C4 shard -4.0 %; with ONE query tile and the
+    // corpus stream on the `nt` policy C2 -3.5 %, nq 256 on 10 M rows -2.7 %: profiles/r05_ab_8phase.txt, r05_ab_one_query_tile.txt); its
+    // subset instantiation spills, so filtered searches stay on tile 8, as does the bootstrap
+    const bool auto_8phase = ix->tile == 0 && ps.nq > 128 && !(ix->row_label && ps.q_label);
     const bool persistent = filter_tile_is_persistent(tile);
     const int64_t bn = filter_tile_cols(tile);
 
@@ -430,7 +431,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
                 return 0;
             };
             const bool last = c + 1 == stages.size();
-            int tile_c = (auto_8phase && nq_pad >= 512 && sg.kind == ST_FILTER) ? 14 : tile;
+            int tile_c = (auto_8phase && sg.kind == ST_FILTER) ? 14 : tile;
             if (persistent && ix->tile == 0 && sg.kind == ST_FILTER) {  // (nq_pad is a multiple of 256 there, which the 128-wide tile divides)
                 const int64_t q_tiles = nq_pad / 256;
                 const int64_t x_tiles = (sg.e - sg.b + 255) / 256;
