@@ -294,3 +294,29 @@ def test_config1_through_the_spawned_server_with_float32_vectors(tmp_path, monke
                 differ = res.indices != ri
                 if differ.any():
                     assert np.abs(_score64(q, x, res.indices) - rs.astype(np.float64))[differ].max() <= TIE_TOL
+
+
+def test_exact_mode_against_the_float32_c_restatement_of_indexflatip():
+    """The second oracle - plain C, float32 accumulation + a bounded heap: the arithmetic faiss's CPU IndexFlatIP uses
+    (oracle/flat_ip_ref.c; agrees with the float64 NumPy oracle on the committed fixtures, tests/test_oracle_golden.py) - fed the same
+    float32 N(0, 1) inputs as the exact-f32 store: two float32 summation orders, so scores agree to a few float32 ulps of the score and
+    ids wherever the C restatement's own neighbours are further apart than that."""
+    import ctypes
+
+    from vod_amd.build import build_oracle
+
+    lib = ctypes.CDLL(str(build_oracle()))
+    lib.oracle_flat_ip_f32.restype = ctypes.c_int
+    lib.oracle_flat_ip_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int64] * 5 + [ctypes.c_void_p, ctypes.c_void_p]
+    q, x = _gauss(31, 100_000, 384, 32)  # BASELINE config 1's shape
+    k = 10
+    cs, ci = np.empty((len(q), k), dtype=np.float32), np.empty((len(q), k), dtype=np.int64)
+    assert lib.oracle_flat_ip_f32(q.ctypes.data, x.ctypes.data, len(q), len(x), q.shape[1], k, 0, cs.ctypes.data, ci.ctypes.data) == 0
+    with _index(x) as ix:
+        s, i = ix.search(torch.from_numpy(q).cuda(), k)
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    assert np.abs(s - cs).max() <= 1e-4  # (|score| ~ 70: float32 ulp 7.6e-6)
+    differ = i != ci
+    assert np.mean([len(set(a) & set(b)) / k for a, b in zip(i, ci)]) == 1.0
+    if differ.any():  # only where two neighbours of the list are closer than the float32 summation noise
+        assert np.abs(_score64(q, x, i) - _score64(q, x, ci))[differ].max() <= TIE_TOL
