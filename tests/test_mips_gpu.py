@@ -791,3 +791,36 @@ def test_stage_tile_order_does_not_change_the_result(n, tile):
     rs, ri = _oracle(q, x, k, id_base=7)
     np.testing.assert_array_equal(res[0][1], ri)
     np.testing.assert_array_equal(res[0][0], rs)
+
+
+@pytest.mark.parametrize("lanes", [0, 1, 2])
+def test_pipelined_searches_on_two_lanes_equal_synchronous_ones(lanes):
+    """Up to four searches in flight alternate between the index's two workspaces / streams (`lanes`: 0 = auto for batches of one query
+    tile, 2 = always); batches of different sizes, k and kernel families, one with candidate-list overflow (recovery on the lane's own
+    stream), enqueued from a NON-default stream with the queries produced on that stream right before the call: every result must equal
+    the one a synchronous search returns."""
+    rng = np.random.default_rng(lanes)
+    n, d = 150_000, 128
+    x = rng.integers(-8, 9, size=(n, d)).astype(np.float16)
+    x[100_000:103_000] = x[7]  # 3,000 tied copies: the 256-slot candidate lists below overflow for queries aligned with row 7
+    batches = [(200, 50), (64, 10), (300, 100), (17, 7), (256, 100), (1, 1), (130, 33), (700, 20)]
+    qs = [rng.integers(-8, 9, size=(nq, d)).astype(np.float16) for nq, _ in batches]
+    qs[2][:5] = x[7]
+    with _index(x) as ref:
+        want = [[t.clone() for t in ref.search(torch.from_numpy(q).cuda(), k)] for q, (_, k) in zip(qs, batches)]
+    side = torch.cuda.Stream()
+    with _index(x, lanes=lanes, cand_cap=256) as ix:
+        for _round in range(3):
+            outs = []
+            with torch.cuda.stream(side):
+                for j, (q, (nq, k)) in enumerate(zip(qs, batches)):
+                    tq = (torch.from_numpy(q).cuda(non_blocking=True).float() * 1.0).half()  # produced on `side` just before the enqueue
+                    outs.append(ix.search_async(tq, k))
+                    if len(outs) - sum(o is None for o in outs) > 3:
+                        pass
+                    if j % 4 == 3:  # four in flight: finish them oldest first
+                        for _ in range(4):
+                            ix.finish()
+            side.synchronize()
+            for (s, i), (ws, wi) in zip(outs, want):
+                assert torch.equal(i, wi) and torch.equal(s, ws)
