@@ -1422,3 +1422,26 @@ def test_native_client_reopens_a_connection_the_server_closed_while_idle():
     finally:
         t.join(timeout=10)
         srv.close()
+
+
+def test_factory_serves_float32_vectors_exactly_by_default(tmp_path):
+    """`exact_f32=None` (the default): float32 / float64 vectors - what the reference's index holds (build.py:65-73) - get a float32 hand-off
+    file and a server started with --exact-f32, so the drop-in returns the reference's result unless the caller opts out; float16 vectors
+    are served as they are; an explicit True / False wins."""
+    from vod_amd import factory
+
+    rng = np.random.default_rng(0)
+    x32 = rng.normal(size=(50, 8)).astype(np.float32)
+    cases = [(x32, None, True, np.float32), (x32.astype(np.float64), None, True, np.float32), (x32.astype(np.float16), None, False, np.float16),
+             (x32, False, False, np.float16), (x32.astype(np.float16), True, True, np.float32)]
+    for j, (x, flag, want_exact, want_file) in enumerate(cases):
+        cfg = {"port": 23470 + j}
+        if flag is not None:
+            cfg["exact_f32"] = flag
+        m = factory.build_hip_mips_index(x, config=cfg, cache_dir=tmp_path / str(j))
+        assert m.exact_f32 is want_exact and ("--exact-f32" in m._make_cmd()) is want_exact
+        assert np.load(m.vectors_path, mmap_mode="r").dtype == want_file
+    # the two modes of the same vectors never share a cached store
+    a = factory.build_hip_mips_index(x32, config={"port": 23480}, cache_dir=tmp_path / "c")
+    b = factory.build_hip_mips_index(x32, config={"port": 23481, "exact_f32": False}, cache_dir=tmp_path / "c")
+    assert a.vectors_path != b.vectors_path

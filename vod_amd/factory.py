@@ -25,9 +25,12 @@ class HipMipsFactoryConfig:
     factory: str = "Flat"           # only the exact index exists here
     metric: str = "inner_product"   # src/vod_configs/search.py:130
     dtype: str = "float16"          # HBM storage type of the SCAN copy (float16 | bfloat16)
-    exact_f32: bool = False         # also keep the float32 rows and return the float32 brute-force result on the unrounded vectors and
+    exact_f32: bool | None = None   # also keep the float32 rows and return the float32 brute-force result on the unrounded vectors and
                                     # queries - what the reference's faiss IndexFlat computes (build.py:65-73); the vector file handed
-                                    # to the server is float32 then.  Off: scores are dot products of the values rounded to `dtype`
+                                    # to the server is float32 then.  False: scores are dot products of the values rounded to `dtype`.
+                                    # None (default) = decided by the vectors handed to `build_hip_mips_index`: True for float32 /
+                                    # float64 vectors (the reference's: the drop-in returns the reference's result by default),
+                                    # False for float16 vectors (nothing to keep: the scan copy IS the data)
     host: str = "http://localhost"
     port: int = -1                  # the reference config's default (src/vod_configs/search.py:134): < 0 = pick a free port, so two
                                     # default-config indexes on one host (hybrid set-ups, shards, two jobs) never collide; ONE
@@ -47,7 +50,7 @@ class HipMipsFactoryConfig:
 
     def fingerprint(self) -> dict:
         fp = {"factory": self.factory, "metric": self.metric, "dtype": self.dtype}
-        if self.exact_f32:  # (absent when off: the cache names of existing stores do not change)
+        if self.exact_f32:  # (absent when off / undecided: the cache names of existing fp16 stores do not change)
             fp["exact_f32"] = True
         return fp
 
@@ -91,6 +94,12 @@ def build_hip_mips_index(
         config = resolve_port(config, broadcast_fn)
     if devices is None and config.devices is not None:
         devices = list(config.devices)
+    if config.exact_f32 is None:  # auto: float32 / float64 vectors are served exactly, float16 vectors as they are
+        try:
+            vec_dtype = np.dtype(getattr(vectors, "dtype", None) or np.asarray(vectors[0]).dtype) if len(vectors) else np.dtype(np.float16)
+        except Exception:  # noqa: BLE001 - an exotic sequence: fall back to looking at one row
+            vec_dtype = np.asarray(vectors[0]).dtype
+        config = dataclasses.replace(config, exact_f32=bool(vec_dtype in (np.dtype(np.float32), np.dtype(np.float64))))
     if config.factory != "Flat" or config.metric != "inner_product":
         raise ValueError("the HIP MIPS engine is an exact inner-product index (factory='Flat', metric='inner_product')")
     from vod_amd.zarr_store import ZarrVectors
@@ -119,7 +128,7 @@ def build_hip_mips_index(
         skip_setup=skip_setup,
         free_resources=free_resources,
         dtype=config.dtype,
-        exact_f32=config.exact_f32,
+        exact_f32=bool(config.exact_f32),
         device=config.device,
         devices=None if devices is None else list(devices),
         group_backend=config.group_backend,
