@@ -24,6 +24,7 @@
 #include <algorithm>
 
 #include "mips_common.h"
+#include "wg_sort.h"
 
 namespace vodhip {
 
@@ -68,24 +69,22 @@ __device__ __forceinline__ float round_to_store(float f, int store_dtype) {
     return (float)(__bf16)f;
 }
 
-constexpr int XT = 512;  // threads of the re-scoring workgroup: 8 waves x 4 rows = 32 float32 rows in flight per query
+constexpr int XT = 512;  // threads of the re-scoring workgroup
+constexpr int NCR = 8;   // float32 rows a wave has in flight: 8 waves x 8 rows = 64 per query
 
-// descending bitonic sort of P (power of two, >= 2) keys in LDS by XT threads
+// descending sort of P (a power of two, 64 .. 4096) keys in LDS: up to 512 keys ONE wavefront sorts them in its registers (shuffles only,
+// no barrier: the 28-45 barrier-separated LDS stages this replaces were a third of the re-scoring launch), above that the
+// workgroup-wide register network of wg_sort.h (3 of its levels touch LDS)
 __device__ __forceinline__ void sort_desc_lds(key_t64* keys, int P, int tid) {
-    const int half = P >> 1;
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int t = tid; t < half; t += XT) {
-                const int pos = 2 * t - (t & (stride - 1));
-                const key_t64 a = keys[pos], b = keys[pos + stride];
-                const bool desc = (pos & size) == 0;
-                if ((a < b) == desc) {
-                    keys[pos] = b;
-                    keys[pos + stride] = a;
-                }
-            }
-        }
+    __syncthreads();
+    switch (P) {
+        case 64: if (tid < 64) wave_sort_regs<1, true>(keys, tid); break;
+        case 128: if (tid < 64) wave_sort_regs<2, true>(keys, tid); break;
+        case 256: if (tid < 64) wave_sort_regs<4, true>(keys, tid); break;
+        case 512: if (tid < 64) wave_sort_regs<8, true>(keys, tid); break;
+        case 1024: wg_sort_regs<XT, 2, true>(keys, tid); break;
+        case 2048: wg_sort_regs<XT, 4, true>(keys, tid); break;
+        default: wg_sort_regs<XT, 8, true>(keys, tid); break;  // 4096
     }
     __syncthreads();
 }
@@ -263,10 +262,10 @@ __global__ __launch_bounds__(XT) void exact_rescore_kernel(ExactArgs a) {
     int done = 0;
     do {
         const int take = min(CH, n_total - done);
-        for (int j0 = wave * 4; j0 < take; j0 += 4 * (XT / 64)) {
-            int rows[4];
+        for (int j0 = wave * NCR; j0 < take; j0 += NCR * (XT / 64)) {
+            int rows[NCR];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < NCR; ++n) {
                 const int j = j0 + n;
                 int row = -1;
                 if (j < take) {
@@ -280,15 +279,15 @@ __global__ __launch_bounds__(XT) void exact_rescore_kernel(ExactArgs a) {
                 }
                 rows[n] = __builtin_amdgcn_readfirstlane(row);
             }
-            float s[4];
-            exact_dot<4>(a.plane, a.stride, rows, qs, a.dim_pad, lane, s);
+            float s[NCR];
+            exact_dot<NCR>(a.plane, a.stride, rows, qs, a.dim_pad, lane, s);
             if (lane == 0) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
+                for (int n = 0; n < NCR; ++n)
                     if (j0 + n < take) kb[KR + j0 + n] = (rows[n] >= 0 && s[n] == s[n]) ? make_key(s[n], (unsigned)rows[n]) : 0ull;  // NaN never enters
             }
         }
-        int P_eff = 2;
+        int P_eff = 64;
         while (P_eff < KR + take) P_eff <<= 1;
         for (int c = KR + take + tid; c < P_eff; c += XT) kb[c] = 0ull;
         sort_desc_lds(kb, P_eff, tid);  // (starts and ends with a barrier)

@@ -534,7 +534,7 @@ int enqueue_exact_list(vodhip_index* ix, const PendingSearch& ps, hipStream_t st
     xa.list_s = ix->x_list_s[ps.slot];
     xa.list_i = ix->x_list_i[ps.slot];
     xa.kx = ps.kx;
-    xa.P = 2;
+    xa.P = 64;
     while (xa.P < ps.kx) xa.P <<= 1;
     xa.k = ps.k;
     xa.id_base = ps.id_base;
