@@ -130,7 +130,8 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
  *   scored densely, default 2048), "sample_div" (the threshold bootstrap scores ~ntotal / sample_div sampled rows, default 96),
  *   "growth" (x100: a filter stage covers growth x the rows its threshold was calibrated on, default 800),
  *   "force_safe" (1 = exhaustive schedule: dense chunks of <= cand_cap rows), "tile" (0 = auto; 1 = 128x128, 42 / 46 = small-batch
- *   rings, 8 / 9 = persistent 256x256 without / with the wave stagger), "small_chunk_tiles", "profile" (1 = HIP events around
+ *   rings, 8 / 9 = persistent 256x256 two-slot kernel without / with the wave stagger, 14 = persistent 256x256 on the 8-phase K loop: the
+ *   auto choice above 128 queries), "small_chunk_tiles", "profile" (1 = HIP events around
  *   every filter launch), "ingest_threads" (CPU threads staging pageable host rows, 0 = auto), "kflags" (timing knobs of
  *   diagnostic builds), "tile_order" (0 = default: the FILTER stages of a search walk the store's 256-row tiles in a low-discrepancy
  *   order, so that every stage samples the whole store whatever order the rows were added in; 1 = in row order; results are identical),
