@@ -24,6 +24,10 @@ for w in $LIST; do
   timeout 900 python3 $ROOTD/bench.py $a $extra > $OUT/${w}_bench.json 2> $OUT/${w}_bench.err
   tail -1 $OUT/${w}_bench.json | cut -c1-400
   P="--steps 5 --warmup 2 --no-cpu-baseline --no-verify --no-side"
+  # one-query-tile workloads run on two lanes (two searches overlap on the device): the kernel trace of those is taken with ONE lane, so that
+  # every kernel's duration and the last batch's timeline are exclusive (the bench line above them is the two-lane figure)
+  case $w in c2|c2exact|c3nq256) P="$P --param lanes=1";; esac
+  rm -rf $OUT/${w}_prof $OUT/${w}_pmc_sq1 $OUT/${w}_pmc_tcc1 $OUT/${w}_pmc_tcc2   # (a re-run must not leave two traces side by side)
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${w}_prof -- python3 $ROOTD/bench.py $a $P > $OUT/${w}_prof.log 2>&1
   [ "$w" = "shardfc" ] && continue   # (the exchange step: kernel trace only - what the RCCL all-gather and the merge cost per step)
   for pass in "sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "tcc1 FETCH_SIZE GRBM_GUI_ACTIVE" "tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do

@@ -45,7 +45,7 @@ for bench in sorted(src.glob("*_bench.json")):
         with open(prof / f"{rnd}_{w}_last_batch_timeline.csv", "w") as f:
             f.write("start_us,duration_us,grid,kernel\n")
             for x in sel:
-                if "mips_" not in x["Kernel_Name"] and "merge_topk" not in x["Kernel_Name"]:
+                if "mips_" not in x["Kernel_Name"] and "merge_topk" not in x["Kernel_Name"] and "exact_rescore" not in x["Kernel_Name"]:
                     continue
                 f.write(f"{(int(x['Start_Timestamp']) - t0) / 1e3:.1f},{(int(x['End_Timestamp']) - int(x['Start_Timestamp'])) / 1e3:.1f},"
                         f"{x.get('Grid_Size_X', x.get('Grid_Size', ''))},\"{x['Kernel_Name'][:90]}\"\n")
