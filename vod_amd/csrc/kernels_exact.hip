@@ -64,13 +64,47 @@ __device__ __forceinline__ void exact_dot(const float* __restrict__ plane, int64
     for (int n = 0; n < NC; ++n) out[n] = wave_sum_fixed((acc[n][0] + acc[n][1]) + (acc[n][2] + acc[n][3]));
 }
 
+// the same function with every load of the NC rows issued before the first fma (dim_pad <= 256 * NI): one memory latency per group of
+// rows instead of one per 256 columns.  Same fma order per component -> the same bits as exact_dot.
+template <int NC, int NI>
+__device__ __forceinline__ void exact_dot_preload(const float* __restrict__ plane, int64_t stride, const int (&rows)[NC], const float* qs,
+                                                  int dim_pad, int lane, float (&out)[NC]) {
+    float4 xv[NI][NC];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int c = lane * 4 + it * 256;
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+            xv[it][n] = (c < dim_pad && rows[n] >= 0) ? *reinterpret_cast<const float4*>(plane + (size_t)rows[n] * stride + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float acc[NC][4];
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[n][0] = acc[n][1] = acc[n][2] = acc[n][3] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int c = lane * 4 + it * 256;
+        if (c < dim_pad) {
+            const float4 qv = *reinterpret_cast<const float4*>(qs + c);
+#pragma unroll
+            for (int n = 0; n < NC; ++n) {
+                acc[n][0] = __builtin_fmaf(xv[it][n].x, qv.x, acc[n][0]);
+                acc[n][1] = __builtin_fmaf(xv[it][n].y, qv.y, acc[n][1]);
+                acc[n][2] = __builtin_fmaf(xv[it][n].z, qv.z, acc[n][2]);
+                acc[n][3] = __builtin_fmaf(xv[it][n].w, qv.w, acc[n][3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NC; ++n) out[n] = wave_sum_fixed((acc[n][0] + acc[n][1]) + (acc[n][2] + acc[n][3]));
+}
+
 __device__ __forceinline__ float round_to_store(float f, int store_dtype) {
     if (store_dtype == 0) return (float)(_Float16)f;
     return (float)(__bf16)f;
 }
 
 constexpr int XT = 512;  // threads of the re-scoring workgroup
-constexpr int NCR = 8;   // float32 rows a wave has in flight: 8 waves x 8 rows = 64 per query
+constexpr int NCR = 4;   // float32 rows a wave has in flight, every column of them requested at once: 8 waves x 4 rows = 32 rows x dim floats per query
 
 // descending sort of P (a power of two, 64 .. 4096) keys in LDS: up to 512 keys ONE wavefront sorts them in its registers (shuffles only,
 // no barrier: the 28-45 barrier-separated LDS stages this replaces were a third of the re-scoring launch), above that the
@@ -194,6 +228,7 @@ __global__ __launch_bounds__(XT) void exact_rescore_kernel(ExactArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* qs = reinterpret_cast<float*>(smem);
     key_t64* kb = reinterpret_cast<key_t64*>(smem + (size_t)a.dim_pad * sizeof(float));
+    int* row_of = reinterpret_cast<int*>(smem + (size_t)a.dim_pad * sizeof(float) + (size_t)a.P * sizeof(key_t64));  // [P] rows of the chunk's candidates
     __shared__ float red[2 * (XT / 64)];
     const int r = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -262,25 +297,32 @@ __global__ __launch_bounds__(XT) void exact_rescore_kernel(ExactArgs a) {
     int done = 0;
     do {
         const int take = min(CH, n_total - done);
+        // the chunk's candidate rows first, in ONE coalesced pass (a wave fetching its candidates' ids one by one pays a memory latency each)
+        for (int j = tid; j < take; j += XT) {
+            int row = -1;
+            if (cand_mode) {
+                const key_t64 key = a.cand[(size_t)r * a.cap + done + j];
+                if (key != 0ull) row = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            } else {
+                const int64_t id = a.list_i[qo * a.kx + done + j];
+                if (id >= 0) row = (int)id;
+            }
+            row_of[j] = row;
+        }
+        __syncthreads();
+        const int ni = (a.dim_pad + 255) >> 8;
         for (int j0 = wave * NCR; j0 < take; j0 += NCR * (XT / 64)) {
             int rows[NCR];
 #pragma unroll
-            for (int n = 0; n < NCR; ++n) {
-                const int j = j0 + n;
-                int row = -1;
-                if (j < take) {
-                    if (cand_mode) {
-                        const key_t64 key = a.cand[(size_t)r * a.cap + done + j];
-                        if (key != 0ull) row = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
-                    } else {
-                        const int64_t id = a.list_i[qo * a.kx + done + j];
-                        if (id >= 0) row = (int)id;
-                    }
-                }
-                rows[n] = __builtin_amdgcn_readfirstlane(row);
-            }
+            for (int n = 0; n < NCR; ++n) rows[n] = __builtin_amdgcn_readfirstlane(j0 + n < take ? row_of[j0 + n] : -1);
             float s[NCR];
-            exact_dot<NCR>(a.plane, a.stride, rows, qs, a.dim_pad, lane, s);
+            switch (ni) {
+                case 1: exact_dot_preload<NCR, 1>(a.plane, a.stride, rows, qs, a.dim_pad, lane, s); break;
+                case 2: exact_dot_preload<NCR, 2>(a.plane, a.stride, rows, qs, a.dim_pad, lane, s); break;
+                case 3: exact_dot_preload<NCR, 3>(a.plane, a.stride, rows, qs, a.dim_pad, lane, s); break;
+                case 4: exact_dot_preload<NCR, 4>(a.plane, a.stride, rows, qs, a.dim_pad, lane, s); break;
+                default: exact_dot<NCR>(a.plane, a.stride, rows, qs, a.dim_pad, lane, s); break;
+            }
             if (lane == 0) {
 #pragma unroll
                 for (int n = 0; n < NCR; ++n)
@@ -329,7 +371,7 @@ __global__ __launch_bounds__(XT) void exact_rescore_kernel(ExactArgs a) {
 
 hipError_t launch_exact_rescore(const ExactArgs& a, int64_t nq, hipStream_t stream) {
     if (nq <= 0) return hipSuccess;
-    const int bytes = (int)((size_t)a.dim_pad * sizeof(float) + (size_t)a.P * sizeof(key_t64));
+    const int bytes = (int)((size_t)a.dim_pad * sizeof(float) + (size_t)a.P * (sizeof(key_t64) + sizeof(int)));
     if (hipError_t e = allow_dynamic_lds((const void*)exact_rescore_kernel, bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(exact_rescore_kernel, dim3((unsigned)nq), dim3(XT), bytes, stream, a);
     return hipGetLastError();
