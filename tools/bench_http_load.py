@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--batcher-param", action="append", default=[], metavar="KEY=VALUE")
     ap.add_argument("--devices", type=int, nargs="+", default=None, help="serve the store row-sharded over these GPUs (a device may repeat)")
     ap.add_argument("--group-backend", default="node", choices=["node", "nccl", "gloo"])
+    ap.add_argument("--exact-f32", action="store_true", help="serve an exact-f32 store (float32 rows kept, float32 brute-force results): what a float32 corpus gets by default")
     ap.add_argument("--think-ms", type=float, nargs="+", default=[0.0],
                     help="mean of an exponential pause between a worker's requests (0 = closed loop, the default cells); > 0 shows what the "
                          "fusion policy costs / gives when arrivals are not synchronised by the server itself")
@@ -135,7 +136,7 @@ def main():
     for mb in a.micro_batch_ms:
         bparams = {kv.partition("=")[0]: int(kv.partition("=")[2]) for kv in a.batcher_param}
         multi = {} if a.devices is None else dict(devices=a.devices, group_backend=a.group_backend)
-        with HipMipsMaster(spec, port=-1, logging_level="warning", micro_batch_wait_ms=mb, http=a.http, batcher_params=bparams, **multi) as master:
+        with HipMipsMaster(spec, port=-1, logging_level="warning", micro_batch_wait_ms=mb, http=a.http, batcher_params=bparams, exact_f32=a.exact_f32, **multi) as master:
             import requests
 
             def stats():
