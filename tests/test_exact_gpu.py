@@ -320,3 +320,26 @@ def test_exact_mode_against_the_float32_c_restatement_of_indexflatip():
     assert np.mean([len(set(a) & set(b)) / k for a, b in zip(i, ci)]) == 1.0
     if differ.any():  # only where two neighbours of the list are closer than the float32 summation noise
         assert np.abs(_score64(q, x, i) - _score64(q, x, ci))[differ].max() <= TIE_TOL
+
+
+def test_non_finite_inputs_do_not_poison_the_bound():
+    """A NaN query returns pads (a NaN score never enters a result, as in the plain store and in faiss); a row with an infinite / NaN
+    component does not move the norm maxima of the error bound, so every OTHER query stays exact and cheap (no band pass for them)."""
+    q, x = _gauss(37, 30_000, 64, 12)
+    x[123, 5] = np.inf
+    x[456, 7] = np.nan
+    q[3, 0] = np.nan
+    ok = np.ones(len(x), dtype=bool)
+    ok[[123, 456]] = False
+    with _index(x) as ix:
+        s, i = ix.search(torch.from_numpy(q).cuda(), 20)
+        s, i = s.cpu().numpy(), i.cpu().numpy()
+    assert (i[3] == -1).all() and np.isneginf(s[3]).all()
+    keep = [r for r in range(len(q)) if r != 3]
+    rs, ri = _oracle(q[keep], x[ok], 20)          # the oracle on the finite rows ...
+    ids_ok = np.nonzero(ok)[0]
+    for j, r in enumerate(keep):
+        got = [(v, w) for v, w in zip(i[r], s[r]) if v not in (123, 456)]  # ... the +inf row may legitimately lead a list (score +inf)
+        want = list(zip(ids_ok[ri[j]], rs[j]))
+        assert [v for v, _ in got][:18] == [v for v, _ in want][:18]
+        assert np.allclose([w for _, w in got][:18], [w for _, w in want][:18], atol=SCORE_TOL)
