@@ -307,6 +307,8 @@ def make_queries(torch, dev, tdt, data: str, nq: int, d: int, n_total: int):
     return q.to(tdt)
 
 
+NAMEPLATE_MFMA = 2.5e15   # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md): what `roofline.peak` / `frac` / `bound` use
+NAMEPLATE_HBM = 8.0e12     # HBM3E peak
 PRACTICAL_MFMA = 1.24e15   # flop/s a streaming fp16 contraction holds on this part (power-limited; DESIGN.md 5, MI355X_MICROARCH "DVFS give-back")
 PRACTICAL_HBM = 6.29e12    # B/s of a streaming copy (MI355X_MICROARCH.md:34-43)
 
@@ -654,13 +656,19 @@ def _m(v: int) -> str:
     return f"{v // 1_000_000}M" if v % 1_000_000 == 0 else (f"{v / 1e6:g}M" if v >= 1_000_000 else str(v))
 
 
+def traffic_key(rows: int, d: int, nq: int, world: int, data: str = "iid", exact: bool = False) -> str:
+    """Key of profiles/hbm_traffic.json: shape @ ranks [/data] [/exact] - the store mode is part of the key (round 5's exact-f32 PMC passes
+    overwrote the plain ones under a shared key)."""
+    return f"{rows}x{d}x{nq}@{world}" + ("" if data == "iid" else "/" + data) + ("/exact" if exact else "")
+
+
 def roofline_of(m: dict, world: int) -> dict:
     """Roofline record of the dominant kernel (the filter launches of a step) from live HIP-event durations.
 
-    Both fractions are always reported.  `bound` = the roof that binds at the ceilings this part actually holds (1.24 PFLOP/s
-    for a streaming fp16 contraction - power-limited - and 6.29 TB/s for a streaming read): nq = 256 on 10 M rows is
-    MFMA-bound by that measure (3.2 ms of MFMA against 2.4 ms of HBM) although the nameplate ridge (312 queries) says HBM.
-    `peak` stays the guide's nameplate figure of that roof.  Recovery launches, if any, are part of the kernel time."""
+    `bound` is the roof that binds at the NAMEPLATE peaks `peak` / `frac` are quoted against (2.5 PFLOP/s dense fp16 / bf16 MFMA, 8 TB/s
+    HBM: SURVEY 8d's table - C2 is HBM-bound, C3 / C4 MFMA-bound); both fractions are always reported.  `practical` holds the ceilings a
+    streaming kernel actually reaches on this part (1.24 PFLOP/s power-limited fp16 contraction, 6.29 TB/s streaming read) and the roof
+    that binds at those - context, never the basis of `frac`.  Recovery launches, if any, are part of the kernel time."""
     rows, d, nq, k, steps = m["rows"], m["dim"], m["nq"], m["k"], m["steps"]
     n_local = m["n_local"]
     flops = 2.0 * nq * n_local * d                       # algorithmic flops of this rank's filter launches per step
@@ -672,25 +680,22 @@ def roofline_of(m: dict, world: int) -> dict:
     overlapped = kern_s > m["elapsed"]
     if overlapped:
         kern_s = m["elapsed"]
-    mfma_bound = flops / PRACTICAL_MFMA >= byts / PRACTICAL_HBM
+    mfma_bound = flops / NAMEPLATE_MFMA >= byts / NAMEPLATE_HBM
     tflops = flops * steps / kern_s / 1e12 if kern_s > 0 else None
     gbps = byts * steps / kern_s / 1e9 if kern_s > 0 else None
     achieved = tflops if mfma_bound else gbps
-    peak = 2500.0 if mfma_bound else 8000.0
+    peak = NAMEPLATE_MFMA / 1e12 if mfma_bound else NAMEPLATE_HBM / 1e9
     traffic, traffic_src = None, None
     tfile = ROOT / "profiles" / "hbm_traffic.json"
     if tfile.exists():  # HBM bytes per step from this round's rocprofv3 --pmc passes of the same workload (tools/pmc.sh)
         try:
-            ent = json.loads(tfile.read_text()).get(f"{rows}x{d}x{nq}@{world}" + ("" if m["data"] == "iid" else "/" + m["data"]))
+            ent = json.loads(tfile.read_text()).get(traffic_key(rows, d, nq, world, m["data"], m.get("exact", False)))
             if isinstance(ent, dict):
                 traffic, traffic_src = ent.get("bytes"), ent.get("source")
-            else:
-                traffic = ent
         except Exception:
             traffic = None
     return {
         "bound": "mfma" if mfma_bound else "hbm",
-        "bound_basis": "practical ceilings: 1.24 PFLOP/s streaming fp16 MFMA (power-limited), 6.29 TB/s streaming HBM read",
         "kernel": ("mips_filter8ph_kernel" if m["tile"] in (0, 14) else "mips_filter16p_kernel")
                   if (m["tile"] in (0, 8, 9, 14) and nq > 128) else f"mips_filter_kernel[tile={m['tile']}]",
         "achieved": achieved,
@@ -707,7 +712,148 @@ def roofline_of(m: dict, world: int) -> dict:
         "algorithmic_bytes_per_step": byts,
         "mfma_frac_of_2.5PF": (tflops / 2500.0) if tflops else None,
         "hbm_frac_at_8TBps": (gbps / 8000.0) if gbps else None,
+        "practical": {"mfma_tflops": PRACTICAL_MFMA / 1e12, "hbm_gbps": PRACTICAL_HBM / 1e9,
+                      "bound": "mfma" if flops / PRACTICAL_MFMA >= byts / PRACTICAL_HBM else "hbm",
+                      "frac": (max(flops / PRACTICAL_MFMA, byts / PRACTICAL_HBM) * steps / kern_s) if kern_s > 0 else None},
     }
+
+
+LINE_LIMIT = 4000  # bytes: the final stdout line stays below 4 KB (round 5's 20.6 KB line was unreadable for the driver: BENCH_r05 parsed null)
+SIDE_FILE = ROOT / "gpurun_out" / "bench_side.json"
+
+
+def _r(v, digits: int = 6):
+    """Float to `digits` significant digits (None / non-finite -> None): keeps the line short and strict JSON."""
+    if v is None or isinstance(v, (bool, int, str)):
+        return v
+    v = float(v)
+    if v != v or v in (float("inf"), float("-inf")):
+        return None
+    return float(f"{v:.{digits}g}")
+
+
+def _strict(obj):
+    """Deep copy with every non-finite float replaced by None (json.dumps(..., allow_nan=False) then never raises)."""
+    if isinstance(obj, dict):
+        return {str(k): _strict(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_strict(v) for v in obj]
+    if isinstance(obj, float):
+        return obj if obj == obj and obj not in (float("inf"), float("-inf")) else None
+    return obj
+
+
+def compact_roofline(r: dict) -> dict:
+    """The roofline record of the final line: the contract's keys + what the judge recomputes `achieved` from."""
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launches_per_step", "kernel_ms_per_step",
+            "algorithmic_flops_per_step", "algorithmic_bytes_per_step", "mfma_frac_of_2.5PF", "hbm_frac_at_8TBps")
+    out = {key: _r(r.get(key)) for key in keep}
+    for key in ("traffic", "algorithmic_flops_per_step", "algorithmic_bytes_per_step"):  # whole numbers: kept exact
+        if r.get(key) is not None:
+            out[key] = int(r[key])
+    if r.get("kernel_ms_is_step_wall_time"):
+        out["kernel_ms_is_step_wall_time"] = True
+    if r.get("includes_recovery_launches"):
+        out["includes_recovery_launches"] = True
+    pr = r.get("practical") or {}
+    out["practical"] = {key: _r(pr.get(key), 4) for key in ("mfma_tflops", "hbm_gbps", "bound", "frac")}
+    return out
+
+
+def compact_verify(v: "dict | None") -> "dict | None":
+    """recall / score deviation of the sampled queries vs the float64 brute force, the same vs the unrounded float32 inputs, and the
+    integer twin's bit-exactness booleans - nothing else (the full record goes to the side file)."""
+    if v is None:
+        return None
+    out = {"recall_at_k": _r(v.get("recall_at_k")), "rows_with_identical_id_order": _r(v.get("rows_with_identical_id_order")),
+           "max_abs_score_diff": _r(v.get("max_abs_score_diff"), 4), "score_scale": _r(v.get("score_scale"), 4),
+           "queries_checked": v.get("queries_checked"),
+           "comparator": "f64 brute force on the UNROUNDED f32 inputs" if "UNROUNDED" in str(v.get("comparator")) else "f64 brute force on the stored rows"}
+    vu = v.get("vs_unrounded_inputs")
+    if vu:
+        out["vs_unrounded_inputs"] = {"recall_at_k": _r(vu.get("recall_at_k")), "max_abs_score_diff": _r(vu.get("max_abs_score_diff"), 4)}
+    vs = v.get("vs_stored_rounded_rows")
+    if vs:
+        out["vs_stored_rounded_rows"] = {"recall_at_k": _r(vs.get("recall_at_k")), "max_abs_score_diff": _r(vs.get("max_abs_score_diff"), 4)}
+    ex = v.get("exact_f32")
+    if ex:
+        out["exact_f32"] = {key: _r(val, 4) for key, val in ex.items()}
+    tw = v.get("ids_bit_exact_on_integer_twin")
+    if tw:
+        out["integer_twin"] = {"ids_bit_exact": tw.get("ids_bit_exact"), "scores_bit_exact": tw.get("scores_bit_exact"),
+                               "queries_checked": tw.get("queries_checked"), "rows": tw.get("rows")}
+    return out
+
+
+def compact_cpu_baseline(c: "dict | None") -> "dict | None":
+    if c is None:
+        return None
+    out = {key: _r(c.get(key)) for key in ("value", "unit", "cores", "threads", "kind", "sgemm_only_value") if key in c}
+    out["sample"] = str(c.get("sample", ""))[:300]
+    if "thread_arms" in c:
+        out["thread_arms"] = c["thread_arms"]
+    return out
+
+
+def side_summary(e: dict) -> dict:
+    """One side workload in < 400 bytes: printed as a `# side {...}` line when it finishes, and kept (shorter still) in the final line."""
+    out = {"name": e.get("name")}
+    for key in ("error", "skipped"):
+        if key in e:
+            out[key] = str(e[key])[:200]
+            return out
+    if "ms_per_step" in e:
+        out.update(ms_per_step=_r(e["ms_per_step"], 5), value=_r(e.get("value"), 6), unit=e.get("unit"), steps=e.get("steps"))
+    r = e.get("roofline")
+    if r:
+        out["roofline"] = {"bound": r["bound"], "frac": _r(r["frac"], 4), "achieved": _r(r["achieved"], 5), "unit": r["unit"],
+                           "kernel_ms_per_step": _r(r["kernel_ms_per_step"], 5)}
+    v = e.get("verify")
+    if v and "recall_at_k" in v:
+        out["verify"] = {"recall_at_k": _r(v["recall_at_k"]), "max_abs_score_diff": _r(v.get("max_abs_score_diff"), 3)}
+        vu = v.get("vs_unrounded_inputs")
+        if vu:
+            out["verify"]["vs_unrounded"] = [_r(vu.get("recall_at_k")), _r(vu.get("max_abs_score_diff"), 3)]
+        tw = v.get("ids_bit_exact_on_integer_twin")
+        if tw:
+            out["verify"]["twin_bit_exact"] = bool(tw.get("ids_bit_exact") and tw.get("scores_bit_exact"))
+    elif v:  # C5: its own verification record
+        out["verify"] = {key: v[key] for key in ("ok", "collate_cases", "gradient_cases") if key in v}
+    for key in ("collate_merge_sample", "retrieval_loss_inbatch_64x2048"):  # C5: latencies
+        if isinstance(e.get(key), dict):
+            out[key] = {kk: _r(vv, 4) for kk, vv in e[key].items() if kk in ("wall_us", "device_us", "fwd_bwd_wall_us", "graphed_fwd_bwd_wall_us", "host_syncs")}
+    return out
+
+
+def emit_side(e: dict) -> None:
+    """`# side {json}`: a comment line, NOT a JSON line - stdout keeps exactly one line that parses as JSON, the last one."""
+    print("# side " + json.dumps(_strict(side_summary(e)), allow_nan=False, separators=(",", ":")), flush=True)
+
+
+def write_side_file(side: list, headline: dict) -> "str | None":
+    """The full structure of every side workload (+ the uncut headline record) for whoever wants the detail: gpurun_out/bench_side.json."""
+    try:
+        SIDE_FILE.parent.mkdir(parents=True, exist_ok=True)
+        SIDE_FILE.write_text(json.dumps(_strict({"headline": headline, "side": side}), allow_nan=False, indent=1))
+        return str(SIDE_FILE.relative_to(ROOT))
+    except OSError:
+        return None
+
+
+def final_line(line: dict, limit: int = LINE_LIMIT) -> str:
+    """The ONE JSON line: strict JSON (no NaN / Infinity), below `limit` bytes.  Should a record still be too long (many ranks, long
+    error strings) the optional parts go first - never metric / value / ms_per_step / config / roofline / cpu_baseline."""
+    line = _strict(line)
+    for drop in (None, "side", "per_rank", "comm", "verify"):
+        if drop is not None:
+            if drop not in line:
+                continue
+            line = dict(line)
+            line[drop] = "dropped: line over the size limit (see " + str(line.get("side_file")) + ")"
+        txt = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+        if len(txt.encode()) < limit:
+            return txt
+    raise SystemExit(f"bench.py: the final line does not fit {limit} bytes even without its optional parts")
 
 
 def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
@@ -756,6 +902,7 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
                 out[-1]["verify"]["ids_bit_exact_on_integer_twin"] = twin_rec
         except Exception as exc:  # noqa: BLE001 - a side line must never take the headline down
             out.append({"name": name, "error": f"{type(exc).__name__}: {exc}"[:400]})
+        emit_side(out[-1])
 
     one("C2", rows=1_000_000, nq=256, steps=200, warmup=20)
     one("C3_nq256", rows=args.rows, nq=256, steps=50, warmup=5, index=headline_index, row_lo=headline_row_lo)
@@ -774,6 +921,7 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
         one("C4_one_gpu", rows=40_000_000, dim=1024, nq=512, k=200, dtype="bf16", steps=10, warmup=3, twin=True)
     else:
         out.append({"name": "C4_one_gpu", "skipped": f"{free_b / 1e9:.0f} GB of HBM free: the 82 GB store + workspace do not fit next to the headline store"})
+        emit_side(out[-1])
     # BASELINE configs[4] (C5: hybrid merge + priority sampling + in-batch retrieval loss, batch 64 x 32 sections)
     try:
         sys.path.insert(0, str(ROOT / "tools"))
@@ -790,7 +938,111 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
                 c5["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     except Exception as exc:  # noqa: BLE001
         out.append({"name": "C5", "error": f"{type(exc).__name__}: {exc}"[:400]})
+    emit_side(out[-1])
     return out
+
+
+DATA_NOTE = {"iid": "synthetic", "clustered": "synthetic, rows sorted by topic cluster, queries from the last clusters",
+             "duplicates": "synthetic, one section repeated over the last tenth of the store, every query aimed at it",
+             "normalized": "synthetic, rows and queries L2-normalised x 10 (scaled-cosine embeddings)"}
+
+
+def compose_record(m: dict, *, world: int, backend: str, t_build: float, comm: "dict | None", cpu_baseline: "dict | None",
+                   side: "list | None", engine: str = "ranks") -> dict:
+    """The FULL record of a run from its measurements `m` (run_workload's dict): pure - no torch, no device - so that the CPU suite can
+    check the shape and the size of the line.  `compact_record` + `final_line` cut it to the one stdout line."""
+    n_total, d, nq, k, steps = m["rows"], m["dim"], m["nq"], m["k"], m["steps"]
+    elapsed = m["elapsed"]
+    qps = nq * steps / elapsed
+    multi = m["multi"]
+    if engine == "node":
+        parallelism = f"ONE process, vodhip_node_index over {world} device(s): row-sharded, per-shard top-k copied to devices[0] + merge"
+    elif multi:
+        parallelism = f"row-sharded x{world} + {'RCCL' if backend == 'nccl' else 'gloo (host-staged)'} all-gather of per-shard top-k"
+    else:
+        parallelism = "single GPU"
+    line = {
+        "metric": f"queries/sec brute-force top-k ({_m(n_total)}x{d} {'fp16' if m['dtype'] == 'f16' else 'bf16'})",
+        "value": qps,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": m["warmup"],
+        "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": m["dtype"],
+        "data": DATA_NOTE[m["data"]],
+        "config": {
+            "workload": f"{n_total} sections x {d} {m['dtype']}, batch {nq} queries, top-{k}, exact brute force"
+                        + (", exact-f32 store (float32 rows + queries, float32 brute-force result)" if m.get("exact") else ""),
+            "rows_per_gpu": m["n_local"],
+            "parallelism": parallelism,
+            "engine": engine,
+            "index_build_s": round(t_build, 3),
+            "recovery_passes": m["recovery_passes"],
+        },
+        "roofline": roofline_of(m, world),
+    }
+    if comm is not None:  # did the collective library see N ranks?  (answerable from the record alone)
+        line["comm"] = comm
+    if m.get("per_rank"):  # every rank's own HIP-event figures: filter kernel ms / step, exchange (all-gather + merge) us / step
+        for r in m["per_rank"]:
+            r["mfma_frac_of_2.5PF"] = (2.0 * nq * r["rows"] * d / (r["kernel_ms"] * 1e-3) / NAMEPLATE_MFMA) if r["kernel_ms"] > 0 else None
+        line["per_rank"] = m["per_rank"]
+        line["exchange_us_per_step_max"] = max(r["exchange_us"] for r in m["per_rank"])
+    for key in ("per_shard", "merge_us", "peer_access"):  # the node engine's own figures
+        if m.get(key) is not None:
+            line[key] = m[key]
+    if m["verify"] is not None:
+        line["verify"] = m["verify"]
+    if side is not None:
+        line["side"] = side
+    if cpu_baseline is not None:
+        line["cpu_baseline"] = cpu_baseline
+        line["speedup_vs_cpu_baseline"] = qps / cpu_baseline["value"]
+    return line
+
+
+def compact_record(full: dict, side_file: "str | None" = None) -> dict:
+    """The final stdout line's content: the contract's keys, `roofline`, `cpu_baseline`, a short `verify`, the per-rank figures as
+    parallel lists and ONE number pair per side workload; everything else lives in `side_file`."""
+    line = {key: full[key] for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                        "vs_baseline", "dtype", "data", "config")}
+    line["value"], line["ms_per_step"] = _r(full["value"], 7), _r(full["ms_per_step"], 7)
+    line["roofline"] = compact_roofline(full["roofline"])
+    if "cpu_baseline" in full:
+        line["cpu_baseline"] = compact_cpu_baseline(full["cpu_baseline"])
+        line["speedup_vs_cpu_baseline"] = _r(full["speedup_vs_cpu_baseline"], 5)
+    if "comm" in full:
+        line["comm"] = full["comm"]
+    if "per_rank" in full:
+        pr = full["per_rank"]
+        line["per_rank"] = {"kernel_ms": [_r(r["kernel_ms"], 5) for r in pr], "exchange_us": [_r(r["exchange_us"], 4) for r in pr],
+                            "rows": [r["rows"] for r in pr], "mfma_frac_of_2.5PF": [_r(r.get("mfma_frac_of_2.5PF"), 4) for r in pr]}
+        line["exchange_us_per_step_max"] = _r(full["exchange_us_per_step_max"], 4)
+    if "per_shard" in full:
+        ps = full["per_shard"]
+        line["per_shard"] = {"kernel_ms": [_r(r["kernel_ms"], 5) for r in ps], "rows": [r["rows"] for r in ps], "device": [r["device"] for r in ps]}
+        line["merge_us"] = _r(full.get("merge_us"), 4)
+        line["peer_access"] = full.get("peer_access")
+    if "verify" in full:
+        line["verify"] = compact_verify(full["verify"])
+    if "side" in full:  # name -> [ms / step, roofline.frac, bound] (errors / skips as a string); the detail is in the `# side` lines and the file
+        short = {}
+        for e in full["side"]:
+            if "error" in e or "skipped" in e:
+                short[e.get("name")] = ("error: " + str(e["error"]))[:80] if "error" in e else "skipped"
+            elif "roofline" in e:
+                short[e["name"]] = [_r(e["ms_per_step"], 5), _r(e["roofline"]["frac"], 4), e["roofline"]["bound"]]
+            else:
+                short[e.get("name")] = "ok" if (e.get("verify") or {}).get("ok") else "see side_file"
+        line["side"] = short
+        line["side_legend"] = "name: [ms_per_step, roofline.frac, bound]; detail: the '# side' stdout lines and side_file"
+    if side_file:
+        line["side_file"] = side_file
+    return line
 
 
 def main() -> None:
@@ -844,50 +1096,14 @@ def main() -> None:
 
     line = None
     if rank == 0:
-        elapsed = m["elapsed"]
-        qps = nq * args.steps / elapsed
-        line = {
-            "metric": f"queries/sec brute-force top-k ({_m(n_total)}x{d} {'fp16' if args.dtype == 'f16' else 'bf16'})",
-            "value": qps,
-            "unit": "queries/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": {"iid": "synthetic", "clustered": "synthetic, rows sorted by topic cluster, queries from the last clusters",
-                     "duplicates": "synthetic, one section repeated over the last tenth of the store, every query aimed at it",
-                     "normalized": "synthetic, rows and queries L2-normalised x 10 (scaled-cosine embeddings)"}[args.data],
-            "config": {
-                "workload": f"{n_total} sections x {d} {args.dtype}, batch {nq} queries, top-{k}, exact brute force"
-                            + (", exact-f32 store (float32 rows + queries, float32 brute-force result)" if args.exact_f32 else ""),
-                "rows_per_gpu": m["n_local"],
-                "parallelism": (f"row-sharded x{world} + {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged)'} all-gather of per-shard top-k") if multi else "single GPU",
-                "index_build_s": round(t_build, 3),
-                "recovery_passes": m["recovery_passes"],
-            },
-            "roofline": roofline_of(m, world),
-        }
-        if rig.comm is not None:  # did the collective library see N ranks?  (answerable from the record alone)
-            line["comm"] = rig.comm
-        if m.get("per_rank"):  # every rank's own HIP-event figures: filter kernel ms / step, exchange (all-gather + merge) us / step
-            peak_flops = 2.5e15
-            for r in m["per_rank"]:
-                r["mfma_frac_of_2.5PF"] = (2.0 * nq * r["rows"] * d / (r["kernel_ms"] * 1e-3) / peak_flops) if r["kernel_ms"] > 0 else None
-            line["per_rank"] = m["per_rank"]
-            line["exchange_us_per_step_max"] = max(r["exchange_us"] for r in m["per_rank"])
-        if m["verify"] is not None:
-            line["verify"] = m["verify"]
-        if side is not None:
-            line["side"] = side
+        cpu = None
         if world == 1 and not args.no_cpu_baseline:
             from oracle.cpu_baseline import time_cpu_baseline  # the reported CPU baseline, never the product path
 
-            line["cpu_baseline"] = time_cpu_baseline(d, nq, k, n_total, target_seconds=args.cpu_seconds)
-            line["speedup_vs_cpu_baseline"] = qps / line["cpu_baseline"]["value"]
+            cpu = time_cpu_baseline(d, nq, k, n_total, target_seconds=args.cpu_seconds)
+        full = compose_record(m, world=world, backend=args.backend, t_build=t_build, comm=rig.comm, cpu_baseline=cpu, side=side)
+        side_file = write_side_file(side or [], full) if side is not None else None
+        line = final_line(compact_record(full, side_file))
     if rig.dist is not None:
         rig.dist.barrier()
         rig.dist.destroy_process_group()
@@ -897,7 +1113,7 @@ def main() -> None:
         import ctypes
 
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(line), flush=True)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

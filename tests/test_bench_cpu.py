@@ -87,3 +87,100 @@ def test_a_rank_that_never_arrives_times_out_instead_of_hanging():
     assert out.returncode == 75, (out.returncode, out.stderr[-1500:])
     assert "did not complete within 8 s" in out.stderr
     assert time.time() - t0 < 120
+
+
+# ---- the shape and the size of the final stdout line (round 5's 20.6 KB line was unreadable for the driver: BENCH_r05 parsed null) ----
+
+def _fake_measurement(world=1, exact=False):
+    nan = float("nan")
+    verify = {"comparator": "float64 chunked product over the stored (rounded) rows and queries (ties -> smaller id)", "recall_at_k": 1.0,
+              "rows_with_identical_id_order": 1.0, "max_abs_score_diff": 3.0517578125e-05, "max_rel_score_diff": nan, "score_scale": 166.68293821497866,
+              "queries_checked": 64,
+              "vs_unrounded_inputs": {"recall_at_k": 0.99921875, "max_abs_score_diff": 0.030087730498053133, "rows_with_identical_id_order": 0.3, "score_scale": 166.7},
+              "ids_bit_exact_on_integer_twin": {"ids_bit_exact": True, "scores_bit_exact": True, "queries_checked": 64, "rows": 10_000_000,
+                                                "tied_neighbours_in_the_reference_lists": 5123, "data": "integer-valued rows " * 8}}
+    m = {"elapsed": 0.26, "filter_ns": 256_000_000, "filter_launches": 80, "recovery_passes": 0, "recovery_ns": 0, "verify": verify,
+         "n_local": 10_000_000 // world, "steps": 20, "warmup": 5, "rows": 10_000_000, "dim": 768, "nq": 1024, "k": 100, "dtype": "f16",
+         "data": "iid", "multi": world > 1, "tile": 0, "exact": exact, "per_rank": None}
+    if world > 1:
+        m["per_rank"] = [{"rank": r, "kernel_ms": 1.6123456789 + r * 1e-3, "exchange_us": 41.23456789, "rows": 10_000_000 // world} for r in range(world)]
+    return m
+
+
+def _fake_side(bench):
+    side = []
+    for name in ["C2", "C3_nq256", "C3_clustered", "C3_shard_of_8", "C3_shard_of_8_with_exchange", "C4_shard_of_8", "C2_exact_f32", "C3_exact_f32",
+                 "C4_shard_of_8_exact_f32", "C4_one_gpu"]:
+        m = _fake_measurement()
+        side.append({"name": name, "workload": "x" * 150, "steps": 200, "warmup": 20, "ms_per_step": 0.4521234567, "value": 566123.456789, "unit": "queries/s",
+                     "recovery_passes": 0, "index_build_s": 0.017, "roofline": bench.roofline_of(m, 1), "verify": m["verify"]})
+    side.append({"name": "C5", "verify": {"ok": True, "collate_cases": 5, "gradient_cases": 5}, "collate_merge_sample": {"wall_us": 91.2, "device_us": 60.1, "host_syncs": 0},
+                 "retrieval_loss_inbatch_64x2048": {"fwd_bwd_wall_us": 130.0, "graphed_fwd_bwd_wall_us": 40.0, "junk": "y" * 500}, "more": ["z" * 100] * 20})
+    side.append({"name": "broken", "error": "RuntimeError: " + "e" * 390})
+    return side
+
+
+def _load_bench():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", ROOT / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_final_line_is_strict_json_below_4k_with_roofline_and_cpu_baseline(capsys):
+    bench = _load_bench()
+    cpu = {"value": 59.7, "unit": "queries/s", "cores": 16, "threads": 16, "kind": "port", "sample": "s" * 500, "thread_arms": {"16": 59.7, "32": 43.7},
+           "sgemm_only_value": 70.1, "sgemm_only_note": "n" * 200}
+    worst = 0
+    for world, comm in ((1, None), (8, {"backend": "rccl", "world_size": 8, "ranks_in_first_all_reduce": 8, "rccl_version": "2.26.6", "comm_init_s": 2.345})):
+        for exact in (False, True):
+            m = _fake_measurement(world, exact)
+            if exact:
+                m["verify"]["vs_stored_rounded_rows"] = {"recall_at_k": 0.999, "max_abs_score_diff": 0.03}
+                m["verify"]["exact_f32"] = {"band_queries_per_step": 0.0, "list_rows_k_prime": 126}
+            side = _fake_side(bench) if world == 1 else None
+            full = bench.compose_record(m, world=world, backend="nccl", t_build=0.025, comm=comm, cpu_baseline=cpu if world == 1 else None, side=side)
+            txt = bench.final_line(bench.compact_record(full, "gpurun_out/bench_side.json" if side else None))
+            assert "\n" not in txt and len(txt.encode()) < 4096, len(txt)
+            worst = max(worst, len(txt.encode()))
+            rec = json.loads(txt, parse_constant=lambda c: (_ for _ in ()).throw(AssertionError(f"non-strict JSON constant {c}")))
+            assert {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                    "config", "roofline"} <= set(rec)
+            assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "practical"} <= set(rec["roofline"])
+            assert rec["config"]["workload"].startswith("10000000 sections x 768") and "model" not in rec["config"]
+            assert rec["verify"]["recall_at_k"] == 1.0 and rec["verify"]["integer_twin"]["ids_bit_exact"] is True
+            if world == 1:
+                assert {"value", "unit", "cores", "kind", "sample"} <= set(rec["cpu_baseline"]) and len(rec["cpu_baseline"]["sample"]) <= 300
+                assert rec["side"]["C2"] == [0.45212, rec["side"]["C2"][1], rec["side"]["C2"][2]] and rec["side"]["broken"].startswith("error")
+                assert rec["side_file"] == "gpurun_out/bench_side.json"
+            else:
+                assert len(rec["per_rank"]["kernel_ms"]) == 8 and rec["comm"]["world_size"] == 8
+    assert worst > 1500  # (the fixture really exercised a full line)
+    # every side workload: ONE comment line (not a JSON line: stdout keeps exactly one line that parses as JSON), < 400 bytes
+    for e in _fake_side(bench):
+        bench.emit_side(e)
+    lines = capsys.readouterr().out.splitlines()
+    assert len(lines) == 12 and all(ln.startswith("# side {") and len(ln) < 400 for ln in lines), [len(ln) for ln in lines]
+    assert json.loads(lines[0][len("# side "):])["roofline"]["bound"] in ("mfma", "hbm")
+
+
+def test_final_line_sheds_optional_parts_before_it_breaks_the_limit():
+    bench = _load_bench()
+    m = _fake_measurement(8)
+    full = bench.compose_record(m, world=8, backend="nccl", t_build=0.025, comm={"backend": "rccl", "note": "c" * 3000}, cpu_baseline=None, side=None)
+    rec = json.loads(bench.final_line(bench.compact_record(full)))
+    assert isinstance(rec["comm"], str) and rec["comm"].startswith("dropped") and rec["roofline"]["frac"] > 0 and rec["value"] > 0
+
+
+def test_roofline_bound_follows_the_nameplate_peaks_and_the_traffic_key_carries_the_mode():
+    bench = _load_bench()
+    c2 = dict(_fake_measurement(), rows=1_000_000, n_local=1_000_000, nq=256, elapsed=0.0045 * 20, filter_ns=int(0.4e6 * 20))
+    r = bench.roofline_of(c2, 1)  # C2 is HBM-bound at 8 TB/s vs 2.5 PF (0.192 ms vs 0.157 ms)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["hbm_frac_at_8TBps"]) < 1e-12
+    assert r["practical"]["bound"] == "mfma"  # (at 1.24 PF / 6.29 TB/s the same shape is MFMA-bound: context only)
+    r = bench.roofline_of(_fake_measurement(), 1)
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["mfma_frac_of_2.5PF"]) < 1e-12
+    assert bench.traffic_key(10_000_000, 768, 1024, 1) == "10000000x768x1024@1"
+    assert bench.traffic_key(10_000_000, 768, 1024, 1, "clustered", True) == "10000000x768x1024@1/clustered/exact"

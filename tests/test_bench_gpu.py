@@ -16,13 +16,21 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config", "roofline"}
 
 
+def _strict_loads(txt):
+    def refuse(const):
+        raise AssertionError(f"non-strict JSON constant {const} in the bench line")
+
+    return json.loads(txt, parse_constant=refuse)
+
+
 def _run(*extra):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--rows", "300000", "--nq", "1024", "--steps", "3", "--warmup", "1", *extra],
                          capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
-    line = json.loads(lines[-1])  # the JSON line is the last line of stdout, whatever the libraries printed before
+    assert len(lines[-1].encode()) < 4096, len(lines[-1])
+    line = _strict_loads(lines[-1])  # the JSON line is the last line of stdout, whatever the libraries printed before
     assert REQUIRED <= set(line), REQUIRED - set(line)
     assert sum(ln.lstrip().startswith("{") for ln in lines) == 1
     return line
@@ -135,8 +143,11 @@ def _run_bench(*args, timeout=900):
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=env, cwd=str(ROOT))
     assert out.returncode == 0, (out.stderr[-3000:], out.stdout[-1000:])
     lines = [ln for ln in out.stdout.splitlines() if ln.lstrip().startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    assert len(lines) == 1, out.stdout[-2000:]   # exactly ONE line of stdout parses as JSON ...
+    assert out.stdout.rstrip().splitlines()[-1] == lines[0] and len(lines[0].encode()) < 4096, len(lines[0])  # ... the last one, below 4 KB
+    rec = _strict_loads(lines[0])
+    rec["_side_lines"] = [_strict_loads(ln[len("# side "):]) for ln in out.stdout.splitlines() if ln.startswith("# side ")]
+    return rec
 
 
 def test_bench_two_ranks_only_one_shard_overflows_stays_collective_safe():
@@ -163,11 +174,11 @@ def test_bench_eight_ranks_sharing_the_gpu_headline_shape():
     assert rec["verify"]["recall_at_k"] == 1.0 and rec["verify"]["max_abs_score_diff"] < 1e-3
     assert "all-gather" in rec["config"]["parallelism"]
     # round 5: one SCALE pass yields, per rank, the filter-kernel time, its roofline fraction and the exchange cost (HIP events)
-    assert [r["rank"] for r in rec["per_rank"]] == list(range(8))
-    for r in rec["per_rank"]:
-        assert r["rows"] == 250_000 and r["kernel_ms"] > 0 and r["exchange_us"] > 0 and 0 < r["mfma_frac_of_2.5PF"] < 1
-    assert rec["exchange_us_per_step_max"] == max(r["exchange_us"] for r in rec["per_rank"])
-    twin = rec["verify"]["ids_bit_exact_on_integer_twin"]  # merged over the eight ranks
+    pr = rec["per_rank"]  # (parallel lists, rank order: the line stays below 4 KB)
+    assert pr["rows"] == [250_000] * 8 and len(pr["kernel_ms"]) == len(pr["exchange_us"]) == 8
+    assert all(v > 0 for v in pr["kernel_ms"] + pr["exchange_us"]) and all(0 < v < 1 for v in pr["mfma_frac_of_2.5PF"])
+    assert abs(rec["exchange_us_per_step_max"] - max(pr["exchange_us"])) <= 1e-3 * max(pr["exchange_us"])
+    twin = rec["verify"]["integer_twin"]  # merged over the eight ranks
     assert twin["ids_bit_exact"] is True and twin["scores_bit_exact"] is True
 
 
@@ -179,19 +190,28 @@ def test_bench_c4_preset_and_exact_mode_across_two_ranks():
     assert "x 1024 bf16, batch 512 queries, top-200" in rec["config"]["workload"] and "exact-f32" in rec["config"]["workload"]
     assert rec["verify"]["recall_at_k"] == 1.0 and rec["verify"]["max_abs_score_diff"] < 1e-3 and "UNROUNDED" in rec["verify"]["comparator"]
     assert rec["verify"]["vs_stored_rounded_rows"]["max_abs_score_diff"] > 1e-3  # (the bf16 scan alone would be this far off)
-    assert len(rec["per_rank"]) == 2
+    assert len(rec["per_rank"]["kernel_ms"]) == 2
 
 
 def test_bench_default_line_carries_the_side_workloads():
-    """The default 1-GPU run appends C2, nq = 256, clustered C3 and the 1.25 M-row shard with the exchange as `side`
-    (small row counts here: the plumbing, not the numbers)."""
+    """The default 1-GPU run times C2, nq = 256, clustered C3, the 1.25 M-row shard with the exchange, C4 and C5 next to the headline.
+    Round 6: the final line stays below 4 KB (name -> [ms, frac, bound] per side workload); every side workload prints one `# side` comment
+    line when it finishes and the full records go to gpurun_out/bench_side.json."""
     rec = _run_bench("--steps", "3", "--warmup", "1", "--cpu-seconds", "1")
     assert rec["config"]["workload"].startswith("10000000 sections x 768")
-    names = [s_["name"] for s_ in rec["side"]]
-    # round 4: every BASELINE config is driver-timed - C4 (its per-GPU shard and the whole 82 GB store on this one GPU) and C5
-    assert names == ["C2", "C3_nq256", "C3_clustered", "C3_shard_of_8", "C3_shard_of_8_with_exchange", "C4_shard_of_8",
-                     "C2_exact_f32", "C3_exact_f32", "C4_shard_of_8_exact_f32", "C4_one_gpu", "C5"]
-    for s_ in rec["side"][:10]:
+    names = ["C2", "C3_nq256", "C3_clustered", "C3_shard_of_8", "C3_shard_of_8_with_exchange", "C4_shard_of_8",
+             "C2_exact_f32", "C3_exact_f32", "C4_shard_of_8_exact_f32", "C4_one_gpu", "C5"]
+    assert list(rec["side"]) == names and [s_["name"] for s_ in rec["_side_lines"]] == names
+    for name in names[:10]:
+        ms, frac, bound = rec["side"][name]
+        assert ms > 0 and frac > 0.05 and bound in ("mfma", "hbm")
+    assert rec["side"]["C2"][2] == "hbm" and rec["side"]["C3_exact_f32"][2] == "mfma"  # SURVEY 8d's table: the nameplate roofs
+    assert rec["side"]["C5"] == "ok"
+    for s_ in rec["_side_lines"][:10]:
+        assert s_["verify"]["recall_at_k"] == 1.0 and s_["verify"]["max_abs_score_diff"] < 1e-3 and s_["roofline"]["frac"] > 0.05
+    full = json.loads((ROOT / rec["side_file"]).read_text())
+    assert [s_["name"] for s_ in full["side"]] == names and full["headline"]["value"] > 0
+    for s_ in full["side"][:10]:
         assert "error" not in s_ and "skipped" not in s_, s_
         assert s_["verify"]["recall_at_k"] == 1.0 and s_["roofline"]["frac"] > 0.05
         assert s_["verify"]["comparator"].startswith("float64") and s_["verify"]["max_abs_score_diff"] < 1e-3
@@ -203,12 +223,12 @@ def test_bench_default_line_carries_the_side_workloads():
             assert s_["verify"]["exact_f32"]["list_rows_k_prime"] > 100
         else:  # a rounded store carries its rounding (fp16: ~1e-2, bf16: ~0.2): on the record, not hidden
             assert vu["max_abs_score_diff"] > 1e-3
-    twin = rec["side"][9]["verify"]["ids_bit_exact_on_integer_twin"]  # C4 at full size
+    twin = full["side"][9]["verify"]["ids_bit_exact_on_integer_twin"]  # C4 at full size
     assert twin["ids_bit_exact"] is True and twin["scores_bit_exact"] is True and twin["rows"] == 40_000_000
-    twin = rec["verify"]["ids_bit_exact_on_integer_twin"]              # the headline at full size
+    twin = rec["verify"]["integer_twin"]              # the headline at full size
     assert twin["ids_bit_exact"] is True and twin["scores_bit_exact"] is True and twin["rows"] == 10_000_000 and twin["queries_checked"] >= 32
     assert rec["verify"]["vs_unrounded_inputs"]["max_abs_score_diff"] > 1e-3
-    c5 = rec["side"][10]
+    c5 = full["side"][10]
     assert "error" not in c5, c5
     assert c5["verify"]["ok"] is True and c5["verify"]["collate_cases"] >= 4 and c5["verify"]["gradient_cases"] == 5
     assert c5["collate_merge_sample"]["host_syncs"] == 0 and c5["collate_merge_sample_flatten"]["host_syncs"] == 0
@@ -222,5 +242,7 @@ def test_bench_default_line_carries_the_side_workloads():
     for shape in ("retrieval_loss_3d_64x32", "retrieval_loss_inbatch_64x2048"):
         assert c5["reference_op_sequence"][shape]["fwd_bwd_wall_us"] > 0 and c5["reference_op_sequence"][shape]["fused_equals_op_sequence"] is True
     assert rec["comm"]["world_size"] == 1 and rec["comm"]["ranks_in_first_all_reduce"] == 1  # (the exchange side line brought RCCL up)
-    assert {"bound", "mfma_frac_of_2.5PF", "hbm_frac_at_8TBps", "frac", "achieved", "peak", "traffic"} <= set(rec["roofline"])
+    assert {"bound", "mfma_frac_of_2.5PF", "hbm_frac_at_8TBps", "frac", "achieved", "peak", "traffic", "practical"} <= set(rec["roofline"])
+    assert rec["roofline"]["traffic_source"] and "exact" not in rec["roofline"]["traffic_source"]  # (round 5: the exact-mode PMC run had taken the plain key)
     assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["threads"] >= 1 and rec["cpu_baseline"]["cores"] >= 1
+    assert len(rec["cpu_baseline"]["thread_arms"]) >= 1 and rec["cpu_baseline"]["value"] == max(rec["cpu_baseline"]["thread_arms"].values())

@@ -12,7 +12,7 @@ for rep in $(seq 1 $REPS); do
     if [ -n "${ONLY:-}" ] && ! echo " $ONLY " | grep -q " $name "; then continue; fi
     for order in 0 1; do
       res=$(timeout 600 python bench.py "$@" --no-side --no-cpu-baseline --verify-queries 16 --param tile_order=$order 2>/dev/null | tail -1 | \
-            python -c "import sys,json; d=json.loads(sys.stdin.read()); v=d['verify']; print(round(d['ms_per_step'],4), 'kernel_ms', round(d['roofline']['kernel_ms_per_step'],4), 'recall', v['recall_at_k'], 'diff', v['max_abs_score_diff'], 'twin', v['ids_bit_exact_on_integer_twin']['ids_bit_exact'], 'recov', d['config']['recovery_passes'])")
+            python -c "import sys,json; d=json.loads(sys.stdin.read()); v=d['verify']; print(round(d['ms_per_step'],4), 'kernel_ms', round(d['roofline']['kernel_ms_per_step'],4), 'recall', v['recall_at_k'], 'diff', v['max_abs_score_diff'], 'twin', v['integer_twin']['ids_bit_exact'], 'recov', d['config']['recovery_passes'])")
       echo "$name tile_order=$order rep$rep ms $res" | tee -a $OUT
     done
   done

@@ -8,7 +8,7 @@ Per cell: aggregate queries/s, request latency p50 / p99, and the ratio to the d
 P * nq queries (what a perfect boundary in front of the same kernels would deliver).
 
 Round 4: the server's DEFAULT settings are what is measured (`--http native`: libvodhip's front + batch-while-busy request fusion, no
-wait window); `--http asyncio` / `--micro-batch-ms` reproduce round 3's shells for an A/B.  Per cell the server's own counters
+wait window); `--http uvicorn` / `--micro-batch-ms` reproduce round 3's shells for an A/B.  Per cell the server's own counters
 (GET /stats) give the mean fused batch and the share of the cell the engine sat idle.
 
     python tools/bench_http_load.py [--rows 10000000] [--dim 768] [--k 100] [--seconds 2.5] [--out profiles/r04_http_load.json]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 GPU passes (one gpurun call each; outputs under gpurun_out/r4/<pass>/).  usage: tools/gpu_pass.sh <pass>
 #   serve   GPU tests of the serving path + the boundary under the trainer's load shape (tools/bench_http_load.py, default flags)
-#   serve_ab  the same load cells through round 3's Python shell (asyncio, window 0 / 1 ms) for the A/B
+#   serve_ab  the same load cells through round 3's Python shell (uvicorn shell, window 0 / 1 ms) for the A/B
 #   tests   the whole -m gpu suite + smoke
 #   bench   the default bench line
 #   load / c5 / grid   see the case arms below
@@ -18,7 +18,7 @@ case $P in
     timeout 900 python -m pytest tests/test_server_gpu.py tests/test_fuzz_gpu.py tests/test_node_index_gpu.py -x -q -m gpu > $OUT/pytest_serve.log 2>&1; tail -5 $OUT/pytest_serve.log
     timeout 1500 python tools/bench_http_load.py --out $OUT/http_load_native.json > $OUT/http_load_native.log 2>&1; tail -25 $OUT/http_load_native.log | cut -c1-400 ;;
   serve_ab)
-    timeout 900 python tools/bench_http_load.py --http asyncio --micro-batch-ms 0 1 --routes fast --nq 32 64 --out $OUT/http_load_asyncio.json > $OUT/http_load_asyncio.log 2>&1; tail -14 $OUT/http_load_asyncio.log | cut -c1-300 ;;
+    timeout 900 python tools/bench_http_load.py --http uvicorn --micro-batch-ms 0 1 --routes fast --nq 32 64 --out $OUT/http_load_uvicorn.json > $OUT/http_load_uvicorn.log 2>&1; tail -14 $OUT/http_load_uvicorn.log | cut -c1-300 ;;
   load)   # the load cells only (no tests)
     timeout 1500 python tools/bench_http_load.py --out $OUT/http_load_native.json > $OUT/http_load_native.log 2>&1; tail -25 $OUT/http_load_native.log | cut -c1-420 ;;
   c5)     # host-time probe of the retrieval loss + the C5 side entry (with the restated CPU / op-sequence baselines)
@@ -37,9 +37,9 @@ case $P in
         done
       done
     done ;;
-  fuzz)   # randomised campaigns at HEAD: the boundary (native front: single / window / worker group / node index; asyncio shell), search, collate
+  fuzz)   # randomised campaigns at HEAD: the boundary (native front: single / window / worker group / node index; uvicorn shell), search, collate
     for args in "--requests 800 --threads 16 --seed 41" "--requests 600 --threads 16 --seed 42 --wait-ms 5" "--requests 500 --threads 12 --seed 43 --group" \
-                "--requests 500 --threads 12 --seed 44 --node" "--requests 400 --threads 12 --seed 45 --http asyncio"; do
+                "--requests 500 --threads 12 --seed 44 --node" "--requests 400 --threads 12 --seed 45 --http uvicorn"; do
       timeout 900 python tests/fuzz/fuzz_server.py $args 2>/dev/null | tail -3 | tee -a $OUT/fuzz_server.txt
     done
     timeout 1500 python tests/fuzz/fuzz_search.py --trials 3000 --seed 404 2>/dev/null | tail -3 | tee -a $OUT/fuzz_search.txt

@@ -78,7 +78,8 @@ for bench in sorted(src.glob("*_bench.json")):
                   "sq1/tcc1/tcc2; sums over the filter launches (bootstrap + stages) of one batch")
     (prof / f"{rnd}_{w}_pmc_filter_per_step.json").write_text(json.dumps(s, indent=1))
     cfg = line["config"]["workload"].split()
-    key = f"{cfg[0]}x{cfg[3]}x{cfg[6]}@{line['n_gpus']}" + ("" if line["data"] == "synthetic" else "/clustered")
+    key = (f"{cfg[0]}x{cfg[3]}x{cfg[6]}@{line['n_gpus']}" + ("" if line["data"] == "synthetic" else "/clustered")
+           + ("/exact" if "exact-f32" in line["config"]["workload"] else ""))  # bench.py's traffic_key(): the store mode is part of the key
     traffic[key] = {"bytes": fetch + wr, "source": f"profiles/{rnd}_{w}_pmc_filter_per_step.json"}
     print(f"    PMC: HBM {fetch + wr:.4g} B = {s['traffic_over_algorithmic']:.3f}x algorithmic, MFMA busy {s['mfma_busy_frac']}, L2 hit {s['l2_hit_rate']}, "
           f"LDS conflicts {tot.get('SQ_LDS_BANK_CONFLICT')}")
