@@ -245,4 +245,4 @@ def test_bench_default_line_carries_the_side_workloads():
     assert {"bound", "mfma_frac_of_2.5PF", "hbm_frac_at_8TBps", "frac", "achieved", "peak", "traffic", "practical"} <= set(rec["roofline"])
     assert rec["roofline"]["traffic_source"] and "exact" not in rec["roofline"]["traffic_source"]  # (round 5: the exact-mode PMC run had taken the plain key)
     assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["threads"] >= 1 and rec["cpu_baseline"]["cores"] >= 1
-    assert len(rec["cpu_baseline"]["thread_arms"]) >= 1 and rec["cpu_baseline"]["value"] == max(rec["cpu_baseline"]["thread_arms"].values())
+    assert len(rec["cpu_baseline"]["thread_arms"]) >= 1 and abs(rec["cpu_baseline"]["value"] - max(rec["cpu_baseline"]["thread_arms"].values())) < 0.01
