@@ -138,9 +138,17 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
  *   "lanes" (0 = auto, 1, 2: with 2 lanes consecutive searches alternate between two workspaces, the second on a stream of the index's
  *   own that starts behind the work the caller's stream holds at enqueue - two searches of a caller that runs one search ahead overlap
  *   on the device; auto = 2 for batches of up to 256 queries, where a search's select / prepare launches and partly filled last
- *   rounds leave ~12 % of the device idle; results and the finish contract are unchanged),
+ *   rounds leave ~12 % of the device idle; results are unchanged.  STREAM ORDERING with 2 lanes: every second search in flight runs on
+ *   the index's stream, so work the caller enqueues on ITS stream behind vodhip_index_search_async is NOT ordered behind that search:
+ *   only vodhip_index_search_finish completes a search - a hipStreamSynchronize of the caller's stream does not; set "lanes" = 1 to keep
+ *   every search on the caller's stream.  add / reset / set_row_labels refuse while searches are in flight),
  *   "exact_expand" (x100, VODHIP_EXACT_F32 stores: the scan lists k' = k * exact_expand / 100 + 16 rows per
- *   query; 0 = default: 110 for an fp16 store, 200 for bf16; speed only - results are exact for any value).
+ *   query; 0 = default: 110 for an fp16 store, 200 for bf16 as the upper limit, with k' following what the last searches of the same k
+ *   needed ("exact_adapt" = 1, default; 0 = always the formula); speed only - results are exact for any value).
+ * VODHIP_EXACT_F32 input range: finite float32 rows and queries of ANY magnitude whose squared norm is finite in float32 (|x| < 1.8e19)
+ *   give the float32 brute-force result; values beyond the scan dtype's range (fp16: |v| > 65504) saturate in the scan copy only, and
+ *   the up to 64 rows whose norm / rounding error exceeds the rest of the store's by 2x or more ("outliers") are scored exactly by
+ *   every query instead of widening the error bound.  Rows with NaN / inf components never enter a result (NaN scores are dropped).
  * stats (of the search completed by the last vodhip_index_search_finish): "last_overflow" (a candidate list overflowed),
  *   "last_safe_reruns" (recovery passes run), "last_recovered_queries" (queries the first recovery pass re-searched),
  *   "last_chunks" (stages), "last_filter_launches", "last_filter_ns" (with "profile"), "last_recovery_launches",

@@ -21,6 +21,15 @@
 //      candidate lists that overflow split the pass into more stages, down to dense chunks that cannot overflow.
 //
 // One kernel does the re-scoring in both shapes (a top-k' list / a stage's candidate list folded into a running top-k).
+//
+// Round 6 - input range and outliers.  (a) finite float32 values beyond the store dtype's range SATURATE in the scan copy
+// (mips_common.h: `saturate_for_store`), rows and queries alike, so x - x~ and q - q~ stay finite and enter the bound.  (b) the maxima
+// of the bound are taken over the ORDINARY rows only: every row's |x|^2 and |x - x~|^2 are kept (8 bytes per row); before the first
+// search after rows were added the maxima are re-derived: with M the largest value, the rows above M / 4^j for the largest j that
+// leaves at most EXACT_MAX_OUTLIERS of them are OUTLIERS (separately for the two statistics; j = 0: none).  Outliers are not bounded,
+// they are SCORED: every query re-scores all of them next to its list (LIST) / its first stage's candidates (CAND), and a list entry
+// or candidate that is an outlier is dropped in favour of that copy.  One row of norm 1e5 in a store of norm-30 rows therefore costs
+// every query one more float32 dot product instead of widening every query's eps 3000-fold (round 5: every query fell to the BAND pass).
 #include <algorithm>
 
 #include "mips_common.h"
@@ -98,9 +107,10 @@ __device__ __forceinline__ void exact_dot_preload(const float* __restrict__ plan
     for (int n = 0; n < NC; ++n) out[n] = wave_sum_fixed((acc[n][0] + acc[n][1]) + (acc[n][2] + acc[n][3]));
 }
 
-__device__ __forceinline__ float round_to_store(float f, int store_dtype) {
-    if (store_dtype == 0) return (float)(_Float16)f;
-    return (float)(__bf16)f;
+__device__ __forceinline__ float round_to_store(float f, int store_dtype) {  // what mips_prepare_kernel stages for the scan
+    float r;
+    (void)store_bits(f, store_dtype, &r);
+    return r;
 }
 
 constexpr int XT = 512;  // threads of the re-scoring workgroup
@@ -132,7 +142,8 @@ __device__ __forceinline__ void sort_desc_lds(key_t64* keys, int P, int tid) {
 template <int SRC, int DST>
 __global__ __launch_bounds__(256) void ingest_exact_kernel(const void* __restrict__ src, int64_t n_rows, int64_t dim,
                                                            uint16_t* __restrict__ dst16, float* __restrict__ dst32, int64_t stride,
-                                                           unsigned int* __restrict__ stats) {
+                                                           unsigned int* __restrict__ stats, float* __restrict__ row_n2,
+                                                           float* __restrict__ row_d2) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
@@ -174,15 +185,7 @@ __global__ __launch_bounds__(256) void ingest_exact_kernel(const void* __restric
             const float v = in[e];
             f[e] = v;
             float r;
-            if constexpr (DST == 0) {
-                const _Float16 hv = (_Float16)v;
-                h[e] = __builtin_bit_cast(uint16_t, hv);
-                r = (float)hv;
-            } else {
-                const __bf16 hv = (__bf16)v;
-                h[e] = __builtin_bit_cast(uint16_t, hv);
-                r = (float)hv;
-            }
+            h[e] = store_bits(v, DST, &r);  // (finite values beyond the store dtype's range saturate: x - x~ stays finite)
             n2 = __builtin_fmaf(v, v, n2);
             d2 = __builtin_fmaf(v - r, v - r, d2);
         }
@@ -194,6 +197,10 @@ __global__ __launch_bounds__(256) void ingest_exact_kernel(const void* __restric
     d2 = wave_sum_fixed(d2);
     // (atomics on ONE address execute one after the other, ~3 ns each: only a row that would raise a maximum issues one - after the
     // first few hundred rows almost none does)
+    if (lane == 0) {
+        row_n2[row] = n2;
+        row_d2[row] = d2;
+    }
     if (lane == 0 && n2 < __builtin_inff()) {  // (false for NaN too)
         if (__float_as_uint(n2) > __hip_atomic_load(stats + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(stats + 0, __float_as_uint(n2));
         if (d2 < __builtin_inff() && __float_as_uint(d2) > __hip_atomic_load(stats + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -202,18 +209,115 @@ __global__ __launch_bounds__(256) void ingest_exact_kernel(const void* __restric
 }
 
 hipError_t launch_ingest_exact(const void* src, int src_dtype, int64_t n_rows, int64_t dim, void* dst16, int dst_dtype, float* dst32,
-                               int64_t stride, unsigned int* stats, hipStream_t stream) {
+                               int64_t stride, unsigned int* stats, float* row_n2, float* row_d2, hipStream_t stream) {
     if (n_rows == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((n_rows + 3) / 4);
 #define VOD_ING(S, D)                                                                                                          \
     if (src_dtype == S && dst_dtype == D) {                                                                                    \
         hipLaunchKernelGGL((ingest_exact_kernel<S, D>), dim3(blocks), dim3(256), 0, stream, src, n_rows, dim, (uint16_t*)dst16, \
-                           dst32, stride, stats);                                                                              \
+                           dst32, stride, stats, row_n2, row_d2);                                                              \
         return hipGetLastError();                                                                                              \
     }
     VOD_ING(0, 0) VOD_ING(1, 0) VOD_ING(2, 0) VOD_ING(0, 1) VOD_ING(1, 1) VOD_ING(2, 1)
 #undef VOD_ING
     return hipErrorInvalidValue;
+}
+
+// ---- the maxima of the bound over the ORDINARY rows, and the outliers ----------------------------------------------------------
+// words of the statistics buffer (ExactStatsWords in vodhip_internal.h): [0] max n2 bits, [1] max d2 bits (atomicMax at ingest),
+// [2] ordinary max n2, [3] ordinary max d2, [4] number of outliers, [5] cut n2, [6] cut d2 (float bits), [8 + j] / [24 + j]: rows of
+// level j of n2 / d2, [64 ...] the outliers' rows.
+namespace {
+
+constexpr int LEVELS = 15;  // cuts M / 4^1 .. M / 4^15 (a factor 2^15 in the norm)
+
+// the level of a value: the smallest j >= 1 with v > M / 4^j (LEVELS + 1: below every cut).  Power-of-two scaling: exact.
+__device__ __forceinline__ int level_of(float v, float m) {
+    float t = m;
+#pragma unroll 1
+    for (int j = 1; j <= LEVELS; ++j) {
+        t *= 0.25f;
+        if (v > t) return j;
+    }
+    return LEVELS + 1;
+}
+
+__global__ __launch_bounds__(256) void exact_stats_levels_kernel(const float* __restrict__ row_n2, const float* __restrict__ row_d2,
+                                                                 int64_t n, unsigned int* __restrict__ st) {
+    __shared__ unsigned int hist[2][LEVELS + 2];
+    if (threadIdx.x < 2 * (LEVELS + 2)) (&hist[0][0])[threadIdx.x] = 0u;
+    __syncthreads();
+    const float mn = __uint_as_float(st[EXS_MAX_N2]), md = __uint_as_float(st[EXS_MAX_D2]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = row_n2[i], b = row_d2[i];
+        if (!(a < __builtin_inff())) continue;  // rows with a non-finite norm never moved the maxima: not rows of the bound
+        const int ja = level_of(a, mn);
+        if (ja <= LEVELS) atomicAdd(&hist[0][ja], 1u);
+        if (b < __builtin_inff()) {
+            const int jb = level_of(b, md);
+            if (jb <= LEVELS) atomicAdd(&hist[1][jb], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x <= LEVELS) {
+        if (hist[0][threadIdx.x]) atomicAdd(st + EXS_HIST_N2 + threadIdx.x, hist[0][threadIdx.x]);
+        if (hist[1][threadIdx.x]) atomicAdd(st + EXS_HIST_D2 + threadIdx.x, hist[1][threadIdx.x]);
+    }
+}
+
+// the deepest cut that leaves at most EXACT_MAX_OUTLIERS rows above it, per statistic (j = 0: no outliers, the cut is the maximum)
+__global__ void exact_stats_pick_kernel(unsigned int* __restrict__ st) {
+    if (threadIdx.x >= 2) return;
+    const int which = threadIdx.x;
+    const unsigned int* hist = st + (which ? EXS_HIST_D2 : EXS_HIST_N2);
+    float cut = __uint_as_float(st[which ? EXS_MAX_D2 : EXS_MAX_N2]);
+    unsigned int above = 0;
+    float t = cut;
+    for (int j = 1; j <= LEVELS; ++j) {
+        above += hist[j];
+        t *= 0.25f;
+        if (above > (unsigned)EXACT_MAX_OUTLIERS) break;
+        cut = t;
+    }
+    st[which ? EXS_CUT_D2 : EXS_CUT_N2] = __float_as_uint(cut);
+}
+
+__global__ __launch_bounds__(256) void exact_stats_collect_kernel(const float* __restrict__ row_n2, const float* __restrict__ row_d2,
+                                                                  int64_t n, unsigned int* __restrict__ st) {
+    const float cn = __uint_as_float(st[EXS_CUT_N2]), cd = __uint_as_float(st[EXS_CUT_D2]);
+    float mn = 0.f, md = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = row_n2[i], b = row_d2[i];
+        if (!(a < __builtin_inff())) continue;
+        if (a > cn || (b < __builtin_inff() && b > cd)) {
+            const unsigned int slot = atomicAdd(st + EXS_N_OUT, 1u);
+            if (slot < 2u * EXACT_MAX_OUTLIERS) st[EXS_OUT_ROWS + slot] = (unsigned int)i;
+        } else {
+            mn = fmaxf(mn, a);
+            if (b < __builtin_inff()) md = fmaxf(md, b);
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        mn = fmaxf(mn, __shfl_xor(mn, m, 64));
+        md = fmaxf(md, __shfl_xor(md, m, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (__float_as_uint(mn) > __hip_atomic_load(st + EXS_ORD_N2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st + EXS_ORD_N2, __float_as_uint(mn));
+        if (__float_as_uint(md) > __hip_atomic_load(st + EXS_ORD_D2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(st + EXS_ORD_D2, __float_as_uint(md));
+    }
+}
+
+}  // namespace
+
+hipError_t launch_exact_stats(const float* row_n2, const float* row_d2, int64_t n_rows, unsigned int* stats, hipStream_t stream) {
+    if (hipError_t e = hipMemsetAsync(stats + EXS_ORD_N2, 0, (EXS_WORDS - EXS_ORD_N2) * sizeof(unsigned int), stream); e != hipSuccess) return e;
+    if (n_rows <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<int64_t>(1024, (n_rows + 255) / 256);
+    hipLaunchKernelGGL(exact_stats_levels_kernel, dim3(blocks), dim3(256), 0, stream, row_n2, row_d2, n_rows, stats);
+    hipLaunchKernelGGL(exact_stats_pick_kernel, dim3(1), dim3(64), 0, stream, stats);
+    hipLaunchKernelGGL(exact_stats_collect_kernel, dim3(blocks), dim3(256), 0, stream, row_n2, row_d2, n_rows, stats);
+    return hipGetLastError();
 }
 
 // ---- re-scoring -----------------------------------------------------------------------------------------------------------
@@ -266,7 +370,8 @@ __global__ __launch_bounds__(XT) void exact_rescore_kernel(ExactArgs a) {
     }
     // |s - s~| <= |q - q~| |x| + |q~| |x - x~|, plus the rounding of the two fp32 summations (each below dim_pad * 2^-23 * |q| |x|
     // whatever the order), everything inflated by 2^-9 for the float arithmetic of the norms themselves
-    const float xn = __builtin_sqrtf(__uint_as_float(a.stats[0])), dxn = __builtin_sqrtf(__uint_as_float(a.stats[1]));
+    // (the maxima over the ORDINARY rows: the outliers are scored, not bounded - below)
+    const float xn = __builtin_sqrtf(a.ord_n2), dxn = __builtin_sqrtf(a.ord_d2);
     const float qn = __builtin_sqrtf(n2), dqn = __builtin_sqrtf(d2);
     const float eps = (dqn * xn + qn * dxn + 2.f * (float)a.dim_pad * 1.1920929e-7f * (qn + dqn) * xn) * 1.002f;
 
@@ -293,6 +398,10 @@ __global__ __launch_bounds__(XT) void exact_rescore_kernel(ExactArgs a) {
     } else {
         n_total = a.kx;
     }
+    // the outliers of the bound are candidates of every query: behind its list (LIST) / behind its first stage's candidates (CAND)
+    const int n_listed = n_total;
+    const int n_out = (!cand_mode || first) ? a.n_out : 0;
+    n_total += n_out;
     const int CH = a.P - KR;
     int done = 0;
     do {
@@ -300,12 +409,32 @@ __global__ __launch_bounds__(XT) void exact_rescore_kernel(ExactArgs a) {
         // the chunk's candidate rows first, in ONE coalesced pass (a wave fetching its candidates' ids one by one pays a memory latency each)
         for (int j = tid; j < take; j += XT) {
             int row = -1;
-            if (cand_mode) {
-                const key_t64 key = a.cand[(size_t)r * a.cap + done + j];
-                if (key != 0ull) row = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            if (done + j >= n_listed) {  // an outlier: every query scores it (subject to the query's subset filter)
+                row = (int)a.out_rows[done + j - n_listed];
+                if (a.row_label != nullptr) {
+                    const int lab = a.row_label[row];
+                    bool any = false, ok = false;
+                    for (int s = 0; s < a.n_qlab; ++s) {
+                        const int ql = a.q_label[(size_t)qo * a.n_qlab + s];
+                        any |= ql != -1;
+                        ok |= ql == lab;
+                    }
+                    if (!(ok || !any)) row = -1;
+                }
             } else {
-                const int64_t id = a.list_i[qo * a.kx + done + j];
-                if (id >= 0) row = (int)id;
+                if (cand_mode) {
+                    const key_t64 key = a.cand[(size_t)r * a.cap + done + j];
+                    if (key != 0ull) row = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+                } else {
+                    const int64_t id = a.list_i[qo * a.kx + done + j];
+                    if (id >= 0) row = (int)id;
+                }
+                // a listed row that is an outlier leaves: its one copy is the injected one (LIST: behind the list; CAND: in the first stage)
+                // (the predicate of exact_stats_collect_kernel: rows with a non-finite norm are no outliers - they keep their list entry)
+                if (a.n_out > 0 && row >= 0) {
+                    const float a2 = a.row_n2[row], b2 = a.row_d2[row];
+                    if (a2 < __builtin_inff() && (a2 > a.cut_n2 || (b2 < __builtin_inff() && b2 > a.cut_d2))) row = -1;
+                }
             }
             row_of[j] = row;
         }
@@ -344,6 +473,16 @@ __global__ __launch_bounds__(XT) void exact_rescore_kernel(ExactArgs a) {
         a.out_scores[qo * k + c] = key ? unflip_f32((unsigned)(key >> 32)) : -__builtin_inff();
         a.out_ids[qo * k + c] = key ? a.id_base + (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : -1;
     }
+    // LIST: how long a list this query needed - the entries whose scan score is within eps of the k-th exact score (the list is sorted
+    // by scan score: its entries behind those cannot be hits); the host sizes the next searches' lists by the maximum over the queries
+    __shared__ int need_s;
+    if (!cand_mode) {
+        if (tid == 0) need_s = 0;
+        __syncthreads();
+        for (int j = tid; j < a.kx; j += XT)
+            if (a.list_i[qo * a.kx + j] >= 0 && a.list_s[qo * a.kx + j] + eps >= s_k) atomicMax(&need_s, j + 1);
+        __syncthreads();
+    }
     if (tid == 0) {
         if (cand_mode) {
             if (kth) {  // every row of the true top-k has s >= s_k, hence s~ >= s_k - eps
@@ -365,6 +504,7 @@ __global__ __launch_bounds__(XT) void exact_rescore_kernel(ExactArgs a) {
             const bool complete = !full || (a.list_s[qo * a.kx + a.kx - 1] + eps < s_k);
             a.flag_q[qo] = complete ? 0u : 1u;
             if (!complete) atomicOr(a.flag_word, 1u);
+            if ((unsigned)need_s > __hip_atomic_load(a.flag_word + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.flag_word + 1, (unsigned)need_s);
         }
     }
 }

@@ -1015,13 +1015,8 @@ __global__ void convert_rows_kernel(const void* __restrict__ src, int64_t n_rows
             } else {
                 f = (float)(((const __bf16*)src)[row * dim + c]);
             }
-            if constexpr (DST == 0) {
-                const _Float16 h = (_Float16)f;
-                v = __builtin_bit_cast(uint16_t, h);
-            } else {
-                const __bf16 h = (__bf16)f;
-                v = __builtin_bit_cast(uint16_t, h);
-            }
+            float rounded;
+            v = store_bits(f, DST, &rounded);  // (finite float32 values beyond the store dtype's range saturate: mips_common.h)
         }
         out[e] = v;
     }
@@ -1073,13 +1068,8 @@ __global__ void mips_prepare_kernel(const void* __restrict__ q_src, int q_dtype,
                 if (q_dtype == 2) f = ((const float*)q_src)[srow * dim + c];
                 else if (q_dtype == 0) f = (float)(((const _Float16*)q_src)[srow * dim + c]);
                 else f = (float)(((const __bf16*)q_src)[srow * dim + c]);
-                if (store_dtype == 0) {
-                    const _Float16 h = (_Float16)f;
-                    v = __builtin_bit_cast(uint16_t, h);
-                } else {
-                    const __bf16 h = (__bf16)f;
-                    v = __builtin_bit_cast(uint16_t, h);
-                }
+                float rounded;
+                v = store_bits(f, store_dtype, &rounded);  // (finite values beyond the store dtype's range saturate: mips_common.h)
             }
             out[e] = v;
         }
@@ -1106,6 +1096,7 @@ __global__ void mips_prepare_kernel(const void* __restrict__ q_src, int q_dtype,
     if (i == 0 && clear_overflow) {
         overflow[0] = 0u;
         overflow[1] = 0u;  // exact mode's "some list did not prove complete" word (kernels_exact.hip)
+        overflow[2] = 0u;  // exact mode's "list entries within eps of the k-th exact score, maximum over the queries" word
     }
 }
 

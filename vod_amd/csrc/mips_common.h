@@ -26,6 +26,31 @@ __device__ __forceinline__ key_t64 make_key(float s, unsigned int local_row) {
     return ((key_t64)flip_f32(s) << 32) | (key_t64)(0xFFFFFFFFu - local_row);
 }
 
+// ---- rounding to the store dtype ------------------------------------------------------------------
+// Finite float32 values beyond the store dtype's range SATURATE to its largest finite value instead of rounding to +-inf (fp16:
+// |v| >= 65520 would; bf16: |v| > 3.3895e38).  An infinite scan copy of a finite value makes every scan score of the row +-inf / NaN and
+// the rounding error x - x~ infinite: exact mode's error bound (kernels_exact.hip) could not cover such a row (round 5: a true top-k hit
+// with a component of 7e4 in an fp16 store was lost).  Saturated, x - x~ is finite, enters the row statistics, and the row is handled
+// as an outlier of the bound.  NaN and +-inf inputs pass through unchanged.
+__device__ __forceinline__ float saturate_for_store(float v, int store_dtype) {
+    const float lim = store_dtype == 0 ? 65504.f : 3.3895313892515355e38f;
+    if (v > lim && v < __builtin_inff()) return lim;
+    if (v < -lim && v > -__builtin_inff()) return -lim;
+    return v;
+}
+// the 16 bits the store / the rounded query holds for float32 `v`, and the value they stand for
+__device__ __forceinline__ uint16_t store_bits(float v, int store_dtype, float* rounded) {
+    v = saturate_for_store(v, store_dtype);
+    if (store_dtype == 0) {
+        const _Float16 h = (_Float16)v;
+        *rounded = (float)h;
+        return __builtin_bit_cast(uint16_t, h);
+    }
+    const __bf16 h = (__bf16)v;
+    *rounded = (float)h;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
 template <int DT>
 __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
     if constexpr (DT == 0) {

@@ -75,6 +75,7 @@ struct PendingSearch {
     int lane = 0;                  // which of the index's two workspaces / streams this search runs on (1 = the index's own stream)
 };
 
+constexpr int FLAG_WORDS = 4;     // flag words of a workspace / of a slot's host copy
 constexpr int MAX_IN_FLIGHT = 4;  // searches that may be enqueued before the oldest is finished
 constexpr int64_t OVF_ROWS = 65536;  // per-query overflow flags are kept for batches up to this many queries
 
@@ -99,7 +100,15 @@ struct vodhip_index {
     // VODHIP_EXACT_F32 (kernels_exact.hip): the float32 rows, the statistics of the error bound, per-slot lists of the scan
     bool exact = false;
     float* data32 = nullptr;                 // [capacity + 1][dim_pad]
-    unsigned int* norm_stats = nullptr;      // device [2]: bit patterns of max |x|^2, max |x - x~|^2
+    unsigned int* norm_stats = nullptr;      // device [EXS_WORDS]: max |x|^2, max |x - x~|^2 (atomics at ingest), the ordinary maxima, the outliers
+    float* row_n2 = nullptr;                 // device [capacity + 1]: |x|^2 of every row (written at ingest)
+    float* row_d2 = nullptr;                 // device [capacity + 1]: |x - x~|^2
+    bool stats_dirty = true;                 // rows were added / the store was reset since the statistics below were derived
+    float ord_n2 = 0.f, ord_d2 = 0.f, cut_n2 = 0.f, cut_d2 = 0.f;  // host copies (refresh_exact_stats): the bound's maxima over the ordinary rows, the outlier cuts
+    int n_out = 0;                           // outlier rows (scored by every query instead of bounded)
+    int64_t exact_adapt = 1;                 // 1: the list length k' follows what the last searches needed (0: always the formula)
+    int adapt_k = 0, adapt_kx = 0;           // the k the adapted k' belongs to / the adapted k' (0 = none yet)
+    int64_t last_exact_need = 0;             // list entries within eps of the k-th exact score, maximum over the last search's queries
     float* x_list_s[4] = {nullptr, nullptr, nullptr, nullptr};     // per in-flight slot: the scan's top-k' list [nq][k']
     int64_t* x_list_i[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t x_list_cap[4] = {0, 0, 0, 0};     // elements
@@ -115,7 +124,7 @@ struct vodhip_index {
     hipStream_t lane_stream = nullptr;
     hipEvent_t lane_in[4] = {};              // recorded on the caller's stream at enqueue: lane 1 starts behind the caller's pending work
     int64_t lanes = 0;
-    unsigned int* overflow_host = nullptr;  // pinned, two words per in-flight slot: [0] a candidate list overflowed, [1] exact mode: some list did not prove complete
+    unsigned int* overflow_host = nullptr;  // pinned, FLAG_WORDS per in-flight slot: [0] a candidate list overflowed, [1] exact mode: some list did not prove complete, [2] exact mode: max over queries of the list entries within eps of the k-th exact score
     unsigned int* ovf_q = nullptr;          // device [MAX_IN_FLIGHT][OVF_ROWS]: which queries of a slot's search overflowed
     int* q_map = nullptr;                   // device [MAX_IN_FLIGHT][OVF_ROWS]: the rows a slot's recovery pass re-searches
     hipEvent_t done[MAX_IN_FLIGHT] = {};    // recorded after a search's overflow word is copied back
@@ -167,19 +176,26 @@ int free_workspace(vodhip_index* ix, int lane) {
 
 int ensure_workspace(vodhip_index* ix, int lane, int64_t nq_pad, int64_t cap, int64_t kp) {
     SearchWorkspace& w = ix->ws_lane[lane];
-    if (w.nq_cap >= nq_pad && w.cap == cap && w.kp == kp && w.q_pad) return 0;
+    // (kp: the running top-k's row stride of THIS search, passed to the launches by value; the buffer is sized for the widest seen - an
+    // exact-mode scan (k') and its band pass (k) alternate between two widths: reallocating per search is a device-wide hipFree each time)
+    if (w.nq_cap >= nq_pad && w.cap == cap && w.kp_cap >= kp && w.q_pad) {
+        w.kp = kp;
+        return 0;
+    }
     const int64_t nq_cap = std::max(nq_pad, w.nq_cap);
+    const int64_t kp_cap = std::max(kp, w.kp_cap);
     free_workspace(ix, lane);
     HIP_OK(hipMalloc((void**)&w.q_pad, (size_t)nq_cap * ix->dim_pad * 2));
-    HIP_OK(hipMalloc((void**)&w.topk, (size_t)nq_cap * kp * sizeof(key_t64)));
+    HIP_OK(hipMalloc((void**)&w.topk, (size_t)nq_cap * kp_cap * sizeof(key_t64)));
     HIP_OK(hipMalloc((void**)&w.cand, (size_t)nq_cap * cap * sizeof(key_t64)));
     HIP_OK(hipMalloc((void**)&w.cnt, (size_t)nq_cap * CNT_STRIDE * sizeof(unsigned int)));
     HIP_OK(hipMalloc((void**)&w.thr_s, (size_t)nq_cap * sizeof(float)));
     HIP_OK(hipMalloc((void**)&w.thr_key, (size_t)nq_cap * sizeof(key_t64)));
-    HIP_OK(hipMalloc((void**)&w.overflow, 2 * sizeof(unsigned int)));  // [0] overflow, [1] exact mode's "incomplete" word
+    HIP_OK(hipMalloc((void**)&w.overflow, FLAG_WORDS * sizeof(unsigned int)));  // [0] overflow, [1] exact mode's "incomplete" word, [2] its "needed list length"
     w.nq_cap = nq_cap;
     w.cap = cap;
     w.kp = kp;
+    w.kp_cap = kp_cap;
     return 0;
 }
 
@@ -325,6 +341,38 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad,
     if (ix->growth_x100 <= 0 && st.size() == n_head + 2 && (st[n_head + 1].e - st[n_head + 1].b) > 6 * (st[n_head].e - st[n_head].b)) plan(4.0);
 }
 
+// exact mode: the statistics of the error bound as the re-scoring launches take them (host copies: refresh_exact_stats)
+void exact_bound_args(const vodhip_index* ix, ExactArgs& xa) {
+    xa.ord_n2 = ix->ord_n2;
+    xa.ord_d2 = ix->ord_d2;
+    xa.cut_n2 = ix->cut_n2;
+    xa.cut_d2 = ix->cut_d2;
+    xa.n_out = ix->n_out;
+    xa.out_rows = ix->norm_stats + EXS_OUT_ROWS;
+    xa.row_n2 = ix->row_n2;
+    xa.row_d2 = ix->row_d2;
+}
+
+// exact mode, before the first search after rows were added (no search is in flight then: `add` refuses otherwise): re-derive the maxima
+// of the bound over the ORDINARY rows and the list of outliers from the per-row planes (8 bytes per row: ~30 us for 10 M rows), and
+// fetch them.  ONE host sync per batch of adds.
+int refresh_exact_stats(vodhip_index* ix, hipStream_t stream) {
+    if (!ix->exact || !ix->stats_dirty) return 0;
+    HIP_OK(launch_exact_stats(ix->row_n2, ix->row_d2, ix->ntotal, ix->norm_stats, stream));
+    unsigned int w[8];
+    HIP_OK(hipMemcpyAsync(w, ix->norm_stats, sizeof(w), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    auto f = [](unsigned int u) { float v; memcpy(&v, &u, 4); return v; };
+    ix->ord_n2 = f(w[EXS_ORD_N2]);
+    ix->ord_d2 = f(w[EXS_ORD_D2]);
+    ix->cut_n2 = f(w[EXS_CUT_N2]);
+    ix->cut_d2 = f(w[EXS_CUT_D2]);
+    ix->n_out = (int)std::min<unsigned int>(w[EXS_N_OUT], 2u * EXACT_MAX_OUTLIERS);
+    if (w[EXS_N_OUT] > 2u * EXACT_MAX_OUTLIERS) return fail("internal error: %u outlier rows", w[EXS_N_OUT]);
+    ix->stats_dirty = false;
+    return 0;
+}
+
 int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, int recovery, hipStream_t stream) {
     SearchWorkspace& W = ix->ws_lane[ps.lane];  // this search's lane
     const int k = ps.k;
@@ -458,7 +506,10 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
                 xa.q_dtype = ps.q_dtype;
                 xa.q_map = q_map;
                 xa.store_dtype = ix->dtype;
-                xa.stats = ix->norm_stats;
+                exact_bound_args(ix, xa);
+                xa.row_label = W.extra.row_label;
+                xa.q_label = W.extra.q_label;
+                xa.n_qlab = W.extra.n_qlab;
                 xa.mode = EXACT_CAND | (c == 0 ? EXACT_FIRST : 0);
                 xa.cand = ws.cand;
                 xa.cnt = ws.cnt;
@@ -483,7 +534,7 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
             HIP_OK(launch_output(ws, nq, k, ps.id_base, ps.out_scores + qb * k, ps.out_ids + qb * k, stream));
     }
     if (ps.defer_flags) return 0;
-    HIP_OK(hipMemcpyAsync(ix->overflow_host + 2 * ps.slot, ws.overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(ix->overflow_host + FLAG_WORDS * ps.slot, ws.overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipEventRecord(ix->done[ps.slot], stream));
     return 0;
 }
@@ -529,13 +580,16 @@ int enqueue_exact_list(vodhip_index* ix, const PendingSearch& ps, hipStream_t st
     xa.q_src = ps.queries;
     xa.q_dtype = ps.q_dtype;
     xa.store_dtype = ix->dtype;
-    xa.stats = ix->norm_stats;
+    exact_bound_args(ix, xa);
+    xa.row_label = (ix->row_label && ps.q_label) ? ix->row_label : nullptr;
+    xa.q_label = ps.q_label;
+    xa.n_qlab = ps.n_qlab;
     xa.mode = EXACT_LIST;
     xa.list_s = ix->x_list_s[ps.slot];
     xa.list_i = ix->x_list_i[ps.slot];
     xa.kx = ps.kx;
     xa.P = 64;
-    while (xa.P < ps.kx) xa.P <<= 1;
+    while (xa.P < ps.kx + xa.n_out) xa.P <<= 1;
     xa.k = ps.k;
     xa.id_base = ps.id_base;
     xa.out_scores = ps.out_scores;
@@ -544,7 +598,7 @@ int enqueue_exact_list(vodhip_index* ix, const PendingSearch& ps, hipStream_t st
     xa.flag_word = ix->ws_lane[ps.lane].overflow + 1;
     xa.flag_q = ix->x_flag_q + (size_t)ps.slot * OVF_ROWS;
     HIP_OK(launch_exact_rescore(xa, ps.nq, stream));
-    HIP_OK(hipMemcpyAsync(ix->overflow_host + 2 * ps.slot, ix->ws_lane[ps.lane].overflow, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipMemcpyAsync(ix->overflow_host + FLAG_WORDS * ps.slot, ix->ws_lane[ps.lane].overflow, 3 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipEventRecord(ix->done[ps.slot], stream));
     return 0;
 }
@@ -600,7 +654,7 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e == hipSuccess) e = hipMalloc((void**)&ix->ovf_q, MAX_IN_FLIGHT * OVF_ROWS * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc((void**)&ix->q_map, MAX_IN_FLIGHT * OVF_ROWS * sizeof(int));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&ix->overflow_host, 2 * MAX_IN_FLIGHT * sizeof(unsigned int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ix->overflow_host, FLAG_WORDS * MAX_IN_FLIGHT * sizeof(unsigned int), hipHostMallocDefault);
     for (int i = 0; i < MAX_IN_FLIGHT && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ix->done[i], hipEventDisableTiming);
     for (int i = 0; i < MAX_IN_FLIGHT && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ix->lane_in[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->lane_stream, hipStreamNonBlocking);
@@ -617,8 +671,10 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
             delete ix;
             return fail("hipMalloc of the %zu-byte float32 plane (VODHIP_EXACT_F32) failed: %s", bytes32, hipGetErrorString(e));
         }
-        if (e == hipSuccess) e = hipMalloc((void**)&ix->norm_stats, 2 * sizeof(unsigned int));
-        if (e == hipSuccess) e = hipMemset(ix->norm_stats, 0, 2 * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMalloc((void**)&ix->norm_stats, EXS_WORDS * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMemset(ix->norm_stats, 0, EXS_WORDS * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipMalloc((void**)&ix->row_n2, ((size_t)capacity_rows + 1) * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void**)&ix->row_d2, ((size_t)capacity_rows + 1) * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&ix->x_eps, MAX_IN_FLIGHT * OVF_ROWS * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void**)&ix->x_flag_q, MAX_IN_FLIGHT * OVF_ROWS * sizeof(unsigned int));
         if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
@@ -630,7 +686,7 @@ int vodhip_index_create(int device, int64_t dim, int store_dtype, int64_t capaci
         delete ix;
         return fail("store initialisation failed: %s", hipGetErrorString(e));
     }
-    for (int i = 0; i < 2 * MAX_IN_FLIGHT; ++i) ix->overflow_host[i] = 0;
+    for (int i = 0; i < FLAG_WORDS * MAX_IN_FLIGHT; ++i) ix->overflow_host[i] = 0;
     *out = ix;
     return 0;
 }
@@ -655,6 +711,8 @@ int vodhip_index_destroy(vodhip_index_t* ix) {
     }
     (void)hipFree(ix->data32);
     (void)hipFree(ix->norm_stats);
+    (void)hipFree(ix->row_n2);
+    (void)hipFree(ix->row_d2);
     (void)hipFree(ix->x_eps);
     (void)hipFree(ix->x_flag_q);
     for (int i = 0; i < MAX_IN_FLIGHT; ++i) {
@@ -678,12 +736,14 @@ int vodhip_index_add(vodhip_index_t* ix, const void* rows, int64_t n_rows, int s
     if (!ix->inflight.empty()) return fail("%d searches are in flight: finish them before adding rows", (int)ix->inflight.size());
     hipStream_t stream = (hipStream_t)stream_;
     HIP_OK(hipSetDevice(ix->device));
+    ix->stats_dirty = true;  // exact mode: the bound's maxima / outliers are re-derived before the next search
     const int es = elem_size(src_dtype);
     // one launch per slice: the rounded plane, and for VODHIP_EXACT_F32 stores also the float32 plane + the row statistics
     auto ingest = [&](const void* dev_src, int64_t n, int64_t first_row) -> hipError_t {
         if (ix->exact)
             return launch_ingest_exact(dev_src, src_dtype, n, ix->dim, ix->data + (size_t)first_row * ix->dim_pad, ix->dtype,
-                                       ix->data32 + (size_t)first_row * ix->dim_pad, ix->dim_pad, ix->norm_stats, stream);
+                                       ix->data32 + (size_t)first_row * ix->dim_pad, ix->dim_pad, ix->norm_stats, ix->row_n2 + first_row,
+                                       ix->row_d2 + first_row, stream);
         return launch_convert_rows(dev_src, src_dtype, n, ix->dim, ix->data + (size_t)first_row * ix->dim_pad, ix->dtype, ix->dim_pad, stream);
     };
     if (src_location == VODHIP_DEVICE) {
@@ -752,8 +812,10 @@ int vodhip_index_reset(vodhip_index_t* ix) {
     if (ix->exact) {  // the row maxima of the error bound start over with the store (stale maxima would only loosen it)
         HIP_OK(hipSetDevice(ix->device));
         HIP_OK(hipDeviceSynchronize());  // ingests of the old rows may still run on some stream
-        HIP_OK(hipMemset(ix->norm_stats, 0, 2 * sizeof(unsigned int)));
+        HIP_OK(hipMemset(ix->norm_stats, 0, EXS_WORDS * sizeof(unsigned int)));
         HIP_OK(hipStreamSynchronize(nullptr));
+        ix->stats_dirty = true;
+        ix->adapt_k = ix->adapt_kx = 0;
     }
     ix->ntotal = 0;
     return 0;
@@ -822,6 +884,10 @@ int vodhip_index_get_rows_f32(const vodhip_index_t* ix, int64_t row_begin, int64
 
 int vodhip_index_set_row_labels(vodhip_index_t* ix, const int32_t* labels, int64_t n_rows, int location, void* stream_) {
     if (!ix) return fail("index is NULL");
+    std::lock_guard<std::mutex> guard(ix->mu);
+    // searches in flight read the labels - on the caller's stream or, with two lanes, on the index's own: like add / reset, refuse
+    // (round-5 advisor: a lane-1 subset search could still be reading `row_label` while this call overwrote / freed it)
+    if (!ix->inflight.empty() || ix->unfinished) return fail("%d searches are in flight: finish them before changing the row labels", (int)ix->inflight.size() + ix->unfinished);
     HIP_OK(hipSetDevice(ix->device));
     if (!labels) {  // clear
         (void)hipFree(ix->row_label);
@@ -881,6 +947,7 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
     // lane: batches of one query tile alternate between the two workspaces (auto), so that a caller running one search ahead has two
     // searches on the device at once; lane 1 runs on the index's own stream, behind what the caller's stream holds now (the queries)
     hipStream_t stream = (hipStream_t)stream_;
+    if (ix->exact && nq > 0 && refresh_exact_stats(ix, stream)) return -1;
     const int64_t lanes_eff = ix->lanes > 0 ? ix->lanes : (nq <= 256 ? 2 : 1);
     if (lanes_eff == 2 && nq > 0) {
         // the lane the youngest search in flight does NOT use; a caller that finishes every search before the next (nothing in flight)
@@ -897,8 +964,11 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
     if (ix->exact && nq > 0) {
         // exact mode: the scan fills the slot's top-k' list, the re-scoring kernel behind it writes the caller's rows (no host round
         // trip in between: the list is re-scored even if it later turns out that a candidate list overflowed - finish repeats it then)
-        ps.kx = exact_kx(ix, k);
-        if (exact_reserve_lists(ix, ps.slot, (size_t)nq * ps.kx)) return -1;
+        const int kx_formula = exact_kx(ix, k);
+        // (adapted to what the last searches of this k needed - finish() - unless the caller fixed the expansion or switched it off)
+        const bool adapt = ix->exact_adapt && ix->exact_expand_x100 == 0 && ix->adapt_k == k && ix->adapt_kx >= k;
+        ps.kx = adapt ? std::min(ix->adapt_kx, kx_formula) : kx_formula;
+        if (exact_reserve_lists(ix, ps.slot, (size_t)nq * kx_formula)) return -1;
         PendingSearch in = exact_inner(ix, ps);
         in.defer_flags = true;  // ONE copy of both flag words, behind the re-scoring launch
         if (enqueue_search(ix, in, ix->force_safe != 0, 0, stream)) return -1;
@@ -924,7 +994,7 @@ namespace {
 int recover_overflow(vodhip_index* ix, const PendingSearch& ps, hipStream_t stream) {
     PendingSearch rs = ps;  // what the recovery passes search: the whole batch, or only the queries that overflowed
     int pass = 0;
-    while (ix->overflow_host[2 * ps.slot]) {
+    while (ix->overflow_host[FLAG_WORDS * ps.slot]) {
         if (++pass > 40) return fail("internal error: the exhaustive schedule overflowed");
         ix->last_overflow = 1;
         ix->last_safe_reruns += 1;
@@ -990,6 +1060,21 @@ int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
     ix->last_exact_kx = ps.kx;
     ix->last_exact_band_queries = 0;
     ix->last_exact_band_passes = 0;
+    ix->last_exact_need = ps.kx > 0 && ps.nq > 0 ? (int64_t)ix->overflow_host[FLAG_WORDS * ps.slot + 2] : 0;
+    if (ps.kx > 0 && ps.nq > 0 && ix->exact_adapt && ix->exact_expand_x100 == 0) {
+        // The list length of the NEXT searches of this k: what this one needed (the list entries within eps of the k-th exact score,
+        // maximum over the queries) + 1/16 + 8, rounded up to 8; it rises at once and falls by a quarter of the gap per search.  A list
+        // that did not prove complete (need == k') sends the next search back to the formula.  A speed knob only: any k' >= k returns
+        // the same result (the band pass covers what a short list misses).
+        const int need = (int)ix->overflow_host[FLAG_WORDS * ps.slot + 2];
+        const int formula = exact_kx(ix, ps.k);
+        int target = need >= ps.kx ? formula : std::min(formula, (need + need / 16 + 8 + 7) / 8 * 8);
+        target = std::max(target, std::min(formula, ps.k + 8));
+        if (ix->adapt_k != ps.k || ix->adapt_kx <= 0) ix->adapt_kx = formula;
+        ix->adapt_k = ps.k;
+        ix->adapt_kx = target >= ix->adapt_kx ? target : ix->adapt_kx - std::max(8, (ix->adapt_kx - target) / 4 / 8 * 8);
+        if (ix->adapt_kx < target) ix->adapt_kx = target;
+    }
     if (ps.nq > 0 && ps.kx == 0) {
         if (recover_overflow(ix, ps, stream) < 0) return -1;
     } else if (ps.nq > 0) {
@@ -1002,7 +1087,7 @@ int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
         }
         // (2) the lists that did not prove complete: those queries run a BAND pass (every row whose scan score is within eps of
         // the k-th exact score is re-scored); its own candidate lists may overflow, which splits the pass like any recovery
-        if (ix->overflow_host[2 * ps.slot + 1]) {
+        if (ix->overflow_host[FLAG_WORDS * ps.slot + 1]) {
             std::vector<unsigned int> flags((size_t)ps.nq);
             HIP_OK(hipMemcpy(flags.data(), ix->x_flag_q + (size_t)ps.slot * OVF_ROWS, (size_t)ps.nq * sizeof(unsigned int), hipMemcpyDeviceToHost));
             std::vector<int> rows;
@@ -1115,6 +1200,10 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
     } else if (!strcmp(key, "tile_order")) {
         if (value != 0 && value != 1) return fail("tile_order must be 0 (low-discrepancy stage order) or 1 (row order)");
         ix->tile_order = value;
+    } else if (!strcmp(key, "exact_adapt")) {
+        if (value < 0 || value > 1) return fail("exact_adapt must be 0 or 1");
+        ix->exact_adapt = value;
+        ix->adapt_k = ix->adapt_kx = 0;
     } else if (!strcmp(key, "exact_expand")) {
         if (value < 0 || value > 100000) return fail("exact_expand (x100) must be in [0, 100000]");
         ix->exact_expand_x100 = value;
@@ -1155,7 +1244,11 @@ int vodhip_index_get_stat(const vodhip_index_t* ix, const char* key, int64_t* ou
         *out = ix->exact ? 1 : 0;
     else if (!strcmp(key, "last_exact_kx"))
         *out = ix->last_exact_kx;
-    else if (!strcmp(key, "last_exact_band_queries"))
+    else if (!strcmp(key, "last_exact_need"))
+        *out = ix->last_exact_need;
+    else if (!strcmp(key, "exact_outliers")) {  // (derived lazily: before the first search after rows were added this is the previous value)
+        *out = ix->n_out;
+    } else if (!strcmp(key, "last_exact_band_queries"))
         *out = ix->last_exact_band_queries;
     else if (!strcmp(key, "last_exact_band_passes"))
         *out = ix->last_exact_band_passes;

@@ -74,12 +74,13 @@ struct SearchWorkspace {
     unsigned int* cnt = nullptr;     // [nq_pad * CNT_STRIDE] candidates appended in the current stage (one counter per 128-B line)
     float* thr_s = nullptr;          // [nq_pad] score of the current k-th best (-inf until k hits exist)
     key_t64* thr_key = nullptr;      // [nq_pad] key of the current k-th best (0 until k hits exist)
-    unsigned int* overflow = nullptr;  // [1] set when a candidate buffer overflowed
+    unsigned int* overflow = nullptr;  // [4] flag words: [0] a candidate buffer overflowed; exact mode: [1] some list did not prove complete, [2] max needed list length
     unsigned int* ovf_q = nullptr;     // [nq] per query: its candidate list overflowed in some stage (set by the select kernel), or NULL
     int n_cu = 256;                    // compute units of the device (read once at index create)
     int64_t nq_cap = 0;
     int64_t cap = 0;
-    int64_t kp = 0;
+    int64_t kp = 0;       // row stride of `topk` for the search being enqueued (a power of two >= its k)
+    int64_t kp_cap = 0;   // ... and the stride the buffer was allocated for (>= kp)
     FilterExtra extra;  // flags + optional subset filter of the current search
 };
 
@@ -135,7 +136,16 @@ struct ExactArgs {
     int q_dtype = 0;
     const int* q_map = nullptr;       // workspace row -> row of the caller's batch, or NULL
     int store_dtype = 0;              // what the scan rounded to (the bound needs |q - q~|)
-    const unsigned int* stats = nullptr;  // [2] bit patterns of max |x|^2, max |x - x~|^2
+    // the bound's statistics, host copies (refreshed before the first search after rows were added: launch_exact_stats)
+    float ord_n2 = 0.f, ord_d2 = 0.f;     // max |x|^2, max |x - x~|^2 over the ORDINARY rows
+    float cut_n2 = 0.f, cut_d2 = 0.f;     // a row with |x|^2 > cut_n2 or |x - x~|^2 > cut_d2 is an OUTLIER: scored by every query, not bounded
+    int n_out = 0;                        // outliers (<= 2 * EXACT_MAX_OUTLIERS)
+    const unsigned int* out_rows = nullptr;  // [n_out] their local rows (device)
+    const float* row_n2 = nullptr;        // [rows] |x|^2 of every stored row (device)
+    const float* row_d2 = nullptr;        // [rows] |x - x~|^2
+    const int* row_label = nullptr;       // the subset filter in force (outliers are injected past the scan: they are filtered here), or NULL
+    const int* q_label = nullptr;         // [batch rows, n_qlab]
+    int n_qlab = 0;
     int mode = EXACT_LIST;            // EXACT_LIST | EXACT_CAND [| EXACT_FIRST]
     // LIST: the scan's top-kx list, rows of the caller's batch, LOCAL ids (pads -1)
     const float* list_s = nullptr;
@@ -158,8 +168,15 @@ struct ExactArgs {
     unsigned int* flag_word = nullptr;  // LIST: some query is incomplete; CAND: some list lost candidates
     unsigned int* flag_q = nullptr;     // LIST: [batch rows] 0 / 1 per query; CAND: [workspace rows] or NULL
 };
+// words of an exact-mode store's statistics buffer (device)
+constexpr int EXACT_MAX_OUTLIERS = 32;  // per statistic
+enum : int { EXS_MAX_N2 = 0, EXS_MAX_D2 = 1, EXS_ORD_N2 = 2, EXS_ORD_D2 = 3, EXS_N_OUT = 4, EXS_CUT_N2 = 5, EXS_CUT_D2 = 6,
+             EXS_HIST_N2 = 8, EXS_HIST_D2 = 24, EXS_OUT_ROWS = 64, EXS_WORDS = 64 + 2 * EXACT_MAX_OUTLIERS };
+// row_n2 / row_d2: [n_rows] planes of the ingested rows' |x|^2 and |x - x~|^2 (already offset to the first ingested row)
 hipError_t launch_ingest_exact(const void* src, int src_dtype, int64_t n_rows, int64_t dim, void* dst16, int dst_dtype, float* dst32,
-                               int64_t stride, unsigned int* stats, hipStream_t stream);
+                               int64_t stride, unsigned int* stats, float* row_n2, float* row_d2, hipStream_t stream);
+// re-derive words [EXS_ORD_N2 ..) from the per-row planes of rows [0, n_rows) and the global maxima in words [0], [1]
+hipError_t launch_exact_stats(const float* row_n2, const float* row_d2, int64_t n_rows, unsigned int* stats, hipStream_t stream);
 hipError_t launch_exact_rescore(const ExactArgs& a, int64_t nq, hipStream_t stream);
 
 // ---- launchers (kernels_hybrid.hip) -----------------------------------------------------------

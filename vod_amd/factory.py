@@ -9,6 +9,7 @@ master bound to the same host/port (non-zero ranks construct it with `skip_setup
 from __future__ import annotations
 
 import dataclasses
+import logging
 import pathlib
 import typing as typ
 
@@ -71,6 +72,29 @@ def resolve_port(config: HipMipsFactoryConfig, broadcast_fn: None | typ.Callable
     return dataclasses.replace(config, port=port)
 
 
+logger = logging.getLogger(__name__)
+
+
+def store_bytes(n_rows: int, dim: int, exact_f32: bool, n_devices: int = 1) -> int:
+    """HBM bytes ONE device holds for its contiguous share of an `n_rows` x `dim` store (rows padded to 64 columns): 2 bytes per element
+    of the scan copy; with `exact_f32` + 4 for the float32 plane + 8 per row for the row statistics of the error bound."""
+    per_dev = -(-int(n_rows) // max(1, int(n_devices)))
+    dim_pad = -(-int(dim) // 64) * 64
+    return per_dev * dim_pad * (6 if exact_f32 else 2) + (per_dev * 8 if exact_f32 else 0)
+
+
+def _free_device_bytes(devices: typ.Sequence[int]) -> "int | None":
+    """The smallest free HBM among `devices`, or None when this process cannot tell (no torch / no visible GPU: the server decides)."""
+    try:
+        import torch
+
+        if not torch.cuda.is_available():
+            return None
+        return min(int(torch.cuda.mem_get_info(int(d))[0]) for d in devices)
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def build_hip_mips_index(
     vectors: typ.Sequence[np.ndarray],
     *,
@@ -99,7 +123,22 @@ def build_hip_mips_index(
             vec_dtype = np.dtype(getattr(vectors, "dtype", None) or np.asarray(vectors[0]).dtype) if len(vectors) else np.dtype(np.float16)
         except Exception:  # noqa: BLE001 - an exotic sequence: fall back to looking at one row
             vec_dtype = np.asarray(vectors[0]).dtype
-        config = dataclasses.replace(config, exact_f32=bool(vec_dtype in (np.dtype(np.float32), np.dtype(np.float64))))
+        want_exact = bool(vec_dtype in (np.dtype(np.float32), np.dtype(np.float64)))
+        if want_exact:
+            # the float32 plane triples the store (2 -> 6 bytes per element + 8 per row): say so, and do not let the AUTO choice turn a store
+            # that fits into one that fails at create (40 M x 1024: 82 GB -> 246 GB) - an explicit exact_f32=True is taken at its word
+            n_rows, dim = len(vectors), int(np.asarray(vectors[0]).shape[-1]) if len(vectors) else 0
+            n_dev = max(1, len(devices) if devices else 1)
+            need, plain = store_bytes(n_rows, dim, True, n_dev), store_bytes(n_rows, dim, False, n_dev)
+            free = _free_device_bytes(devices if devices else [config.device])
+            if free is not None and need > 0.92 * free:
+                logger.warning("exact_f32 (auto): the float32 plane needs %.1f GB per device, %.1f GB are free - serving the %s copy only "
+                               "(%.1f GB; results carry its rounding).  Pass exact_f32=True to insist.", need / 1e9, free / 1e9, config.dtype, plain / 1e9)
+                want_exact = False
+            else:
+                logger.info("exact_f32 (auto): float32 vectors are served exactly - %.1f GB per device instead of %.1f GB (exact_f32=False)",
+                            need / 1e9, plain / 1e9)
+        config = dataclasses.replace(config, exact_f32=want_exact)
     if config.factory != "Flat" or config.metric != "inner_product":
         raise ValueError("the HIP MIPS engine is an exact inner-product index (factory='Flat', metric='inner_product')")
     from vod_amd.zarr_store import ZarrVectors
