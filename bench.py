@@ -77,6 +77,13 @@ def parse_args() -> argparse.Namespace:
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                    help="process-group backend.  nccl (= RCCL) is the product path; gloo stages the packed all-gather through the host and "
                         "lets several ranks share one GPU (RCCL refuses that): tests of the N > 1 step sequence on a 1-GPU box")
+    p.add_argument("--engine", choices=["ranks", "node"], default="ranks",
+                   help="ranks = one process per GPU, RCCL all-gather of the packed per-shard top-k (the default, what the driver's SCALE pass "
+                        "launches); node = ONE process, `vodhip_node_index_*` over --gpus devices: per-shard top-k copied to devices[0] (xGMI peer "
+                        "copies) + merge - the reference server's own shape (faiss index_cpu_to_all_gpus, server.py:51-54)")
+    p.add_argument("--node-devices", type=str, default=None,
+                   help="--engine node: comma-separated device ordinals, one per shard (default 0 .. gpus-1); repeating a device (0,0) puts several "
+                        "shards on one GPU with the exchange forced through pinned host memory - the N > 1 code path on a 1-GPU box")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true")
     p.add_argument("--no-side", action="store_true",
@@ -992,7 +999,7 @@ def compose_record(m: dict, *, world: int, backend: str, t_build: float, comm: "
             r["mfma_frac_of_2.5PF"] = (2.0 * nq * r["rows"] * d / (r["kernel_ms"] * 1e-3) / NAMEPLATE_MFMA) if r["kernel_ms"] > 0 else None
         line["per_rank"] = m["per_rank"]
         line["exchange_us_per_step_max"] = max(r["exchange_us"] for r in m["per_rank"])
-    for key in ("per_shard", "merge_us", "peer_access"):  # the node engine's own figures
+    for key in ("per_shard", "merge_us", "copy_us_max", "peer_access"):  # the node engine's own figures
         if m.get(key) is not None:
             line[key] = m[key]
     if m["verify"] is not None:
@@ -1026,6 +1033,7 @@ def compact_record(full: dict, side_file: "str | None" = None) -> dict:
         ps = full["per_shard"]
         line["per_shard"] = {"kernel_ms": [_r(r["kernel_ms"], 5) for r in ps], "rows": [r["rows"] for r in ps], "device": [r["device"] for r in ps]}
         line["merge_us"] = _r(full.get("merge_us"), 4)
+        line["copy_us_max"] = _r(full.get("copy_us_max"), 4)
         line["peer_access"] = full.get("peer_access")
     if "verify" in full:
         line["verify"] = compact_verify(full["verify"])
@@ -1045,8 +1053,101 @@ def compact_record(full: dict, side_file: "str | None" = None) -> dict:
     return line
 
 
+def run_node_engine(args) -> None:
+    """`--engine node`: the same workload on ONE process driving `vodhip_node_index_*` over N devices (row shards, per-shard search on
+    every device at once, lists copied to devices[0], one merge) - DESIGN 6's second multi-GPU design, one flag away from a SCALE
+    measurement.  Under an external launcher (torchrun starts N ranks) rank 0 does the work and the others leave at once."""
+    if int(os.environ.get("RANK", "0")) != 0:
+        return
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+
+    from vod_amd.hostcpu import limit_cpu_threads, usable_cpus
+    from vod_amd.index import HipNodeIndex
+
+    limit_cpu_threads(usable_cpus(), export=False)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    devices = [int(v) for v in args.node_devices.split(",")] if args.node_devices else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        raise SystemExit(f"--node-devices lists {len(devices)} devices, --gpus is {args.gpus}")
+    if max(devices) >= torch.cuda.device_count():
+        raise SystemExit(f"--engine node: device {max(devices)} requested, {torch.cuda.device_count()} GPU(s) visible")
+    shared = len(set(devices)) < len(devices)
+    torch.cuda.set_device(devices[0])
+    dev = torch.device("cuda", devices[0])
+    rig = Rig(torch, dev, 0, 1)
+    n_total, d, nq, k, G = args.rows, args.dim, args.nq, args.k, len(devices)
+    tdt = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    exact = args.exact_f32
+    index = HipNodeIndex(d, n_total, devices, dtype=tdt, exact_f32=exact)
+    if shared:
+        index.set_param("host_staging", 1)
+    for kv in args.param:
+        key, _, val = kv.partition("@")[0].partition("=")
+        index.set_param(key, int(val))
+    t0 = time.perf_counter()
+    n_chunks = (n_total + GEN_CHUNK - 1) // GEN_CHUNK
+    for c in range(n_chunks):  # the same corpus as the rank engine, chunk by chunk through the host (the node index ingests host rows)
+        rows = make_rows(torch, dev, torch.float32 if exact else tdt, args.data, c, min(GEN_CHUNK, n_total - c * GEN_CHUNK), d, n_total)
+        index.add((rows if exact else rows.to(torch.float16 if tdt == torch.float16 else torch.float32)).cpu().numpy())
+    t_build = time.perf_counter() - t0
+    assert index.ntotal == n_total
+    queries = make_queries(torch, dev, torch.float32 if exact else tdt, args.data, nq, d, n_total)
+    res = None
+    for _ in range(args.warmup):
+        res = index.search(queries, k)
+    index.set_param("profile", 1)
+    torch.cuda.synchronize()
+    shard_ns = [0] * G
+    launches = merge_ns = copy_ns = recov = 0
+    step_ns = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = index.search(queries, k)   # returns when every shard's exactness check is done; the merge is enqueued on this stream
+        per = [index.shard_stat(g, "last_filter_ns") + index.shard_stat(g, "last_recovery_ns") for g in range(G)]
+        for g in range(G):
+            shard_ns[g] += per[g]
+        step_ns += max(per)
+        launches += index.shard_stat(0, "last_filter_launches")
+        recov += sum(index.shard_stat(g, "last_safe_reruns") for g in range(G))
+        merge_ns += index.get_stat("last_merge_ns")      # (waits for the merge: the node search is synchronous per batch anyway)
+        copy_ns += index.get_stat("last_copy_ns_max")
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    index.set_param("profile", 0)
+    shard_rows = [max(0, min(n_total, (g + 1) * -(-n_total // G)) - g * -(-n_total // G)) for g in range(G)]
+    verify = None
+    if not args.no_verify and args.verify_queries > 0:
+        fs, fi = res
+        n_v = min(nq, args.verify_queries)
+        sample = sorted(set(int(round(j * (nq - 1) / max(1, n_v - 1))) for j in range(n_v))) if n_v > 1 else [0]
+        gen_dt = torch.float32 if exact else tdt  # (a plain store holds exactly the generated, rounded rows)
+        ref_s, ref_i = _brute_force_f64(rig, queries[sample].double(),
+                                        lambda lo, n: make_rows(torch, dev, gen_dt, args.data, lo // GEN_CHUNK, n, d, n_total), n_total, 0, k, False)
+        verify = _compare_with(torch, fs, fi, sample, ref_s, ref_i,
+                               "float64 chunked product over the UNROUNDED float32 rows and queries" if exact
+                               else "float64 chunked product over the stored (rounded) rows and queries (ties -> smaller id)")
+    peer = index.peer_access()
+    index.close()
+    m = {"elapsed": elapsed, "filter_ns": step_ns, "filter_launches": launches, "recovery_passes": recov, "recovery_ns": 0, "verify": verify,
+         "n_local": max(shard_rows), "steps": args.steps, "warmup": args.warmup, "rows": n_total, "dim": d, "nq": nq, "k": k, "dtype": args.dtype,
+         "data": args.data, "multi": G > 1, "tile": args.tile, "exact": exact, "per_rank": None,
+         "per_shard": [{"shard": g, "device": devices[g], "rows": shard_rows[g], "kernel_ms": shard_ns[g] * 1e-6 / args.steps} for g in range(G)],
+         "merge_us": merge_ns * 1e-3 / args.steps, "copy_us_max": copy_ns * 1e-3 / args.steps, "peer_access": peer}
+    cpu = None
+    if G == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_baseline import time_cpu_baseline  # the reported CPU baseline, never the product path
+
+        cpu = time_cpu_baseline(d, nq, k, n_total, target_seconds=args.cpu_seconds)
+    full = compose_record(m, world=G, backend="node", t_build=t_build, comm=None, cpu_baseline=cpu, side=None, engine="node")
+    print(final_line(compact_record(full)), flush=True)
+
+
 def main() -> None:
     args = parse_args()
+    if args.engine == "node":
+        return run_node_engine(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, launch_check_only=args.launch_check or args.backend == "gloo"))  # (gloo test rig: ranks may share a GPU)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool (before HIP starts)

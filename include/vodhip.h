@@ -228,6 +228,11 @@ int vodhip_node_index_set_row_labels(vodhip_node_index_t* index, const int32_t* 
 int vodhip_node_index_set_query_labels(vodhip_node_index_t* index, const int32_t* q_labels, int n_per_query, int location);
 int vodhip_node_index_search(vodhip_node_index_t* index, const void* queries, int q_dtype, int64_t nq, int k, int location,
                              float* out_scores, int64_t* out_ids, void* stream);
+/* With param "profile" = 1 (also set on every shard: their filter launches are bracketed, read per shard through vodhip_index_get_stat on
+ * the handle vodhip_node_index_shard returns): "last_merge_ns" = the merge launch on devices[0], from the moment every shard's list had
+ * arrived; "last_copy_ns_max" = the slowest shard's copy of its list towards devices[0] (peer copy over xGMI, or the down-leg to pinned
+ * host memory when staged).  HIP events of the last search; 0 with one shard.  Waits for that search. */
+int vodhip_node_index_get_stat(vodhip_node_index_t* index, const char* key, int64_t* out);
 
 /* ---------------------------------------------------------------------------------------------
  * H4  hybrid score merge (lookup + up to VODHIP_MAX_ENGINES scored engines), one query row per wavefront.

@@ -246,3 +246,21 @@ def test_bench_default_line_carries_the_side_workloads():
     assert rec["roofline"]["traffic_source"] and "exact" not in rec["roofline"]["traffic_source"]  # (round 5: the exact-mode PMC run had taken the plain key)
     assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["threads"] >= 1 and rec["cpu_baseline"]["cores"] >= 1
     assert len(rec["cpu_baseline"]["thread_arms"]) >= 1 and abs(rec["cpu_baseline"]["value"] - max(rec["cpu_baseline"]["thread_arms"].values())) < 0.01
+
+
+def test_bench_node_engine_two_shards_on_one_gpu():
+    """`bench.py --gpus N --engine node`: ONE process, `vodhip_node_index_*` over N devices - the second multi-GPU design is one flag away
+    from a SCALE measurement.  Here two shards share the box's GPU (the exchange is forced through pinned host memory: the N > 1 step
+    sequence - replicate the queries, search every shard, copy the lists to devices[0], merge - on real kernels)."""
+    rec = _run_bench("--gpus", "2", "--engine", "node", "--node-devices", "0,0", "--rows", "500000", "--dim", "128", "--nq", "512", "--k", "50",
+                     "--steps", "4", "--warmup", "2", "--verify-queries", "32")
+    assert rec["n_gpus"] == 2 and rec["config"]["engine"] == "node" and "vodhip_node_index" in rec["config"]["parallelism"]
+    assert rec["config"]["rows_per_gpu"] == 250_000 and rec["value"] > 0 and rec["roofline"]["frac"] > 0
+    ps = rec["per_shard"]
+    assert ps["rows"] == [250_000, 250_000] and ps["device"] == [0, 0] and all(v > 0 for v in ps["kernel_ms"])
+    assert rec["merge_us"] > 0 and rec["copy_us_max"] > 0 and rec["peer_access"] == [2, 0]   # shard 1: staged through the host
+    assert rec["verify"]["recall_at_k"] == 1.0 and rec["verify"]["rows_with_identical_id_order"] == 1.0 and rec["verify"]["max_abs_score_diff"] < 1e-3
+    # the exact-f32 store behind the same engine: the merged result is the float32 brute force of the unrounded inputs
+    rec = _run_bench("--gpus", "2", "--engine", "node", "--node-devices", "0,0", "--rows", "500000", "--dim", "128", "--nq", "512", "--k", "50",
+                     "--steps", "2", "--warmup", "1", "--verify-queries", "32", "--exact-f32")
+    assert rec["verify"]["recall_at_k"] == 1.0 and rec["verify"]["max_abs_score_diff"] < 1e-3 and "UNROUNDED" in rec["verify"]["comparator"]

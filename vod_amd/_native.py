@@ -69,6 +69,7 @@ SIGNATURES: dict[str, tuple] = {
     "vodhip_node_index_n_shards": (_i32, [_vp]),
     "vodhip_node_index_shard": (_i32, [_vp, _i32, _c.POINTER(_vp), _c.POINTER(_i64), _c.POINTER(_i32)]),
     "vodhip_node_index_set_param": (_i32, [_vp, _c.c_char_p, _i64]),
+    "vodhip_node_index_get_stat": (_i32, [_vp, _c.c_char_p, _c.POINTER(_i64)]),
     "vodhip_node_index_peer_access": (_i32, [_vp, _c.POINTER(_i32), _i32]),
     "vodhip_node_index_set_row_labels": (_i32, [_vp, _vp, _i64]),
     "vodhip_node_index_set_query_labels": (_i32, [_vp, _vp, _i32, _i32]),

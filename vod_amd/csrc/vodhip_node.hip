@@ -83,6 +83,12 @@ struct vodhip_node_index {
     hipEvent_t q_on_host = nullptr;
     // add / reset / label changes / searches on one handle are serialised (the staging buffers and the shards' FIFOs are shared); a
     // `set_query_labels` + `search` pair is two calls: callers that filter from several threads go through a vodhip_batcher
+    // param "profile" = 1: HIP events bracket the merge (recorded once every shard's list has arrived on devices[0]) and every shard's
+    // copy of its list towards devices[0] - `vodhip_node_index_get_stat` reads them: "last_merge_ns", "last_copy_ns_max"
+    int64_t profile = 0;
+    hipEvent_t merge_ev[2] = {nullptr, nullptr};   // on devices[0]
+    std::vector<hipEvent_t> copy_ev;               // [2 * n]: begin / end of shard g's copy, on its device
+    bool timed = false;                            // the events above belong to the last search
     std::mutex mu;
     std::vector<char> enqueued;        // shard g has a search of the CURRENT call in its FIFO (drained if the call fails half-way)
     bool staged(int g) const { return g > 0 && (host_staging != 0 || (device[g] != device[0] && peer_ok[g] == 0)); }
@@ -216,6 +222,10 @@ int vodhip_node_index_destroy(vodhip_node_index_t* nx) {
     }
     if (nx->pin_q) (void)hipHostFree(nx->pin_q);
     if (nx->q_on_host) (void)hipEventDestroy(nx->q_on_host);
+    for (hipEvent_t e : nx->copy_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : nx->merge_ev)
+        if (e) (void)hipEventDestroy(e);
     if (nx->n && nx->shard[0]) (void)hipSetDevice(nx->device[0]);
     (void)hipFree(nx->gathered_scores);
     (void)hipFree(nx->gathered_ids);
@@ -326,6 +336,7 @@ int vodhip_node_index_set_param(vodhip_node_index_t* nx, const char* key, int64_
         nx->host_staging = value;
         return 0;
     }
+    if (key && !strcmp(key, "profile")) nx->profile = value;  // (and on every shard: its filter launches are bracketed too)
     for (int g = 0; g < nx->n; ++g)
         if (vodhip_index_set_param(nx->shard[g], key, value)) return -1;
     return 0;
@@ -344,6 +355,18 @@ int node_search_locked(vodhip_node_index* nx, const void* queries, int q_dtype, 
     if (nq == 0) return 0;
     const int G = nx->n, dev0 = nx->device[0];
     hipStream_t user = location == VODHIP_DEVICE ? (hipStream_t)stream_ : nx->stream[0];
+    nx->timed = false;
+    if (nx->profile && nx->copy_ev.empty()) {
+        nx->copy_ev.assign((size_t)2 * G, nullptr);
+        for (int g = 0; g < G; ++g) {
+            NODE_HIP_OK(hipSetDevice(nx->device[g]));
+            NODE_HIP_OK(hipEventCreate(&nx->copy_ev[2 * g]));
+            NODE_HIP_OK(hipEventCreate(&nx->copy_ev[2 * g + 1]));
+        }
+        NODE_HIP_OK(hipSetDevice(dev0));
+        NODE_HIP_OK(hipEventCreate(&nx->merge_ev[0]));
+        NODE_HIP_OK(hipEventCreate(&nx->merge_ev[1]));
+    }
     const size_t q_bytes = (size_t)nq * (size_t)nx->dim * elem_bytes(q_dtype), res = (size_t)nq * (size_t)k;
 
     // buffers (grown on demand, kept)
@@ -455,8 +478,10 @@ int node_search_locked(vodhip_node_index* nx, const void* queries, int q_dtype, 
             }
             if (!nx->on_host[g]) NODE_HIP_OK(hipEventCreateWithFlags(&nx->on_host[g], hipEventDisableTiming));
             char* pin = (char*)nx->pin_res[g];
+            if (nx->profile) NODE_HIP_OK(hipEventRecord(nx->copy_ev[2 * g], nx->stream[g]));
             NODE_HIP_OK(hipMemcpyAsync(pin, nx->buf[g].scores, res * sizeof(float), hipMemcpyDeviceToHost, nx->stream[g]));
             NODE_HIP_OK(hipMemcpyAsync(pin + nx->pin_res_elems[g] * 4, nx->buf[g].ids, res * sizeof(int64_t), hipMemcpyDeviceToHost, nx->stream[g]));
+            if (nx->profile) NODE_HIP_OK(hipEventRecord(nx->copy_ev[2 * g + 1], nx->stream[g]));  // (the down-leg; the up-leg runs on the merge stream)
             NODE_HIP_OK(hipEventRecord(nx->on_host[g], nx->stream[g]));
             NODE_HIP_OK(hipSetDevice(dev0));
             NODE_HIP_OK(hipStreamWaitEvent(user, nx->on_host[g], 0));
@@ -465,6 +490,7 @@ int node_search_locked(vodhip_node_index* nx, const void* queries, int q_dtype, 
             NODE_HIP_OK(hipEventRecord(nx->arrived[g], user));  // (the merge below runs on `user` anyway: this keeps the wait list uniform)
             continue;
         }
+        if (nx->profile) NODE_HIP_OK(hipEventRecord(nx->copy_ev[2 * g], nx->stream[g]));
         if (nx->device[g] == dev0) {
             NODE_HIP_OK(hipMemcpyAsync(ds, nx->buf[g].scores, res * sizeof(float), hipMemcpyDeviceToDevice, nx->stream[g]));
             NODE_HIP_OK(hipMemcpyAsync(di, nx->buf[g].ids, res * sizeof(int64_t), hipMemcpyDeviceToDevice, nx->stream[g]));
@@ -472,6 +498,7 @@ int node_search_locked(vodhip_node_index* nx, const void* queries, int q_dtype, 
             NODE_HIP_OK(hipMemcpyPeerAsync(ds, dev0, nx->buf[g].scores, nx->device[g], res * sizeof(float), nx->stream[g]));
             NODE_HIP_OK(hipMemcpyPeerAsync(di, dev0, nx->buf[g].ids, nx->device[g], res * sizeof(int64_t), nx->stream[g]));
         }
+        if (nx->profile) NODE_HIP_OK(hipEventRecord(nx->copy_ev[2 * g + 1], nx->stream[g]));
         NODE_HIP_OK(hipEventRecord(nx->arrived[g], nx->stream[g]));
     }
     if (rc) return nfail("%s", first_error.c_str());
@@ -479,7 +506,10 @@ int node_search_locked(vodhip_node_index* nx, const void* queries, int q_dtype, 
     NODE_HIP_OK(hipSetDevice(dev0));
     if (G > 1) {
         for (int g = 0; g < G; ++g) NODE_HIP_OK(hipStreamWaitEvent(user, nx->arrived[g], 0));
+        if (nx->profile) NODE_HIP_OK(hipEventRecord(nx->merge_ev[0], user));  // every list has arrived: what follows is the merge alone
         if (vodhip_merge_topk(nx->gathered_scores, nx->gathered_ids, G, nq, k, k, final_scores, final_ids, user)) return -1;
+        if (nx->profile) NODE_HIP_OK(hipEventRecord(nx->merge_ev[1], user));
+        nx->timed = nx->profile != 0;
     } else if (location == VODHIP_DEVICE) {
         NODE_HIP_OK(hipEventRecord(nx->arrived[0], nx->stream[0]));
         NODE_HIP_OK(hipStreamWaitEvent(user, nx->arrived[0], 0));
@@ -521,6 +551,32 @@ int vodhip_node_index_search(vodhip_node_index_t* nx, const void* queries, int q
         vodhip::set_last_error(keep.c_str());
     }
     return rc;
+}
+
+int vodhip_node_index_get_stat(vodhip_node_index_t* nx, const char* key, int64_t* out) {
+    if (!nx || !key || !out) return nfail("NULL argument");
+    std::lock_guard<std::mutex> guard(nx->mu);
+    *out = 0;
+    if (!strcmp(key, "last_merge_ns") || !strcmp(key, "last_copy_ns_max")) {
+        if (!nx->timed || nx->n < 2) return 0;  // (param "profile" was off, or one shard: no exchange, no merge)
+        float ms = 0.f;
+        if (!strcmp(key, "last_merge_ns")) {
+            NODE_HIP_OK(hipSetDevice(nx->device[0]));
+            NODE_HIP_OK(hipEventSynchronize(nx->merge_ev[1]));
+            NODE_HIP_OK(hipEventElapsedTime(&ms, nx->merge_ev[0], nx->merge_ev[1]));
+            *out = (int64_t)((double)ms * 1e6);
+            return 0;
+        }
+        for (int g = 0; g < nx->n; ++g) {
+            NODE_HIP_OK(hipSetDevice(nx->device[g]));
+            NODE_HIP_OK(hipEventSynchronize(nx->copy_ev[2 * g + 1]));
+            NODE_HIP_OK(hipEventElapsedTime(&ms, nx->copy_ev[2 * g], nx->copy_ev[2 * g + 1]));
+            *out = std::max<int64_t>(*out, (int64_t)((double)ms * 1e6));
+        }
+        NODE_HIP_OK(hipSetDevice(nx->device[0]));
+        return 0;
+    }
+    return nfail("unknown stat '%s'", key);
 }
 
 }  // extern "C"

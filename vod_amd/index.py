@@ -356,6 +356,18 @@ class HipNodeIndex:
     def set_param(self, key: str, value: int) -> None:
         _native.check(self._lib.vodhip_node_index_set_param(self._h, key.encode(), int(value)))
 
+    def get_stat(self, key: str) -> int:
+        """Node-level stats of the last search with `set_param("profile", 1)`: "last_merge_ns", "last_copy_ns_max" (HIP events)."""
+        out = ctypes.c_int64()
+        _native.check(self._lib.vodhip_node_index_get_stat(self._h, key.encode(), ctypes.byref(out)))
+        return out.value
+
+    def shard_stat(self, g: int, key: str) -> int:
+        """`vodhip_index_get_stat` of shard g's own handle (e.g. "last_filter_ns" with profiling on)."""
+        out = ctypes.c_int64()
+        _native.check(self._lib.vodhip_index_get_stat(ctypes.c_void_p(self.shard(g)[0]), key.encode(), ctypes.byref(out)))
+        return out.value
+
     def peer_access(self) -> list[int]:
         """Per shard: 2 = on `devices[0]`, 1 = direct peer copies with it, 0 = staged through pinned host memory (no peer access, or
         `set_param("host_staging", 1)`)."""
