@@ -410,7 +410,7 @@ def test_an_outlier_row_is_scored_not_bounded(dtype):
         assert ix.get_stat("exact_outliers") == 2
         assert ix.get_stat("last_exact_band_queries") <= 2   # (round 5: all 160)
         ids = i.cpu().numpy()
-        assert ((ids == 777).any(axis=1) | (ids == 31_000).any(axis=1)).all()  # |score| ~ 1e4: one of the two leads every list
+        assert (ids[:, 0] == 777).sum() > 40 and (ids[:, 0] == 31_000).sum() > 40  # |score| ~ 1e4: each leads the lists it scores positively on
         # rows added later re-derive the statistics; a reset forgets the outliers
         ix.reset()
         ix.add(x[:500])
