@@ -473,15 +473,19 @@ def _brute_force_f64(rig: Rig, qs, row_block, n_local: int, row_lo: int, k: int,
 
 
 def _compare_with(torch, fs, fi, sample, ref_s, ref_i, comparator: str) -> dict:
+    # recall@k as the reference defines it (vod_models/monitoring/functional.py:74-81,166-180), restated in oracle/metrics.py and pinned
+    # by tests/golden/metrics_recall_ndcg.npz: the comparator's top-k ids are the positives, the returned list is ranked by its scores
+    from oracle.metrics import recall_of_ids  # the checker, outside every timed region
+
     got_i = fi[sample].cpu()
-    hits = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(got_i, ref_i))
+    recall = recall_of_ids(got_i.numpy(), fs[sample].float().cpu().numpy(), ref_i.numpy())
     got_s = fs[sample][:, : ref_s.shape[1]].double().cpu()
     fin = torch.isfinite(ref_s) & torch.isfinite(got_s)
     diff = (got_s - ref_s).abs()[fin]
     scale = float(ref_s[fin].abs().max()) if bool(fin.any()) else 0.0
     return {
         "comparator": comparator,
-        "recall_at_k": hits / float(ref_i.numel()),
+        "recall_at_k": recall,
         "rows_with_identical_id_order": float((got_i[:, : ref_i.shape[1]] == ref_i).all(dim=1).float().mean()),
         "max_abs_score_diff": float(diff.max()) if diff.numel() else 0.0,
         "max_rel_score_diff": float((diff / ref_s[fin].abs().clamp_min(1e-30)).max()) if diff.numel() else 0.0,

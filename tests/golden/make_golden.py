@@ -19,6 +19,7 @@ The reference functions exercised (paths relative to /root/reference/src):
   stack        vod_types/retrieval.py:259-287
   io           vod_search/io.py:17-32
   gradients    vod_models/vod_gradients/retrieval.py:30-243 (incl. the auxiliary losses :94-150)
+  metrics      vod_models/monitoring/functional.py:41-161,166-200 (compute_recall / ndcg / mrr / hitrate / precision)
 """
 from __future__ import annotations
 
@@ -493,6 +494,36 @@ def gen_gradients_aux() -> None:
         5, 12, 32, False, 0.2, True, 36)
 
 
+def gen_metrics() -> None:
+    """`metrics_recall_ndcg`: the reference's retrieval metrics on seeded [B, N] scores / graded relevances with NaN, +inf and
+    -inf scores, rows without positives and a row whose positives are all masked; topk in {None, 1, 5, 10}."""
+    import torch
+
+    F = M["functional"]
+    rng = np.random.default_rng(4242)
+    B, N = 12, 24
+    scores = rng.normal(size=(B, N)).astype(np.float32)
+    rel = (rng.random((B, N)) < 0.2).astype(np.int64) * rng.integers(1, 4, size=(B, N))   # graded relevances 0..3
+    scores[1, :5] = np.nan
+    scores[2, 3] = np.inf        # masked by the reference (+inf), its relevance zeroed
+    scores[3, 10:] = -np.inf     # padding: ranked last, NOT masked (relevance 0, as pads have: equal scores are ranked in an
+    rel[3, 10:] = 0              # implementation-defined order by the reference's unstable argsort, so tied entries carry equal relevances)
+    rel[4] = 0                   # a row without positives
+    rel[5] = 0
+    rel[5, 2] = 2
+    scores[5, 2] = np.nan        # the only positive is masked
+    scores[6, :4] = scores[6, 4]  # ties
+    rel[6, :5] = rel[6, 4]
+    arrays = {"scores": scores, "relevances": rel}
+    topks = [0, 1, 5, 10]  # 0 = None
+    for name in ("recall", "ndcg", "mrr", "hitrate", "precision"):
+        fn = getattr(F, f"compute_{name}")
+        for tk in topks:
+            out = fn.compute(relevances=torch.from_numpy(rel), scores=torch.from_numpy(scores), topk=tk or None)
+            arrays[f"{name}_top{tk}"] = out.to(torch.float64).numpy() if out.dtype != torch.bool else out.numpy()
+    _save("metrics_recall_ndcg", {"seed": 4242, "B": B, "N": N, "topk": topks, "fn": "vod_models.monitoring.functional.compute_*"}, **arrays)
+
+
 def gen_flat_ip() -> None:
     """Build-owned (NOT from the reference: faiss is absent) exact fixtures: small-integer fp16 vectors."""
     sys.path.insert(0, str(HERE.parent.parent))
@@ -518,6 +549,11 @@ if __name__ == "__main__":
         gen_collate_chain()
         (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True))
         raise SystemExit(0)
+    if sys.argv[1:] == ["metrics"]:
+        manifest.update(json.loads((HERE / "manifest.json").read_text()))
+        gen_metrics()
+        (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True))
+        raise SystemExit(0)
     if sys.argv[1:] == ["merge_corners"]:
         manifest.update(json.loads((HERE / "manifest.json").read_text()))
         gen_merge_corners()
@@ -532,6 +568,7 @@ if __name__ == "__main__":
     gen_search_plumbing()
     gen_gradients()
     gen_gradients_aux()
+    gen_metrics()
     gen_flat_ip()
     (HERE / "manifest.json").write_text(json.dumps(manifest, indent=1, sort_keys=True))
     total = sum(p.stat().st_size for p in HERE.glob("*.npz"))

@@ -407,3 +407,25 @@ def test_c_collate_restatement_sampling_matches_reference():
         np.testing.assert_array_equal(out["local"][fin], g[f"out_samples_{c}"][fin])
         np.testing.assert_array_equal(out["labels"], g[f"out_labels_{c}"])
         np.testing.assert_allclose(out["log_weights"][fin], ref_w[fin], rtol=2e-5, atol=2e-5)
+
+
+def test_metrics_restatement_matches_the_reference_fixture():
+    """SURVEY 10's `metrics_recall_ndcg`: recall / ndcg / mrr / hitrate / precision of the reference
+    (vod_models/monitoring/functional.py:41-161) on scores with NaN / +inf / -inf, rows without positives, a masked positive, ties."""
+    from oracle import metrics
+
+    z = np.load(GOLDEN / "metrics_recall_ndcg.npz")
+    scores, rel = z["scores"], z["relevances"]
+    for name in ("recall", "ndcg", "mrr", "hitrate", "precision"):
+        for tk in (0, 1, 5, 10):
+            want = z[f"{name}_top{tk}"]
+            got = getattr(metrics, name)(rel, scores, tk or None)
+            if want.dtype == bool:
+                np.testing.assert_array_equal(got, want, err_msg=f"{name}@{tk}")
+            else:
+                np.testing.assert_allclose(got.astype(np.float64), want, rtol=2e-6, atol=0, equal_nan=True, err_msg=f"{name}@{tk}")
+    # bench.py's verify.recall_at_k = this recall with the comparator's top-k as the positives
+    got_ids = np.array([[5, 3, 9, -1], [1, 2, 3, 4]])
+    got_s = np.array([[3.0, 2.0, 1.0, -np.inf], [4.0, 3.0, 2.0, 1.0]], dtype=np.float32)
+    ref_ids = np.array([[5, 9, 7, -1], [4, 3, 2, 1]])
+    assert metrics.recall_of_ids(got_ids, got_s, ref_ids) == pytest.approx((2 / 3 + 1.0) / 2)
