@@ -121,7 +121,11 @@ hipError_t allow_dynamic_lds(const void* kernel, int bytes);
 // the FILTER stage on the guide's 8-phase K loop (experiments/csrc/kernels_mips_8phase.hip; tiles 13 / 14)
 hipError_t launch_filter_8phase(int store_dtype, int variant /* 14 = production; 13, 15, 16: experiment builds */, const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin, int64_t row_end,
                                 int64_t nq, int64_t nq_pad, const SearchWorkspace& ws, hipStream_t stream);
-inline bool filter_tile_is_persistent(int tile) { return tile >= 8 && tile <= 16; }  // one 256 x 256 workgroup per CU walking tiles
+// the FILTER stage with the query tile resident in registers (experiments/csrc/kernels_mips_qres.hip; tile 17; dim_pad 384 / 768 only)
+bool filter_qres_supports(int64_t dim_pad);
+hipError_t launch_filter_qres(int store_dtype, const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin, int64_t row_end,
+                              int64_t nq, int64_t nq_pad, const SearchWorkspace& ws, hipStream_t stream);
+inline bool filter_tile_is_persistent(int tile) { return tile >= 8 && tile <= 17; }  // one 256 x 256 workgroup per CU walking tiles
 int filter_tile_rows(int tile);  // BM of the tile config
 int filter_tile_cols(int tile);  // BN of the tile config
 int filter_group_rows(int tile); // rows per GMAX group (one lane's rows of one column block)
