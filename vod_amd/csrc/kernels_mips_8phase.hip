@@ -79,7 +79,12 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
         const int arow = (wave >> 2) * 128 + (wave & 3) * 16 + u * 8 + st_row;  // + h * 64
         const int brow = (wave >> 1) * 64 + (wave & 1) * 16 + u * 8 + st_row;   // + h * 32
         a_src[u] = (const char*)X + ((size_t)filter_tile_row0(ex, row_begin, xt0, BM) + arow) * row_stride + ((st_slot ^ sw) << 4);
-        b_src[u] = (const char*)Q + (size_t)(q0 + brow) * row_stride + ((st_slot ^ sw) << 4);
+#ifdef VODHIP_ABLATION  // diagnostic builds, kflags bit 128: every q-tile stages the rows of q-tile 0 (an XCD's query working set shrinks to 256 rows; bytes / timing only)
+        const int q0_stage = (ex.flags & (128 << 8)) ? 0 : q0;
+#else
+        const int q0_stage = q0;
+#endif
+        b_src[u] = (const char*)Q + (size_t)(q0_stage + brow) * row_stride + ((st_slot ^ sw) << 4);
     }
     const size_t a_half_step = 64 * row_stride, b_half_step = 32 * row_stride;
     const size_t tile_step_bytes = (size_t)xt_step * BM * row_stride;
