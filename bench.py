@@ -316,7 +316,7 @@ def make_queries(torch, dev, tdt, data: str, nq: int, d: int, n_total: int):
 
 NAMEPLATE_MFMA = 2.5e15   # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md): what `roofline.peak` / `frac` / `bound` use
 NAMEPLATE_HBM = 8.0e12     # HBM3E peak
-PRACTICAL_MFMA = 1.24e15   # flop/s a streaming fp16 contraction holds on this part (power-limited; DESIGN.md 5, MI355X_MICROARCH "DVFS give-back")
+PRACTICAL_MFMA = 1.24e15   # flop/s a streaming fp16 contraction holds on this part (power-limited; HISTORY.md 5, MI355X_MICROARCH "DVFS give-back")
 PRACTICAL_HBM = 6.29e12    # B/s of a streaming copy (MI355X_MICROARCH.md:34-43)
 
 

@@ -94,7 +94,7 @@ int vodhip_index_get_rows_f32(const vodhip_index_t* index, int64_t row_begin, in
  * guaranteed, not statistical: the scan's top-k' list (k' > k, param "exact_expand") is re-scored from the float32 plane, and the
  * device checks per query that no row outside the list can reach the k-th re-scored score, using the bound
  * |s - s~| <= |q - q~| max|x| + |q~| max|x - x~| (+ summation slack) with the norms of the actual data; a query that fails the check
- * is searched again with every row inside that band as a candidate.  The queries must stay valid until finish, as
+ * is searched again with every row inside that band as a candidate ("Exact-f32 mode").  The queries must stay valid until finish, as
  * always; q_dtype F32 is the point of the mode, F16 / BF16 queries are taken as exact values.
  *
  * vodhip_index_search        enqueue + wait + exactness check (if a query's candidate list overflowed, that query is

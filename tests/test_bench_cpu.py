@@ -41,7 +41,7 @@ def test_single_gpu_without_a_gpu_fails_loudly():
 
 
 def test_kloop_microbenchmark_cross_compiles(tmp_path):
-    """experiments/ubench/kloop.hip (the K loop rebuilt from its parts: profiles/README.md) stays buildable for gfx950."""
+    """experiments/ubench/kloop.hip (the K loop rebuilt from its parts: profiles/README.md, HISTORY.md 5) stays buildable for gfx950."""
     import pathlib
     import shutil
 

@@ -51,7 +51,7 @@ def _assert_exact(ix, q, x, k, **kw):
 
 
 MANIFEST = json.loads((GOLDEN / "manifest.json").read_text())
-# production filter-kernel variants (DESIGN.md 4.1): 1 = 128x128, 42 / 46 = small-batch rings, 8 = persistent 256x256 with
+# production filter-kernel variants (DESIGN.md 4): 1 = 128x128, 42 / 46 = small-batch rings, 8 = persistent 256x256 with
 # both waves of a SIMD in lockstep (default for 129..256 queries), 9 = the same with waves 4..7 staggered by one k-step, 14 = the 8-phase
 # K loop (kernels_mips_8phase.hip: default above 256 queries)
 TILES = [1, 8, 9, 14, 42, 46]

@@ -1,6 +1,6 @@
 """Host-side planning of a search (`vodhip_debug_schedule`: no device is touched), checked on CPU.
 
-Invariants of the stage list, over seeded random (ntotal, k, nq, cand_cap) and the BASELINE shapes:
+Invariants of the stage list (HISTORY.md 4.1), over seeded random (ntotal, k, nq, cand_cap) and the BASELINE shapes:
   * the FILTER / DENSE stages tile [0, ntotal) exactly once, in order; a DENSE stage never exceeds cand_cap rows;
   * a GMAX bootstrap samples S = tiles * BM rows, all below ntotal, all distinct, in >= 2k (4k when cand_cap allows) and
     <= cand_cap groups, and the

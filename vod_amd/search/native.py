@@ -6,7 +6,7 @@ needs no GPU).  `NativeHttpFront` runs the library's HTTP/1.1 server: the hot ro
 answered by `Endpoints.handle` through the fallback callback.
 
 Counterpart of the reference's uvicorn + FastAPI process (/root/reference/src/vod_search/faiss_search/server.py:57-98), whose single worker
-serialises `faiss_index.search` calls; see DESIGN.md 6b for the policy and the measurements.
+serialises `faiss_index.search` calls; see HISTORY.md 6b (summary: DESIGN.md 7) for the policy and the measurements.
 """
 from __future__ import annotations
 
