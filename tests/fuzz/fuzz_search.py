@@ -49,9 +49,15 @@ def draw(rng):
     # queries with more significant bits than fp16 / bf16 keep, sized so that every float32 partial sum is still exact) - the result must
     # equal the float64 oracle on the UNROUNDED values bit for bit; "exact_expand" 1 = the scan lists only k rows (band pass every time)
     c["exact"] = bool(rng.random() < 0.34)
-    c["lossy"] = str(rng.choice(["none", "rows", "queries"])) if c["exact"] else "none"
+    # round 6: "outliers" = a few rows (1 .. 80: more than the 64 the outlier list holds) scaled by 2^6 .. 2^14 - norms far above the rest of
+    # the store's, and in an fp16 store values BEYOND the scan dtype's range (8 x 2^14 > 65504: the scan copy saturates); every float32
+    # partial sum stays an exact integer
+    c["lossy"] = str(rng.choice(["none", "rows", "queries", "outliers"])) if c["exact"] else "none"
     c["exact_expand"] = int(rng.choice([0, 0, 1, 100, 300])) if c["exact"] else 0
-    if c["lossy"] != "none" and c["dtype"] == "f16":
+    c["exact_adapt"] = int(rng.choice([1, 1, 0])) if c["exact"] else 1
+    if c["lossy"] == "outliers":
+        c["d"] = min(c["d"], 32 if c["dtype"] == "f16" else 128)  # 2^17 x 4 x 32 = 2^24
+    elif c["lossy"] != "none" and c["dtype"] == "f16":
         c["d"] = min(c["d"], 128)  # wide values x 3-bit values x d terms must stay below 2^24
     return c
 
@@ -68,6 +74,13 @@ def lossy_inputs(rng, c, x, q):
     elif c["lossy"] == "queries":
         q = rng.integers(-wide, wide + 1, size=q.shape).astype(np.float32)
         x = np.clip(x, -4, 4)
+    elif c["lossy"] == "outliers":
+        q = np.clip(q, -4, 4)
+        x = np.clip(x, -8, 8).copy()
+        m = min(x.shape[0], int(rng.choice([1, 2, 5, 40, 80])))
+        rows = rng.choice(x.shape[0], size=m, replace=False)
+        top = 14 if c["dtype"] == "f16" else 10
+        x[rows] *= np.exp2(rng.integers(6, top + 1, size=(m, 1))).astype(np.float32)
     return x, q
 
 
@@ -101,6 +114,8 @@ def run_node_trial(c):
             nx.set_param("cand_cap", c["cand_cap"])
         if c["exact_expand"]:
             nx.set_param("exact_expand", c["exact_expand"])
+        if c.get("exact_adapt", 1) == 0:
+            nx.set_param("exact_adapt", 0)
         for key in ("dense_rows", "sample_div", "growth"):
             if c[key]:
                 nx.set_param(key, c[key])
@@ -159,6 +174,8 @@ def run_trial(c):
             ix.set_param("cand_cap", c["cand_cap"])
         if c["exact_expand"]:
             ix.set_param("exact_expand", c["exact_expand"])
+        if c.get("exact_adapt", 1) == 0:
+            ix.set_param("exact_adapt", 0)
         for key in ("dense_rows", "sample_div", "growth"):
             if c[key]:
                 ix.set_param(key, c[key])
