@@ -21,7 +21,8 @@ cd /tmp && export TMPDIR=/tmp
 for w in $LIST; do
   a="${W[$w]}"
   extra="--no-cpu-baseline --no-side"; [ "$w" = "c3" ] && extra=""   # c3 = the default command: headline + side workloads + CPU baseline
-  timeout 900 python3 $ROOTD/bench.py $a $extra > $OUT/${w}_bench.json 2> $OUT/${w}_bench.err
+  steps=""; case $w in c2|c2exact) steps="--steps 200 --warmup 20";; shard|shardfc|c4shard) steps="--steps 60 --warmup 10";; esac   # (a 20-step C2 run is 9 ms on a cold device: round 5's r05_c2_bench.json read 0.567 ms for that reason)
+  timeout 900 python3 $ROOTD/bench.py $a $extra $steps > $OUT/${w}_bench.json 2> $OUT/${w}_bench.err
   tail -1 $OUT/${w}_bench.json | cut -c1-400
   P="--steps 5 --warmup 2 --no-cpu-baseline --no-verify --no-side"
   # one-query-tile workloads run on two lanes (two searches overlap on the device): the kernel trace of those is taken with ONE lane, so that
