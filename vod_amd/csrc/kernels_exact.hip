@@ -114,7 +114,10 @@ __device__ __forceinline__ float round_to_store(float f, int store_dtype) {  // 
 }
 
 constexpr int XT = 512;  // threads of the re-scoring workgroup
-constexpr int NCR = 4;   // float32 rows a wave has in flight, every column of them requested at once: 8 waves x 4 rows = 32 rows x dim floats per query
+#ifndef VODHIP_EXACT_NCR
+#define VODHIP_EXACT_NCR 4
+#endif
+constexpr int NCR = VODHIP_EXACT_NCR;   // float32 rows a wave has in flight, every column of them requested at once: 8 waves x 4 rows = 32 rows x dim floats per query
 
 // descending sort of P (a power of two, 64 .. 4096) keys in LDS: up to 512 keys ONE wavefront sorts them in its registers (shuffles only,
 // no barrier: the 28-45 barrier-separated LDS stages this replaces were a third of the re-scoring launch), above that the
