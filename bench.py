@@ -927,9 +927,6 @@ def side_workloads(rig: Rig, args, headline_index, headline_row_lo) -> list:
     one("C2_exact_f32", rows=1_000_000, nq=256, steps=200, warmup=20, exact=True)
     one("C3_exact_f32", rows=args.rows, nq=args.nq, steps=max(5, args.steps), warmup=3, exact=True)
     one("C4_shard_of_8_exact_f32", rows=5_000_000, dim=1024, nq=512, k=200, dtype="bf16", steps=40, warmup=5, exact=True)
-    # ... and the same float32 corpus behind an fp16 SCAN copy: in exact mode the store dtype is only the filter's precision (the result is
-    # the float32 brute force either way) - fp16's 11-bit significand gives an 8x tighter bound than bf16's, i.e. k' ~ 1.1 k instead of 2 k
-    one("C4_shard_of_8_exact_f32_f16_scan", rows=5_000_000, dim=1024, nq=512, k=200, dtype="f16", steps=40, warmup=5, exact=True)
     free_b = rig.torch.cuda.mem_get_info(rig.dev)[0]
     if free_b > 110e9:
         one("C4_one_gpu", rows=40_000_000, dim=1024, nq=512, k=200, dtype="bf16", steps=10, warmup=3, twin=True)

@@ -1,9 +1,10 @@
 import sys, torch
 sys.path.insert(0, '/root/repo')
 from vod_amd.index import HipFlatIndex, PackedTopk
-n, d, nq, k = 500_000, 1024, 512, 200
+n, d, nq, k = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000, 1024, 512, 200
+dt = torch.float16 if (len(sys.argv) > 2 and sys.argv[2] == 'f16') else torch.bfloat16
 g = torch.Generator(device='cuda').manual_seed(1)
-ix = HipFlatIndex(d, n, dtype=torch.bfloat16, device=0, exact_f32=True)
+ix = HipFlatIndex(d, n, dtype=dt, device=0, exact_f32=True)
 for c in range(2):
     ix.add(torch.randn((n // 2, d), generator=g, device='cuda'))
 q = torch.randn((nq, d), generator=g, device='cuda')

@@ -110,7 +110,7 @@ def _fake_measurement(world=1, exact=False):
 def _fake_side(bench):
     side = []
     for name in ["C2", "C3_nq256", "C3_clustered", "C3_shard_of_8", "C3_shard_of_8_with_exchange", "C4_shard_of_8", "C2_exact_f32", "C3_exact_f32",
-                 "C4_shard_of_8_exact_f32", "C4_shard_of_8_exact_f32_f16_scan", "C4_one_gpu"]:
+                 "C4_shard_of_8_exact_f32", "C4_one_gpu"]:
         m = _fake_measurement()
         side.append({"name": name, "workload": "x" * 150, "steps": 200, "warmup": 20, "ms_per_step": 0.4521234567, "value": 566123.456789, "unit": "queries/s",
                      "recovery_passes": 0, "index_build_s": 0.017, "roofline": bench.roofline_of(m, 1), "verify": m["verify"]})
@@ -162,7 +162,7 @@ def test_final_line_is_strict_json_below_4k_with_roofline_and_cpu_baseline(capsy
     for e in _fake_side(bench):
         bench.emit_side(e)
     lines = capsys.readouterr().out.splitlines()
-    assert len(lines) == 13 and all(ln.startswith("# side {") and len(ln) < 400 for ln in lines), [len(ln) for ln in lines]
+    assert len(lines) == 12 and all(ln.startswith("# side {") and len(ln) < 400 for ln in lines), [len(ln) for ln in lines]
     assert json.loads(lines[0][len("# side "):])["roofline"]["bound"] in ("mfma", "hbm")
 
 

@@ -480,3 +480,23 @@ def test_row_labels_cannot_change_under_a_search_in_flight():
             ix.set_row_labels(None)
         ix.finish()
         ix.set_row_labels(None)
+
+
+def test_the_list_length_grows_past_its_starting_point_when_lists_fail_their_proof():
+    """fp16 scan, dim 1024, k 200: the starting k' (1.1 k + 16 = 236) is one or two rows short for a few queries of a batch - each of those
+    costs a band pass (a second scan) per batch.  The adaptive length grows by a quarter (up to the bf16 formula) and then settles just above
+    what the batch needs: no band pass from the second search on; results unchanged."""
+    q, x = _gauss(97, 600_000, 1024, 256)
+    k = 200
+    with _index(x, dtype=torch.float16) as ix:
+        tq = torch.from_numpy(q).cuda()
+        s0, i0 = ix.search(tq, k)
+        assert ix.get_stat("last_exact_kx") == 236
+        first_band = ix.get_stat("last_exact_band_queries")
+        for _ in range(6):
+            s, i = ix.search(tq, k)
+            assert torch.equal(s, s0) and torch.equal(i, i0)
+        assert ix.get_stat("last_exact_band_queries") == 0
+        need, kx = ix.get_stat("last_exact_need"), ix.get_stat("last_exact_kx")
+        assert need < kx <= 2 * k + 16 and (first_band == 0 or kx > 236), (first_band, need, kx)
+        assert _compare(s0, i0, q, x, k)["recall"] == 1.0

@@ -550,8 +550,10 @@ int enqueue_search(vodhip_index* ix, const PendingSearch& ps, bool safe, int rec
 // the scan's list length k' for the caller's k: enough rows that the list usually PROVES itself complete (rows within eps of the
 // k-th score: ~5 % more than k for an fp16 store of N(0, 1) x 768 rows, ~70 % more for bf16 x 1024 - profiles/r05_exact_*.json);
 // a query whose list does not is searched again as a band pass, so this is a speed knob, never a correctness one
-int exact_kx(const vodhip_index* ix, int k) {
-    const int64_t x100 = ix->exact_expand_x100 > 0 ? ix->exact_expand_x100 : (ix->dtype == VODHIP_F16 ? 110 : 200);
+int exact_kx(const vodhip_index* ix, int k, bool upper_limit = false) {
+    // upper_limit: what the adaptive list length may grow to when lists keep failing their proof (the bf16 formula, whatever the scan dtype:
+    // fp16 at dim 1024 / k 200 needs ~1.3 k, more than its 1.1 k + 16 starting point)
+    const int64_t x100 = ix->exact_expand_x100 > 0 ? ix->exact_expand_x100 : ((ix->dtype == VODHIP_F16 && !upper_limit) ? 110 : 200);
     const int64_t kx = ((int64_t)k * x100 + 99) / 100 + 16;
     const int64_t fits = std::max<int64_t>(k, ix->cand_cap / ROW_ALIGN * ROW_ALIGN);  // the scan needs cand_cap >= its list length
     return (int)std::min<int64_t>(std::min<int64_t>(VODHIP_MAX_K, fits), std::max<int64_t>(kx, k));
@@ -967,8 +969,9 @@ int vodhip_index_search_async(vodhip_index_t* ix, const void* queries, int q_dty
         const int kx_formula = exact_kx(ix, k);
         // (adapted to what the last searches of this k needed - finish() - unless the caller fixed the expansion or switched it off)
         const bool adapt = ix->exact_adapt && ix->exact_expand_x100 == 0 && ix->adapt_k == k && ix->adapt_kx >= k;
-        ps.kx = adapt ? std::min(ix->adapt_kx, kx_formula) : kx_formula;
-        if (exact_reserve_lists(ix, ps.slot, (size_t)nq * kx_formula)) return -1;
+        const int kx_limit = exact_kx(ix, k, true);
+        ps.kx = adapt ? std::min(ix->adapt_kx, kx_limit) : kx_formula;
+        if (exact_reserve_lists(ix, ps.slot, (size_t)nq * kx_limit)) return -1;
         PendingSearch in = exact_inner(ix, ps);
         in.defer_flags = true;  // ONE copy of both flag words, behind the re-scoring launch
         if (enqueue_search(ix, in, ix->force_safe != 0, 0, stream)) return -1;
@@ -1064,11 +1067,12 @@ int vodhip_index_search_finish(vodhip_index_t* ix, void* stream_) {
     if (ps.kx > 0 && ps.nq > 0 && ix->exact_adapt && ix->exact_expand_x100 == 0) {
         // The list length of the NEXT searches of this k: what this one needed (the list entries within eps of the k-th exact score,
         // maximum over the queries) + 1/16 + 8, rounded up to 8; it rises at once and falls by a quarter of the gap per search.  A list
-        // that did not prove complete (need == k') sends the next search back to the formula.  A speed knob only: any k' >= k returns
+        // that did not prove complete (need == k') makes the next one a quarter longer, up to the bf16 formula whatever the scan dtype.  A speed knob only: any k' >= k returns
         // the same result (the band pass covers what a short list misses).
         const int need = (int)ix->overflow_host[FLAG_WORDS * ps.slot + 2];
-        const int formula = exact_kx(ix, ps.k);
-        int target = need >= ps.kx ? formula : std::min(formula, (need + need / 16 + 8 + 7) / 8 * 8);
+        const int formula = exact_kx(ix, ps.k), limit = exact_kx(ix, ps.k, true);
+        // (a list that did not prove complete - need == k' - grows by a quarter, up to the limit; one that did settles at need + 1/16 + 8)
+        int target = need >= ps.kx ? std::min(limit, (ps.kx + ps.kx / 4 + 7) / 8 * 8) : std::min(limit, (need + need / 16 + 8 + 7) / 8 * 8);
         target = std::max(target, std::min(formula, ps.k + 8));
         if (ix->adapt_k != ps.k || ix->adapt_kx <= 0) ix->adapt_kx = formula;
         ix->adapt_k = ps.k;
