@@ -228,6 +228,14 @@ int vodhip_node_index_set_row_labels(vodhip_node_index_t* index, const int32_t* 
 int vodhip_node_index_set_query_labels(vodhip_node_index_t* index, const int32_t* q_labels, int n_per_query, int location);
 int vodhip_node_index_search(vodhip_node_index_t* index, const void* queries, int q_dtype, int64_t nq, int k, int location,
                              float* out_scores, int64_t* out_ids, void* stream);
+/* The same search in two halves (round 6), so that the host enqueues batch i + 1 on every shard while batch i runs - with 8 shards the
+ * enqueue alone is ~0.3 ms of host time per batch: `search_async` replicates the queries and enqueues every shard's search (nothing is
+ * waited for), `search_finish` completes the OLDEST pending search (every shard's exactness check, the lists' copies to devices[0], the
+ * merge; HOST outputs are complete on return, DEVICE outputs on `stream`).  Up to 2 searches may be pending; queries, outputs and subset
+ * labels of a pending search must stay valid until its finish.  `vodhip_node_index_search` = async + finish. */
+int vodhip_node_index_search_async(vodhip_node_index_t* index, const void* queries, int q_dtype, int64_t nq, int k, int location,
+                                   float* out_scores, int64_t* out_ids, void* stream);
+int vodhip_node_index_search_finish(vodhip_node_index_t* index);
 /* With param "profile" = 1 (also set on every shard: their filter launches are bracketed, read per shard through vodhip_index_get_stat on
  * the handle vodhip_node_index_shard returns): "last_merge_ns" = the merge launch on devices[0], from the moment every shard's list had
  * arrived; "last_copy_ns_max" = the slowest shard's copy of its list towards devices[0] (peer copy over xGMI, or the down-leg to pinned

@@ -220,3 +220,61 @@ print("ok")
     for _ in range(3):
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:] + out.stdout[-300:]
+
+
+@pytest.mark.parametrize("location", ["host", "device"])
+@pytest.mark.parametrize("staging", [0, 1])
+def test_two_searches_in_flight_return_what_the_synchronous_search_returns(location, staging):
+    """Round 6: `search_async` / `finish` - the host enqueues batch i + 1 on every shard while batch i runs.  Different batches (and k, and a
+    subset filter on one of them) in flight together, both entry modes, peer copies and the host-staged route: every result equals the oracle
+    = what the synchronous search returns; the FIFO order is the enqueue order; a third search is refused until one is finished."""
+    from vod_amd.index import HipNodeIndex
+
+    rng = np.random.default_rng(11)
+    x = rng.integers(-8, 9, size=(40_000, 96)).astype(np.float16)
+    qs = [rng.integers(-8, 9, size=(nq, 96)).astype(np.float16) for nq in (70, 300, 5, 129)]
+    ks = [100, 7, 33, 64]
+    labels = (np.arange(len(x)) % 5).astype(np.int32)
+    sub = np.full((300, 2), -1, dtype=np.int32)
+    sub[::2, 0] = 3
+    with HipNodeIndex(96, len(x), [0, 0, 0]) as nx:
+        nx.add(x)
+        nx.set_row_labels(labels)
+        if staging:
+            nx.set_param("host_staging", 1)
+        want = []
+        for j, (q, k) in enumerate(zip(qs, ks)):
+            if j == 1:
+                rows = [np.nonzero(labels == 3)[0] if r % 2 == 0 else np.arange(len(x)) for r in range(len(q))]
+                rs = np.full((len(q), k), -np.inf, dtype=np.float32)
+                ri = np.full((len(q), k), -1, dtype=np.int64)
+                for r in range(len(q)):
+                    a, b = _oracle(q[r : r + 1], x[rows[r]], k)
+                    rs[r], ri[r] = a[0], rows[r][b[0]]
+                want.append((rs, ri))
+            else:
+                want.append(_oracle(q, x, k))
+        as_in = (lambda q: q) if location == "host" else (lambda q: torch.from_numpy(q).cuda())
+        as_out = (lambda t: t) if location == "host" else (lambda t: t.cpu().numpy())
+        for _ in range(2):  # slots are reused
+            nx.search_async(as_in(qs[0]), ks[0])
+            nx.search_async(as_in(qs[1]), ks[1], subset=sub)
+            with pytest.raises(Exception, match="in flight"):
+                nx.search_async(as_in(qs[2]), ks[2])
+            with pytest.raises(Exception, match="pending|in flight"):
+                nx.search(as_in(qs[2]), ks[2])
+            with pytest.raises(Exception, match="in flight"):
+                nx.add(x[:1])
+            for j in (0, 1):
+                s, i = nx.finish()
+                np.testing.assert_array_equal(as_out(i), want[j][1])
+                np.testing.assert_array_equal(as_out(s), want[j][0])
+                if j == 0:  # one ahead: the next batch goes in before the older one of the pair is finished
+                    nx.search_async(as_in(qs[2 + (_ % 2)]), ks[2 + (_ % 2)])
+            s, i = nx.finish()
+            np.testing.assert_array_equal(as_out(i), want[2 + (_ % 2)][1])
+            np.testing.assert_array_equal(as_out(s), want[2 + (_ % 2)][0])
+            with pytest.raises(Exception, match="no search is pending"):
+                nx.finish()
+        s, i = nx.search(as_in(qs[3]), ks[3])  # the synchronous call still works afterwards
+        np.testing.assert_array_equal(as_out(i), want[3][1])

@@ -74,6 +74,8 @@ SIGNATURES: dict[str, tuple] = {
     "vodhip_node_index_set_row_labels": (_i32, [_vp, _vp, _i64]),
     "vodhip_node_index_set_query_labels": (_i32, [_vp, _vp, _i32, _i32]),
     "vodhip_node_index_search": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "vodhip_node_index_search_async": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "vodhip_node_index_search_finish": (_i32, [_vp]),
     "vodhip_merge_topk": (_i32, [_vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "vodhip_merge_topk_strided": (_i32, [_vp, _i64, _vp, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _vp]),
     "vodhip_merge_hybrid": (

@@ -52,21 +52,49 @@ struct ShardBuffers {
 
 }  // namespace
 
+// Everything ONE search in flight owns (round 6: two slots, so that the host enqueues batch i + 1 on every shard - 7 launches per shard -
+// while batch i runs: with 8 shards the enqueue alone is ~0.3 ms of host time per batch, which a synchronous search adds to every step)
+struct NodeSlot {
+    std::vector<ShardBuffers> buf;     // per shard: queries, top-k list, subset labels on its device
+    std::vector<hipEvent_t> arrived;   // shard g's result is on devices[0]
+    hipEvent_t ready = nullptr;        // on devices[0]: the caller's queries are readable / the slot's previous merge has read `gathered`
+    float* gathered_scores = nullptr;  // devices[0]: [n, nq, k]
+    int64_t* gathered_ids = nullptr;
+    float* merged_scores = nullptr;    // devices[0]: [nq, k] (host-located outputs)
+    int64_t* merged_ids = nullptr;
+    size_t gathered_elems = 0, merged_elems = 0;
+    std::vector<void*> pin_res;        // per shard: pinned [scores f32 | ids i64] of its top-k list (host-staged route)
+    std::vector<size_t> pin_res_elems;
+    std::vector<hipEvent_t> on_host;   // shard g's list is in pin_res[g]
+    void* pin_q = nullptr;             // the query batch (+ subset labels) staged from devices[0]
+    size_t pin_q_bytes = 0;
+    hipEvent_t q_on_host = nullptr;
+    hipEvent_t merge_ev[2] = {nullptr, nullptr};   // param "profile": on devices[0]
+    std::vector<hipEvent_t> copy_ev;               // [2 * n]: begin / end of shard g's copy, on its device
+    bool timed = false;                            // the events above belong to this slot's last search
+    // the search in flight
+    bool pending = false;
+    int64_t nq = 0;
+    int k = 0, location = 0;
+    float* out_scores = nullptr;
+    int64_t* out_ids = nullptr;
+    hipStream_t user = nullptr;
+};
+
 struct vodhip_node_index {
     int n = 0;
     int64_t dim = 0, capacity = 0, rows_per_shard = 0, ntotal = 0;
     int dtype = 0;
     std::vector<int> device;
     std::vector<vodhip_index_t*> shard;
-    std::vector<hipStream_t> stream;   // one per shard, on its device
-    std::vector<hipEvent_t> arrived;   // shard g's result is on devices[0]
-    std::vector<ShardBuffers> buf;
-    hipEvent_t ready = nullptr;        // on devices[0]: the caller's queries are readable / the previous merge has read `gathered`
-    float* gathered_scores = nullptr;  // devices[0]: [n, nq, k]
-    int64_t* gathered_ids = nullptr;
-    float* merged_scores = nullptr;    // devices[0]: [nq, k] (host-located outputs)
-    int64_t* merged_ids = nullptr;
-    size_t gathered_elems = 0, merged_elems = 0;
+    std::vector<hipStream_t> stream;   // one per shard, on its device: the shard's searches
+    // a finished shard's list leaves on a stream of its own: with two searches in flight the shard's search stream already holds the NEXT
+    // search's launches, and a copy enqueued behind them would hold this search's merge back by a whole batch
+    std::vector<hipStream_t> copy_stream;
+    hipStream_t merge_stream = nullptr;  // on devices[0]: merge + D2H of HOST-located searches (DEVICE-located ones merge on the caller's stream)
+    NodeSlot slot[2];
+    int next_slot = 0, n_pending = 0;  // FIFO: the oldest pending search sits in slot (next_slot - n_pending) & 1
+    int last_finished = 0;             // the slot whose profile events `get_stat` reads
     const int32_t* q_labels = nullptr;  // the caller's per-query labels for the next searches (host, or devices[0])
     int q_labels_per_query = 0, q_labels_location = VODHIP_HOST;
     bool has_row_labels = false;
@@ -75,20 +103,11 @@ struct vodhip_node_index {
     // its top-k list with devices[0] through pinned host memory instead (two DMA hops over PCIe, no xGMI)
     std::vector<int> peer_ok;          // 2 = same device as devices[0], 1 = peer access both ways, 0 = none
     int64_t host_staging = 0;
-    std::vector<void*> pin_res;        // per shard: pinned [scores f32 | ids i64] of its top-k list
-    std::vector<size_t> pin_res_elems;
-    std::vector<hipEvent_t> on_host;   // shard g's list is in pin_res[g]
-    void* pin_q = nullptr;             // the query batch (+ subset labels) staged from devices[0]
-    size_t pin_q_bytes = 0;
-    hipEvent_t q_on_host = nullptr;
     // add / reset / label changes / searches on one handle are serialised (the staging buffers and the shards' FIFOs are shared); a
     // `set_query_labels` + `search` pair is two calls: callers that filter from several threads go through a vodhip_batcher
     // param "profile" = 1: HIP events bracket the merge (recorded once every shard's list has arrived on devices[0]) and every shard's
     // copy of its list towards devices[0] - `vodhip_node_index_get_stat` reads them: "last_merge_ns", "last_copy_ns_max"
     int64_t profile = 0;
-    hipEvent_t merge_ev[2] = {nullptr, nullptr};   // on devices[0]
-    std::vector<hipEvent_t> copy_ev;               // [2 * n]: begin / end of shard g's copy, on its device
-    bool timed = false;                            // the events above belong to the last search
     std::mutex mu;
     std::vector<char> enqueued;        // shard g has a search of the CURRENT call in its FIFO (drained if the call fails half-way)
     bool staged(int g) const { return g > 0 && (host_staging != 0 || (device[g] != device[0] && peer_ok[g] == 0)); }
@@ -125,12 +144,15 @@ int vodhip_node_index_create(int n_devices, const int* devices, int64_t dim, int
     nx->device.assign(devices, devices + n_devices);
     nx->shard.assign(n_devices, nullptr);
     nx->stream.assign(n_devices, nullptr);
-    nx->arrived.assign(n_devices, nullptr);
-    nx->buf.resize(n_devices);
+    nx->copy_stream.assign(n_devices, nullptr);
+    for (NodeSlot& S : nx->slot) {
+        S.arrived.assign(n_devices, nullptr);
+        S.buf.resize(n_devices);
+        S.pin_res.assign(n_devices, nullptr);
+        S.pin_res_elems.assign(n_devices, 0);
+        S.on_host.assign(n_devices, nullptr);
+    }
     nx->peer_ok.assign(n_devices, 2);
-    nx->pin_res.assign(n_devices, nullptr);
-    nx->pin_res_elems.assign(n_devices, 0);
-    nx->on_host.assign(n_devices, nullptr);
     auto bail = [&](int rc) {
         const std::string keep = vodhip_last_error();
         vodhip_node_index_destroy(nx);
@@ -142,12 +164,17 @@ int vodhip_node_index_create(int n_devices, const int* devices, int64_t dim, int
         if (vodhip_index_create(devices[g], dim, store_dtype, hi - lo, &nx->shard[g])) return bail(-1);
         hipError_t e = hipSetDevice(devices[g]);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&nx->stream[g], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&nx->arrived[g], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&nx->copy_stream[g], hipStreamNonBlocking);
+        for (NodeSlot& S : nx->slot)
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&S.arrived[g], hipEventDisableTiming);
         if (e != hipSuccess) return bail(nfail("stream / event creation on device %d failed: %s", devices[g], hipGetErrorString(e)));
     }
     hipError_t e = hipSetDevice(devices[0]);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&nx->ready, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&nx->q_on_host, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&nx->merge_stream, hipStreamNonBlocking);
+    for (NodeSlot& S : nx->slot) {
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ready, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.q_on_host, hipEventDisableTiming);
+    }
     if (e != hipSuccess) return bail(nfail("event creation failed: %s", hipGetErrorString(e)));
     // topology: direct peer copies where both directions are possible (enabled here; "already enabled" is fine), host staging elsewhere
     for (int g = 0; g < n_devices; ++g) {
@@ -211,27 +238,39 @@ int vodhip_node_index_destroy(vodhip_node_index_t* nx) {
         (void)hipSetDevice(nx->device[g]);
         if (nx->stream[g]) (void)hipStreamSynchronize(nx->stream[g]);
         if (nx->shard[g]) (void)vodhip_index_destroy(nx->shard[g]);
-        (void)hipFree(nx->buf[g].q);
-        (void)hipFree(nx->buf[g].scores);
-        (void)hipFree(nx->buf[g].ids);
-        (void)hipFree(nx->buf[g].q_labels);
-        if (nx->arrived[g]) (void)hipEventDestroy(nx->arrived[g]);
-        if (nx->on_host[g]) (void)hipEventDestroy(nx->on_host[g]);
-        if (nx->pin_res[g]) (void)hipHostFree(nx->pin_res[g]);
+        for (NodeSlot& S : nx->slot) {
+            (void)hipFree(S.buf[g].q);
+            (void)hipFree(S.buf[g].scores);
+            (void)hipFree(S.buf[g].ids);
+            (void)hipFree(S.buf[g].q_labels);
+            if (S.arrived[g]) (void)hipEventDestroy(S.arrived[g]);
+            if (S.on_host[g]) (void)hipEventDestroy(S.on_host[g]);
+            if (S.pin_res[g]) (void)hipHostFree(S.pin_res[g]);
+        }
+        if (nx->copy_stream[g]) {
+            (void)hipStreamSynchronize(nx->copy_stream[g]);
+            (void)hipStreamDestroy(nx->copy_stream[g]);
+        }
         if (nx->stream[g]) (void)hipStreamDestroy(nx->stream[g]);
     }
-    if (nx->pin_q) (void)hipHostFree(nx->pin_q);
-    if (nx->q_on_host) (void)hipEventDestroy(nx->q_on_host);
-    for (hipEvent_t e : nx->copy_ev)
-        if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : nx->merge_ev)
-        if (e) (void)hipEventDestroy(e);
     if (nx->n && nx->shard[0]) (void)hipSetDevice(nx->device[0]);
-    (void)hipFree(nx->gathered_scores);
-    (void)hipFree(nx->gathered_ids);
-    (void)hipFree(nx->merged_scores);
-    (void)hipFree(nx->merged_ids);
-    if (nx->ready) (void)hipEventDestroy(nx->ready);
+    if (nx->merge_stream) {
+        (void)hipStreamSynchronize(nx->merge_stream);
+        (void)hipStreamDestroy(nx->merge_stream);
+    }
+    for (NodeSlot& S : nx->slot) {
+        if (S.pin_q) (void)hipHostFree(S.pin_q);
+        if (S.q_on_host) (void)hipEventDestroy(S.q_on_host);
+        for (hipEvent_t e : S.copy_ev)
+            if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : S.merge_ev)
+            if (e) (void)hipEventDestroy(e);
+        (void)hipFree(S.gathered_scores);
+        (void)hipFree(S.gathered_ids);
+        (void)hipFree(S.merged_scores);
+        (void)hipFree(S.merged_ids);
+        if (S.ready) (void)hipEventDestroy(S.ready);
+    }
     delete nx;
     (void)hipGetLastError();  // best-effort teardown: nothing of it may resurface in the caller's next launch check
     return 0;
@@ -242,6 +281,7 @@ int vodhip_node_index_add(vodhip_node_index_t* nx, const void* rows, int64_t n_r
     std::lock_guard<std::mutex> guard(nx->mu);
     if (n_rows < 0 || (n_rows > 0 && !rows)) return nfail("invalid rows");
     if (src_dtype < 0 || src_dtype > 2) return nfail("invalid src_dtype %d", src_dtype);
+    if (nx->n_pending) return nfail("%d searches are in flight: finish them before adding rows", nx->n_pending);
     if (nx->ntotal + n_rows > nx->capacity)
         return nfail("index full: ntotal=%lld + %lld > capacity=%lld", (long long)nx->ntotal, (long long)n_rows, (long long)nx->capacity);
     // global rows [ntotal, ntotal + n_rows): the part inside shard g's range goes to shard g; the shards ingest concurrently
@@ -277,6 +317,7 @@ int vodhip_node_index_add(vodhip_node_index_t* nx, const void* rows, int64_t n_r
 int vodhip_node_index_reset(vodhip_node_index_t* nx) {
     if (!nx) return nfail("index is NULL");
     std::lock_guard<std::mutex> guard(nx->mu);
+    if (nx->n_pending) return nfail("%d searches are in flight: finish them before resetting the index", nx->n_pending);
     for (int g = 0; g < nx->n; ++g)
         if (vodhip_index_reset(nx->shard[g])) return -1;
     nx->ntotal = 0;
@@ -346,33 +387,29 @@ int vodhip_node_index_set_param(vodhip_node_index_t* nx, const char* key, int64_
 
 namespace {
 
-int node_search_locked(vodhip_node_index* nx, const void* queries, int q_dtype, int64_t nq, int k, int location, float* out_scores,
-                       int64_t* out_ids, void* stream_) {
-    if (k < 1 || k > VODHIP_MAX_K) return nfail("k=%d out of range [1, %d]", k, VODHIP_MAX_K);
-    if (nq < 0 || (nq > 0 && (!queries || !out_scores || !out_ids))) return nfail("invalid query / output pointers");
-    if (q_dtype < 0 || q_dtype > 2) return nfail("invalid q_dtype %d", q_dtype);
-    if (location != VODHIP_HOST && location != VODHIP_DEVICE) return nfail("invalid location %d", location);
-    if (nq == 0) return 0;
+// step 1 of a search, into slot `S`: the query batch reaches every device (replicated: nq * dim * 2-4 bytes), then every shard's search is
+// enqueued - nothing is waited for, so the devices run side by side and the call returns while they do
+int node_enqueue_locked(vodhip_node_index* nx, NodeSlot& S, const void* queries, int q_dtype, int64_t nq, int k, int location,
+                        float* out_scores, int64_t* out_ids, void* stream_) {
     const int G = nx->n, dev0 = nx->device[0];
-    hipStream_t user = location == VODHIP_DEVICE ? (hipStream_t)stream_ : nx->stream[0];
-    nx->timed = false;
-    if (nx->profile && nx->copy_ev.empty()) {
-        nx->copy_ev.assign((size_t)2 * G, nullptr);
+    hipStream_t user = location == VODHIP_DEVICE ? (hipStream_t)stream_ : nx->merge_stream;
+    const size_t q_bytes = (size_t)nq * (size_t)nx->dim * elem_bytes(q_dtype), res = (size_t)nq * (size_t)k;
+    S.timed = false;
+    if (nx->profile && S.copy_ev.empty()) {
+        S.copy_ev.assign((size_t)2 * G, nullptr);
         for (int g = 0; g < G; ++g) {
             NODE_HIP_OK(hipSetDevice(nx->device[g]));
-            NODE_HIP_OK(hipEventCreate(&nx->copy_ev[2 * g]));
-            NODE_HIP_OK(hipEventCreate(&nx->copy_ev[2 * g + 1]));
+            NODE_HIP_OK(hipEventCreate(&S.copy_ev[2 * g]));
+            NODE_HIP_OK(hipEventCreate(&S.copy_ev[2 * g + 1]));
         }
         NODE_HIP_OK(hipSetDevice(dev0));
-        NODE_HIP_OK(hipEventCreate(&nx->merge_ev[0]));
-        NODE_HIP_OK(hipEventCreate(&nx->merge_ev[1]));
+        NODE_HIP_OK(hipEventCreate(&S.merge_ev[0]));
+        NODE_HIP_OK(hipEventCreate(&S.merge_ev[1]));
     }
-    const size_t q_bytes = (size_t)nq * (size_t)nx->dim * elem_bytes(q_dtype), res = (size_t)nq * (size_t)k;
-
     // buffers (grown on demand, kept)
     for (int g = 0; g < G; ++g) {
         NODE_HIP_OK(hipSetDevice(nx->device[g]));
-        ShardBuffers& b = nx->buf[g];
+        ShardBuffers& b = S.buf[g];
         size_t rs = b.res_elems, ri = b.res_elems;
         if (ensure(&b.q, &b.q_bytes, q_bytes, 1)) return -1;
         if (ensure((void**)&b.scores, &rs, res, sizeof(float))) return -1;
@@ -381,23 +418,21 @@ int node_search_locked(vodhip_node_index* nx, const void* queries, int q_dtype, 
     }
     NODE_HIP_OK(hipSetDevice(dev0));
     if (G > 1) {
-        size_t gs = nx->gathered_elems, gi = nx->gathered_elems;
-        if (ensure((void**)&nx->gathered_scores, &gs, res * G, sizeof(float))) return -1;
-        if (ensure((void**)&nx->gathered_ids, &gi, res * G, sizeof(int64_t))) return -1;
-        nx->gathered_elems = std::min(gs, gi);
+        size_t gs = S.gathered_elems, gi = S.gathered_elems;
+        if (ensure((void**)&S.gathered_scores, &gs, res * G, sizeof(float))) return -1;
+        if (ensure((void**)&S.gathered_ids, &gi, res * G, sizeof(int64_t))) return -1;
+        S.gathered_elems = std::min(gs, gi);
     }
     if (location == VODHIP_HOST) {
-        size_t ms = nx->merged_elems, mi = nx->merged_elems;
-        if (ensure((void**)&nx->merged_scores, &ms, res, sizeof(float))) return -1;
-        if (ensure((void**)&nx->merged_ids, &mi, res, sizeof(int64_t))) return -1;
-        nx->merged_elems = std::min(ms, mi);
+        size_t ms = S.merged_elems, mi = S.merged_elems;
+        if (ensure((void**)&S.merged_scores, &ms, res, sizeof(float))) return -1;
+        if (ensure((void**)&S.merged_ids, &mi, res, sizeof(int64_t))) return -1;
+        S.merged_elems = std::min(ms, mi);
     }
-    float* final_scores = location == VODHIP_HOST ? nx->merged_scores : out_scores;
-    int64_t* final_ids = location == VODHIP_HOST ? nx->merged_ids : out_ids;
+    float* final_scores = location == VODHIP_HOST ? S.merged_scores : out_scores;
+    int64_t* final_ids = location == VODHIP_HOST ? S.merged_ids : out_ids;
 
-    // 1. the query batch reaches every device (replicated: nq * dim * 2-4 bytes), then every shard searches - all enqueued before
-    //    anything is waited for, so the devices run side by side
-    if (location == VODHIP_DEVICE) NODE_HIP_OK(hipEventRecord(nx->ready, user));  // the caller's stream has produced the queries
+    if (location == VODHIP_DEVICE) NODE_HIP_OK(hipEventRecord(S.ready, user));  // the caller's stream has produced the queries
     bool any_staged = false;
     for (int g = 0; g < G; ++g) any_staged = any_staged || nx->staged(g);
     const size_t lab_bytes = nx->q_labels ? (size_t)nq * (size_t)nx->q_labels_per_query * sizeof(int32_t) : 0;
@@ -405,56 +440,74 @@ int node_search_locked(vodhip_node_index* nx, const void* queries, int q_dtype, 
     if (stage_q || stage_lab) {
         // shards without peer access read the batch from pinned host memory: ONE copy down from devices[0], then one copy up per shard
         const size_t want = q_bytes + lab_bytes + 64;
-        if (nx->pin_q_bytes < want) {
-            if (nx->pin_q) NODE_HIP_OK(hipHostFree(nx->pin_q));
-            nx->pin_q = nullptr;
-            NODE_HIP_OK(hipHostMalloc(&nx->pin_q, want + want / 4, hipHostMallocDefault));
-            nx->pin_q_bytes = want + want / 4;
+        if (S.pin_q_bytes < want) {
+            if (S.pin_q) NODE_HIP_OK(hipHostFree(S.pin_q));
+            S.pin_q = nullptr;
+            NODE_HIP_OK(hipHostMalloc(&S.pin_q, want + want / 4, hipHostMallocDefault));
+            S.pin_q_bytes = want + want / 4;
         }
-        if (stage_q) NODE_HIP_OK(hipMemcpyAsync(nx->pin_q, queries, q_bytes, hipMemcpyDeviceToHost, user));
-        if (stage_lab) NODE_HIP_OK(hipMemcpyAsync((char*)nx->pin_q + q_bytes, nx->q_labels, lab_bytes, hipMemcpyDeviceToHost, user));
-        NODE_HIP_OK(hipEventRecord(nx->q_on_host, user));
+        if (stage_q) NODE_HIP_OK(hipMemcpyAsync(S.pin_q, queries, q_bytes, hipMemcpyDeviceToHost, user));
+        if (stage_lab) NODE_HIP_OK(hipMemcpyAsync((char*)S.pin_q + q_bytes, nx->q_labels, lab_bytes, hipMemcpyDeviceToHost, user));
+        NODE_HIP_OK(hipEventRecord(S.q_on_host, user));
     }
     for (int g = 0; g < G; ++g) {
         NODE_HIP_OK(hipSetDevice(nx->device[g]));
         const bool staged = nx->staged(g);
         if (location == VODHIP_HOST) {
-            NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q, queries, q_bytes, hipMemcpyHostToDevice, nx->stream[g]));
+            NODE_HIP_OK(hipMemcpyAsync(S.buf[g].q, queries, q_bytes, hipMemcpyHostToDevice, nx->stream[g]));
         } else if (staged) {
-            NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], nx->q_on_host, 0));
-            NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q, nx->pin_q, q_bytes, hipMemcpyHostToDevice, nx->stream[g]));
+            NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], S.q_on_host, 0));
+            NODE_HIP_OK(hipMemcpyAsync(S.buf[g].q, S.pin_q, q_bytes, hipMemcpyHostToDevice, nx->stream[g]));
         } else {
-            NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], nx->ready, 0));
-            if (nx->device[g] == dev0) NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q, queries, q_bytes, hipMemcpyDeviceToDevice, nx->stream[g]));
-            else NODE_HIP_OK(hipMemcpyPeerAsync(nx->buf[g].q, nx->device[g], queries, dev0, q_bytes, nx->stream[g]));
+            NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], S.ready, 0));
+            if (nx->device[g] == dev0) NODE_HIP_OK(hipMemcpyAsync(S.buf[g].q, queries, q_bytes, hipMemcpyDeviceToDevice, nx->stream[g]));
+            else NODE_HIP_OK(hipMemcpyPeerAsync(S.buf[g].q, nx->device[g], queries, dev0, q_bytes, nx->stream[g]));
         }
         if (nx->q_labels) {  // the batch's subset labels travel with the queries
             const size_t n_lab = (size_t)nq * (size_t)nx->q_labels_per_query;
-            if (ensure((void**)&nx->buf[g].q_labels, &nx->buf[g].q_label_elems, n_lab, sizeof(int32_t))) return -1;
+            if (ensure((void**)&S.buf[g].q_labels, &S.buf[g].q_label_elems, n_lab, sizeof(int32_t))) return -1;
             if (nx->q_labels_location == VODHIP_HOST)
-                NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q_labels, nx->q_labels, n_lab * sizeof(int32_t), hipMemcpyHostToDevice, nx->stream[g]));
+                NODE_HIP_OK(hipMemcpyAsync(S.buf[g].q_labels, nx->q_labels, n_lab * sizeof(int32_t), hipMemcpyHostToDevice, nx->stream[g]));
             else if (staged) {
-                NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], nx->q_on_host, 0));
-                NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q_labels, (char*)nx->pin_q + q_bytes, n_lab * sizeof(int32_t), hipMemcpyHostToDevice, nx->stream[g]));
+                NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], S.q_on_host, 0));
+                NODE_HIP_OK(hipMemcpyAsync(S.buf[g].q_labels, (char*)S.pin_q + q_bytes, n_lab * sizeof(int32_t), hipMemcpyHostToDevice, nx->stream[g]));
             } else if (nx->device[g] == dev0)
-                NODE_HIP_OK(hipMemcpyAsync(nx->buf[g].q_labels, nx->q_labels, n_lab * sizeof(int32_t), hipMemcpyDeviceToDevice, nx->stream[g]));
+                NODE_HIP_OK(hipMemcpyAsync(S.buf[g].q_labels, nx->q_labels, n_lab * sizeof(int32_t), hipMemcpyDeviceToDevice, nx->stream[g]));
             else
-                NODE_HIP_OK(hipMemcpyPeerAsync(nx->buf[g].q_labels, nx->device[g], nx->q_labels, dev0, n_lab * sizeof(int32_t), nx->stream[g]));
-            if (vodhip_index_set_query_labels(nx->shard[g], nx->buf[g].q_labels, nx->q_labels_per_query)) return -1;
+                NODE_HIP_OK(hipMemcpyPeerAsync(S.buf[g].q_labels, nx->device[g], nx->q_labels, dev0, n_lab * sizeof(int32_t), nx->stream[g]));
+            if (vodhip_index_set_query_labels(nx->shard[g], S.buf[g].q_labels, nx->q_labels_per_query)) return -1;
         } else if (nx->has_row_labels) {
             if (vodhip_index_set_query_labels(nx->shard[g], nullptr, 0)) return -1;
         }
         // a G = 1 index writes the caller's / the merged buffers directly
-        float* s_out = G == 1 ? final_scores : nx->buf[g].scores;
-        int64_t* i_out = G == 1 ? final_ids : nx->buf[g].ids;
-        if (vodhip_index_search_async(nx->shard[g], nx->buf[g].q, q_dtype, nq, k, g * nx->rows_per_shard, s_out, i_out, nx->stream[g])) {
+        float* s_out = G == 1 ? final_scores : S.buf[g].scores;
+        int64_t* i_out = G == 1 ? final_ids : S.buf[g].ids;
+        if (vodhip_index_search_async(nx->shard[g], S.buf[g].q, q_dtype, nq, k, g * nx->rows_per_shard, s_out, i_out, nx->stream[g])) {
             const std::string keep = vodhip_last_error();
             return nfail("shard %d: %s", g, keep.c_str());
         }
         nx->enqueued[g] = 1;
     }
-    // 2. exactness check of every shard (host side; a shard that needs a recovery pass runs it on its own stream), then its list
-    //    travels to devices[0]
+    NODE_HIP_OK(hipSetDevice(dev0));
+    S.nq = nq;
+    S.k = k;
+    S.location = location;
+    S.out_scores = out_scores;
+    S.out_ids = out_ids;
+    S.user = user;
+    return 0;
+}
+
+// steps 2 and 3 of the search in slot `S`: the exactness check of every shard (host side; a shard that needs a recovery pass runs it on its
+// own stream), its list travels to devices[0], the merge there
+int node_finish_locked(vodhip_node_index* nx, NodeSlot& S) {
+    const int G = nx->n, dev0 = nx->device[0];
+    const int64_t nq = S.nq;
+    const int k = S.k, location = S.location;
+    hipStream_t user = S.user;
+    const size_t res = (size_t)nq * (size_t)k;
+    float* final_scores = location == VODHIP_HOST ? S.merged_scores : S.out_scores;
+    int64_t* final_ids = location == VODHIP_HOST ? S.merged_ids : S.out_ids;
     int rc = 0;
     std::string first_error;
     for (int g = 0; g < G; ++g) {
@@ -466,91 +519,140 @@ int node_search_locked(vodhip_node_index* nx, const void* queries, int q_dtype, 
         }
         if (G == 1 || rc) continue;
         NODE_HIP_OK(hipSetDevice(nx->device[g]));
-        float* ds = nx->gathered_scores + (size_t)g * res;
-        int64_t* di = nx->gathered_ids + (size_t)g * res;
+        float* ds = S.gathered_scores + (size_t)g * res;
+        int64_t* di = S.gathered_ids + (size_t)g * res;
+        hipStream_t cs = nx->copy_stream[g];  // (the shard's search is complete - `finish` waited for it on the host - so the copy depends on nothing)
         if (nx->staged(g)) {
-            // no peer access: the list goes down to pinned host memory on the shard's stream and up to devices[0] on the merge stream
-            if (nx->pin_res_elems[g] < res) {
-                if (nx->pin_res[g]) NODE_HIP_OK(hipHostFree(nx->pin_res[g]));
-                nx->pin_res[g] = nullptr;
-                NODE_HIP_OK(hipHostMalloc(&nx->pin_res[g], (res + res / 4 + 64) * 12, hipHostMallocDefault));
-                nx->pin_res_elems[g] = res + res / 4 + 64;
+            // no peer access: the list goes down to pinned host memory on the shard's copy stream and up to devices[0] on the merge stream
+            if (S.pin_res_elems[g] < res) {
+                if (S.pin_res[g]) NODE_HIP_OK(hipHostFree(S.pin_res[g]));
+                S.pin_res[g] = nullptr;
+                NODE_HIP_OK(hipHostMalloc(&S.pin_res[g], (res + res / 4 + 64) * 12, hipHostMallocDefault));
+                S.pin_res_elems[g] = res + res / 4 + 64;
             }
-            if (!nx->on_host[g]) NODE_HIP_OK(hipEventCreateWithFlags(&nx->on_host[g], hipEventDisableTiming));
-            char* pin = (char*)nx->pin_res[g];
-            if (nx->profile) NODE_HIP_OK(hipEventRecord(nx->copy_ev[2 * g], nx->stream[g]));
-            NODE_HIP_OK(hipMemcpyAsync(pin, nx->buf[g].scores, res * sizeof(float), hipMemcpyDeviceToHost, nx->stream[g]));
-            NODE_HIP_OK(hipMemcpyAsync(pin + nx->pin_res_elems[g] * 4, nx->buf[g].ids, res * sizeof(int64_t), hipMemcpyDeviceToHost, nx->stream[g]));
-            if (nx->profile) NODE_HIP_OK(hipEventRecord(nx->copy_ev[2 * g + 1], nx->stream[g]));  // (the down-leg; the up-leg runs on the merge stream)
-            NODE_HIP_OK(hipEventRecord(nx->on_host[g], nx->stream[g]));
+            if (!S.on_host[g]) NODE_HIP_OK(hipEventCreateWithFlags(&S.on_host[g], hipEventDisableTiming));
+            char* pin = (char*)S.pin_res[g];
+            if (nx->profile) NODE_HIP_OK(hipEventRecord(S.copy_ev[2 * g], cs));
+            NODE_HIP_OK(hipMemcpyAsync(pin, S.buf[g].scores, res * sizeof(float), hipMemcpyDeviceToHost, cs));
+            NODE_HIP_OK(hipMemcpyAsync(pin + S.pin_res_elems[g] * 4, S.buf[g].ids, res * sizeof(int64_t), hipMemcpyDeviceToHost, cs));
+            if (nx->profile) NODE_HIP_OK(hipEventRecord(S.copy_ev[2 * g + 1], cs));  // (the down-leg; the up-leg runs on the merge stream)
+            NODE_HIP_OK(hipEventRecord(S.on_host[g], cs));
             NODE_HIP_OK(hipSetDevice(dev0));
-            NODE_HIP_OK(hipStreamWaitEvent(user, nx->on_host[g], 0));
+            NODE_HIP_OK(hipStreamWaitEvent(user, S.on_host[g], 0));
             NODE_HIP_OK(hipMemcpyAsync(ds, pin, res * sizeof(float), hipMemcpyHostToDevice, user));
-            NODE_HIP_OK(hipMemcpyAsync(di, pin + nx->pin_res_elems[g] * 4, res * sizeof(int64_t), hipMemcpyHostToDevice, user));
-            NODE_HIP_OK(hipEventRecord(nx->arrived[g], user));  // (the merge below runs on `user` anyway: this keeps the wait list uniform)
+            NODE_HIP_OK(hipMemcpyAsync(di, pin + S.pin_res_elems[g] * 4, res * sizeof(int64_t), hipMemcpyHostToDevice, user));
+            NODE_HIP_OK(hipEventRecord(S.arrived[g], user));  // (the merge below runs on `user` anyway: this keeps the wait list uniform)
             continue;
         }
-        if (nx->profile) NODE_HIP_OK(hipEventRecord(nx->copy_ev[2 * g], nx->stream[g]));
+        if (nx->profile) NODE_HIP_OK(hipEventRecord(S.copy_ev[2 * g], cs));
         if (nx->device[g] == dev0) {
-            NODE_HIP_OK(hipMemcpyAsync(ds, nx->buf[g].scores, res * sizeof(float), hipMemcpyDeviceToDevice, nx->stream[g]));
-            NODE_HIP_OK(hipMemcpyAsync(di, nx->buf[g].ids, res * sizeof(int64_t), hipMemcpyDeviceToDevice, nx->stream[g]));
+            NODE_HIP_OK(hipMemcpyAsync(ds, S.buf[g].scores, res * sizeof(float), hipMemcpyDeviceToDevice, cs));
+            NODE_HIP_OK(hipMemcpyAsync(di, S.buf[g].ids, res * sizeof(int64_t), hipMemcpyDeviceToDevice, cs));
         } else {
-            NODE_HIP_OK(hipMemcpyPeerAsync(ds, dev0, nx->buf[g].scores, nx->device[g], res * sizeof(float), nx->stream[g]));
-            NODE_HIP_OK(hipMemcpyPeerAsync(di, dev0, nx->buf[g].ids, nx->device[g], res * sizeof(int64_t), nx->stream[g]));
+            NODE_HIP_OK(hipMemcpyPeerAsync(ds, dev0, S.buf[g].scores, nx->device[g], res * sizeof(float), cs));
+            NODE_HIP_OK(hipMemcpyPeerAsync(di, dev0, S.buf[g].ids, nx->device[g], res * sizeof(int64_t), cs));
         }
-        if (nx->profile) NODE_HIP_OK(hipEventRecord(nx->copy_ev[2 * g + 1], nx->stream[g]));
-        NODE_HIP_OK(hipEventRecord(nx->arrived[g], nx->stream[g]));
+        if (nx->profile) NODE_HIP_OK(hipEventRecord(S.copy_ev[2 * g + 1], cs));
+        NODE_HIP_OK(hipEventRecord(S.arrived[g], cs));
     }
     if (rc) return nfail("%s", first_error.c_str());
-    // 3. merge on devices[0], on the caller's stream (DEVICE) or shard 0's (HOST)
+    // the merge on devices[0], on the caller's stream (DEVICE) or shard 0's (HOST)
     NODE_HIP_OK(hipSetDevice(dev0));
     if (G > 1) {
-        for (int g = 0; g < G; ++g) NODE_HIP_OK(hipStreamWaitEvent(user, nx->arrived[g], 0));
-        if (nx->profile) NODE_HIP_OK(hipEventRecord(nx->merge_ev[0], user));  // every list has arrived: what follows is the merge alone
-        if (vodhip_merge_topk(nx->gathered_scores, nx->gathered_ids, G, nq, k, k, final_scores, final_ids, user)) return -1;
-        if (nx->profile) NODE_HIP_OK(hipEventRecord(nx->merge_ev[1], user));
-        nx->timed = nx->profile != 0;
-    } else if (location == VODHIP_DEVICE) {
-        NODE_HIP_OK(hipEventRecord(nx->arrived[0], nx->stream[0]));
-        NODE_HIP_OK(hipStreamWaitEvent(user, nx->arrived[0], 0));
+        for (int g = 0; g < G; ++g) NODE_HIP_OK(hipStreamWaitEvent(user, S.arrived[g], 0));
+        if (nx->profile) NODE_HIP_OK(hipEventRecord(S.merge_ev[0], user));  // every list has arrived: what follows is the merge alone
+        if (vodhip_merge_topk(S.gathered_scores, S.gathered_ids, G, nq, k, k, final_scores, final_ids, user)) return -1;
+        if (nx->profile) NODE_HIP_OK(hipEventRecord(S.merge_ev[1], user));
+        S.timed = nx->profile != 0;
     }
+    // (G == 1: the one shard wrote the final buffers itself and its search is complete - nothing to order on the device)
     if (location == VODHIP_HOST) {
-        NODE_HIP_OK(hipMemcpyAsync(out_scores, final_scores, res * sizeof(float), hipMemcpyDeviceToHost, user));
-        NODE_HIP_OK(hipMemcpyAsync(out_ids, final_ids, res * sizeof(int64_t), hipMemcpyDeviceToHost, user));
+        NODE_HIP_OK(hipMemcpyAsync(S.out_scores, final_scores, res * sizeof(float), hipMemcpyDeviceToHost, user));
+        NODE_HIP_OK(hipMemcpyAsync(S.out_ids, final_ids, res * sizeof(int64_t), hipMemcpyDeviceToHost, user));
         NODE_HIP_OK(hipStreamSynchronize(user));
-    } else {
-        // the next search must not overwrite `gathered` / the shard buffers before this merge has read them: the shard streams
-        // wait for `ready`, recorded again here on the caller's stream at the start of the next call - and for this call:
-        NODE_HIP_OK(hipEventRecord(nx->ready, user));
+    }
+    if (location == VODHIP_DEVICE) {
+        // the slot's NEXT search must not refill `gathered` / the shard buffers before this merge has read them: every shard stream waits
+        // for `ready`, recorded here behind the merge (the other slot's search - already enqueued on the shard streams - is ahead of the wait)
+        NODE_HIP_OK(hipEventRecord(S.ready, user));
         for (int g = 0; g < G; ++g) {
             NODE_HIP_OK(hipSetDevice(nx->device[g]));
-            NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], nx->ready, 0));
+            NODE_HIP_OK(hipStreamWaitEvent(nx->stream[g], S.ready, 0));
         }
         NODE_HIP_OK(hipSetDevice(dev0));
     }
     return 0;
 }
 
+int node_check_args(vodhip_node_index* nx, const void* queries, int q_dtype, int64_t nq, int k, int location, float* out_scores, int64_t* out_ids) {
+    if (k < 1 || k > VODHIP_MAX_K) return nfail("k=%d out of range [1, %d]", k, VODHIP_MAX_K);
+    if (nq < 0 || (nq > 0 && (!queries || !out_scores || !out_ids))) return nfail("invalid query / output pointers");
+    if (q_dtype < 0 || q_dtype > 2) return nfail("invalid q_dtype %d", q_dtype);
+    if (location != VODHIP_HOST && location != VODHIP_DEVICE) return nfail("invalid location %d", location);
+    (void)nx;
+    return 0;
+}
+
+// whatever failed (a copy, an allocation, one shard's search): no shard keeps a search of the failed call in its FIFO - the next call's
+// `finish` must meet the next call's search
+void node_drain_failed(vodhip_node_index* nx) {
+    const std::string keep = vodhip_last_error();
+    for (int g = 0; g < nx->n; ++g)
+        if (nx->enqueued[(size_t)g]) (void)vodhip_index_search_finish(nx->shard[g], nx->stream[g]);
+    (void)hipGetLastError();
+    vodhip::set_last_error(keep.c_str());
+}
+
 }  // namespace
 
 extern "C" {
 
+int vodhip_node_index_search_async(vodhip_node_index_t* nx, const void* queries, int q_dtype, int64_t nq, int k, int location,
+                                   float* out_scores, int64_t* out_ids, void* stream_) {
+    if (!nx) return nfail("index is NULL");
+    std::lock_guard<std::mutex> guard(nx->mu);
+    if (node_check_args(nx, queries, q_dtype, nq, k, location, out_scores, out_ids)) return -1;
+    if (nx->n_pending >= 2) return nfail("2 searches are already in flight on this node index: call vodhip_node_index_search_finish first");
+    NodeSlot& S = nx->slot[nx->next_slot];
+    S.nq = 0;
+    if (nq > 0) {
+        nx->enqueued.assign((size_t)nx->n, 0);
+        if (node_enqueue_locked(nx, S, queries, q_dtype, nq, k, location, out_scores, out_ids, stream_)) {
+            node_drain_failed(nx);
+            return -1;
+        }
+    }
+    S.pending = true;
+    nx->next_slot ^= 1;
+    ++nx->n_pending;
+    return 0;
+}
+
+int vodhip_node_index_search_finish(vodhip_node_index_t* nx) {
+    if (!nx) return nfail("index is NULL");
+    std::lock_guard<std::mutex> guard(nx->mu);
+    if (nx->n_pending == 0) return nfail("no search is pending on this node index");
+    const int si = (nx->next_slot - nx->n_pending) & 1;
+    NodeSlot& S = nx->slot[si];
+    S.pending = false;
+    --nx->n_pending;
+    nx->last_finished = si;
+    if (S.nq == 0) return 0;
+    nx->enqueued.assign((size_t)nx->n, 1);  // this search sits in every shard's FIFO (a shard whose finish fails has popped it itself)
+    const int rc = node_finish_locked(nx, S);
+    if (rc) node_drain_failed(nx);  // (the shards whose finish this call did not reach still hold the search)
+    return rc;
+}
+
 int vodhip_node_index_search(vodhip_node_index_t* nx, const void* queries, int q_dtype, int64_t nq, int k, int location,
                              float* out_scores, int64_t* out_ids, void* stream_) {
     if (!nx) return nfail("index is NULL");
-    std::lock_guard<std::mutex> guard(nx->mu);
-    nx->enqueued.assign((size_t)nx->n, 0);
-    const int rc = node_search_locked(nx, queries, q_dtype, nq, k, location, out_scores, out_ids, stream_);
-    if (rc) {
-        // whatever failed (a copy, an allocation, one shard's search): no shard keeps a search of this call in its FIFO - the next
-        // call's `finish` must meet the next call's search
-        const std::string keep = vodhip_last_error();
-        for (int g = 0; g < nx->n; ++g)
-            if (nx->enqueued[(size_t)g]) (void)vodhip_index_search_finish(nx->shard[g], nx->stream[g]);
-        (void)hipGetLastError();
-        vodhip::set_last_error(keep.c_str());
+    {
+        std::lock_guard<std::mutex> guard(nx->mu);
+        if (nx->n_pending) return nfail("%d asynchronous searches are pending on this node index: finish them first", nx->n_pending);
     }
-    return rc;
+    if (vodhip_node_index_search_async(nx, queries, q_dtype, nq, k, location, out_scores, out_ids, stream_)) return -1;
+    return vodhip_node_index_search_finish(nx);
 }
 
 int vodhip_node_index_get_stat(vodhip_node_index_t* nx, const char* key, int64_t* out) {
@@ -558,19 +660,20 @@ int vodhip_node_index_get_stat(vodhip_node_index_t* nx, const char* key, int64_t
     std::lock_guard<std::mutex> guard(nx->mu);
     *out = 0;
     if (!strcmp(key, "last_merge_ns") || !strcmp(key, "last_copy_ns_max")) {
-        if (!nx->timed || nx->n < 2) return 0;  // (param "profile" was off, or one shard: no exchange, no merge)
+        NodeSlot& S = nx->slot[nx->last_finished];
+        if (!S.timed || nx->n < 2) return 0;  // (param "profile" was off, or one shard: no exchange, no merge)
         float ms = 0.f;
         if (!strcmp(key, "last_merge_ns")) {
             NODE_HIP_OK(hipSetDevice(nx->device[0]));
-            NODE_HIP_OK(hipEventSynchronize(nx->merge_ev[1]));
-            NODE_HIP_OK(hipEventElapsedTime(&ms, nx->merge_ev[0], nx->merge_ev[1]));
+            NODE_HIP_OK(hipEventSynchronize(S.merge_ev[1]));
+            NODE_HIP_OK(hipEventElapsedTime(&ms, S.merge_ev[0], S.merge_ev[1]));
             *out = (int64_t)((double)ms * 1e6);
             return 0;
         }
         for (int g = 0; g < nx->n; ++g) {
             NODE_HIP_OK(hipSetDevice(nx->device[g]));
-            NODE_HIP_OK(hipEventSynchronize(nx->copy_ev[2 * g + 1]));
-            NODE_HIP_OK(hipEventElapsedTime(&ms, nx->copy_ev[2 * g], nx->copy_ev[2 * g + 1]));
+            NODE_HIP_OK(hipEventSynchronize(S.copy_ev[2 * g + 1]));
+            NODE_HIP_OK(hipEventElapsedTime(&ms, S.copy_ev[2 * g], S.copy_ev[2 * g + 1]));
             *out = std::max<int64_t>(*out, (int64_t)((double)ms * 1e6));
         }
         NODE_HIP_OK(hipSetDevice(nx->device[0]));

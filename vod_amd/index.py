@@ -409,6 +409,47 @@ class HipNodeIndex:
         _native.check(self._lib.vodhip_node_index_set_query_labels(self._h, sub.ctypes.data, int(sub.shape[1]), 0))
         return sub  # kept alive by the caller's frame until the search has returned
 
+    def search_async(self, queries: np.ndarray | torch.Tensor, k: int, subset: np.ndarray | None = None) -> None:
+        """The first half of `search` (round 6): the batch is replicated and every shard's search enqueued; `finish()` completes the OLDEST
+        pending search and returns its (scores, ids).  Up to two searches may be pending, so a caller that runs one batch ahead keeps every
+        device busy while the host enqueues the next batch's launches on all shards.  Inputs / outputs as in `search`."""
+        keep = self._set_subset(subset, int(queries.shape[0]))
+        if isinstance(queries, torch.Tensor):
+            if queries.device != self.device:
+                raise ValueError(f"queries live on {queries.device}, the merge device is {self.device}")
+            q = queries.contiguous()
+            if q.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+                q = q.float()
+            if q.ndim != 2 or q.shape[1] != self.dim:
+                raise ValueError(f"expected [nq, {self.dim}] queries, got {tuple(q.shape)}")
+            out_s = torch.empty((q.shape[0], k), dtype=torch.float32, device=self.device)
+            out_i = torch.empty((q.shape[0], k), dtype=torch.int64, device=self.device)
+            with torch.cuda.device(self.device):
+                _native.check(self._lib.vodhip_node_index_search_async(self._h, q.data_ptr(), _native.torch_dtype_code(q.dtype), q.shape[0], int(k), 1,
+                                                                       out_s.data_ptr(), out_i.data_ptr(), _native.current_stream_ptr(self.device)))
+        else:
+            q = np.ascontiguousarray(queries)
+            if q.dtype not in (np.float32, np.float16):
+                q = q.astype(np.float32)
+            if q.ndim != 2 or q.shape[1] != self.dim:
+                raise ValueError(f"expected [nq, {self.dim}] queries, got {tuple(q.shape)}")
+            out_s = np.empty((q.shape[0], k), dtype=np.float32)
+            out_i = np.empty((q.shape[0], k), dtype=np.int64)
+            _native.check(self._lib.vodhip_node_index_search_async(self._h, q.ctypes.data, 2 if q.dtype == np.float32 else 0, q.shape[0], int(k), 0,
+                                                                   out_s.ctypes.data, out_i.ctypes.data, None))
+        if not hasattr(self, "_pending"):
+            self._pending = []
+        self._pending.append((q, keep, out_s, out_i))  # (queries, labels and outputs stay alive until the finish)
+
+    def finish(self):
+        """Complete the oldest pending `search_async`; returns its (scores, ids)."""
+        if not getattr(self, "_pending", None):
+            raise RuntimeError("no search is pending on this node index")
+        with torch.cuda.device(self.device):
+            _native.check(self._lib.vodhip_node_index_search_finish(self._h))
+        _q, _keep, out_s, out_i = self._pending.pop(0)
+        return out_s, out_i
+
     def search(self, queries: np.ndarray | torch.Tensor, k: int, subset: np.ndarray | None = None):
         """NumPy in -> NumPy out (host buffers, synchronous); a tensor on `devices[0]` in -> tensors there, complete on the current stream.
         `subset`: int32 [nq, n_per_query] allowed row labels per query (-1 = empty slot; host array)."""
