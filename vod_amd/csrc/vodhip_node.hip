@@ -72,6 +72,7 @@ struct NodeSlot {
     hipEvent_t merge_ev[2] = {nullptr, nullptr};   // param "profile": on devices[0]
     std::vector<hipEvent_t> copy_ev;               // [2 * n]: begin / end of shard g's copy, on its device
     bool timed = false;                            // the events above belong to this slot's last search
+    std::vector<char> enqueued;        // shard g holds this slot's search in its FIFO (drained if a call fails half-way)
     // the search in flight
     bool pending = false;
     int64_t nq = 0;
@@ -95,6 +96,7 @@ struct vodhip_node_index {
     NodeSlot slot[2];
     int next_slot = 0, n_pending = 0;  // FIFO: the oldest pending search sits in slot (next_slot - n_pending) & 1
     int last_finished = 0;             // the slot whose profile events `get_stat` reads
+    bool finishing = false;            // a `search_finish` is running (outside the mutex: it waits for the devices) on the oldest slot
     const int32_t* q_labels = nullptr;  // the caller's per-query labels for the next searches (host, or devices[0])
     int q_labels_per_query = 0, q_labels_location = VODHIP_HOST;
     bool has_row_labels = false;
@@ -109,7 +111,6 @@ struct vodhip_node_index {
     // copy of its list towards devices[0] - `vodhip_node_index_get_stat` reads them: "last_merge_ns", "last_copy_ns_max"
     int64_t profile = 0;
     std::mutex mu;
-    std::vector<char> enqueued;        // shard g has a search of the CURRENT call in its FIFO (drained if the call fails half-way)
     bool staged(int g) const { return g > 0 && (host_staging != 0 || (device[g] != device[0] && peer_ok[g] == 0)); }
 };
 
@@ -486,7 +487,7 @@ int node_enqueue_locked(vodhip_node_index* nx, NodeSlot& S, const void* queries,
             const std::string keep = vodhip_last_error();
             return nfail("shard %d: %s", g, keep.c_str());
         }
-        nx->enqueued[g] = 1;
+        S.enqueued[g] = 1;
     }
     NODE_HIP_OK(hipSetDevice(dev0));
     S.nq = nq;
@@ -511,7 +512,7 @@ int node_finish_locked(vodhip_node_index* nx, NodeSlot& S) {
     int rc = 0;
     std::string first_error;
     for (int g = 0; g < G; ++g) {
-        nx->enqueued[g] = 0;
+        S.enqueued[g] = 0;
         if (vodhip_index_search_finish(nx->shard[g], nx->stream[g])) {
             if (!rc) first_error = std::string("shard ") + std::to_string(g) + ": " + vodhip_last_error();
             rc = -1;
@@ -595,10 +596,11 @@ int node_check_args(vodhip_node_index* nx, const void* queries, int q_dtype, int
 
 // whatever failed (a copy, an allocation, one shard's search): no shard keeps a search of the failed call in its FIFO - the next call's
 // `finish` must meet the next call's search
-void node_drain_failed(vodhip_node_index* nx) {
+void node_drain_failed(vodhip_node_index* nx, NodeSlot& S) {
     const std::string keep = vodhip_last_error();
     for (int g = 0; g < nx->n; ++g)
-        if (nx->enqueued[(size_t)g]) (void)vodhip_index_search_finish(nx->shard[g], nx->stream[g]);
+        if (S.enqueued[(size_t)g]) (void)vodhip_index_search_finish(nx->shard[g], nx->stream[g]);
+    S.enqueued.assign((size_t)nx->n, 0);
     (void)hipGetLastError();
     vodhip::set_last_error(keep.c_str());
 }
@@ -615,10 +617,10 @@ int vodhip_node_index_search_async(vodhip_node_index_t* nx, const void* queries,
     if (nx->n_pending >= 2) return nfail("2 searches are already in flight on this node index: call vodhip_node_index_search_finish first");
     NodeSlot& S = nx->slot[nx->next_slot];
     S.nq = 0;
+    S.enqueued.assign((size_t)nx->n, 0);
     if (nq > 0) {
-        nx->enqueued.assign((size_t)nx->n, 0);
         if (node_enqueue_locked(nx, S, queries, q_dtype, nq, k, location, out_scores, out_ids, stream_)) {
-            node_drain_failed(nx);
+            node_drain_failed(nx, S);
             return -1;
         }
     }
@@ -630,17 +632,25 @@ int vodhip_node_index_search_async(vodhip_node_index_t* nx, const void* queries,
 
 int vodhip_node_index_search_finish(vodhip_node_index_t* nx) {
     if (!nx) return nfail("index is NULL");
-    std::lock_guard<std::mutex> guard(nx->mu);
+    // The wait for the devices happens OUTSIDE the mutex: another thread may enqueue the next search into the other slot meanwhile (the
+    // batcher's scheduler beside its completion thread).  The slot stays counted as pending until this call is over, so it is not reused.
+    std::unique_lock<std::mutex> lk(nx->mu);
     if (nx->n_pending == 0) return nfail("no search is pending on this node index");
+    if (nx->finishing) return nfail("another vodhip_node_index_search_finish is running on this node index");
     const int si = (nx->next_slot - nx->n_pending) & 1;
     NodeSlot& S = nx->slot[si];
+    nx->finishing = true;
+    lk.unlock();
+    int rc = 0;
+    if (S.nq > 0) {
+        rc = node_finish_locked(nx, S);
+        if (rc) node_drain_failed(nx, S);  // (the shards whose finish this call did not reach still hold the search)
+    }
+    lk.lock();
     S.pending = false;
     --nx->n_pending;
     nx->last_finished = si;
-    if (S.nq == 0) return 0;
-    nx->enqueued.assign((size_t)nx->n, 1);  // this search sits in every shard's FIFO (a shard whose finish fails has popped it itself)
-    const int rc = node_finish_locked(nx, S);
-    if (rc) node_drain_failed(nx);  // (the shards whose finish this call did not reach still hold the search)
+    nx->finishing = false;
     return rc;
 }
 

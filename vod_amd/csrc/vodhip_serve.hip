@@ -283,7 +283,9 @@ void slot_free(vodhip_batcher* b, Slot& s) {
 bool make_decision(vodhip_batcher* b, tp_t now, tp_t* until) {
     *until = tp_t::max();
     const int in_flight = (int)b->inflight.size();
-    const int max_depth = b->kind == ENGINE_INDEX ? (int)std::max<int64_t>(1, b->depth) : 1;
+    // (the node index takes two searches in flight: vodhip_node_index_search_async / _finish, round 6; a host callback runs one at a time)
+    const int max_depth = b->kind == ENGINE_INDEX ? (int)std::max<int64_t>(1, b->depth)
+                          : b->kind == ENGINE_NODE ? (int)std::min<int64_t>(2, std::max<int64_t>(1, b->depth)) : 1;
     if (in_flight >= max_depth) return false;
     bool slot_ok = false;
     for (const Slot& s : b->slots) slot_ok = slot_ok || !s.busy;
@@ -425,8 +427,9 @@ int submit(vodhip_batcher* b, Batch* bt) {
     }
     if (b->kind == ENGINE_NODE) {
         if (bt->subset && vodhip_node_index_set_query_labels(b->node, s.sub_host, bt->n_subset, VODHIP_HOST)) return -1;
-        const int rc = vodhip_node_index_search(b->node, s.q_host, bt->q_dtype, bt->nq, bt->k, VODHIP_HOST, s.s_host, s.i_host, nullptr);
-        if (bt->subset) (void)vodhip_node_index_set_query_labels(b->node, nullptr, 0, VODHIP_HOST);
+        // (enqueued on every shard, not waited for: the completion thread finishes it while the scheduler assembles the next batch)
+        const int rc = vodhip_node_index_search_async(b->node, s.q_host, bt->q_dtype, bt->nq, bt->k, VODHIP_HOST, s.s_host, s.i_host, nullptr);
+        if (bt->subset) (void)vodhip_node_index_set_query_labels(b->node, nullptr, 0, VODHIP_HOST);  // the search staged its labels at enqueue time
         return rc;
     }
     // callback engine: float32 queries only (the host's engine interface: `search(np.float32[nq, d], k)`)
@@ -522,8 +525,8 @@ void scheduler_main(vodhip_batcher* b) {
             bt->err = vodhip_last_error();
         }
         bt->submitted = rc == 0;
-        if (b->kind != ENGINE_INDEX || rc) {
-            // synchronous engines (and failed submissions) complete here
+        if (b->kind == ENGINE_CALLBACK || rc) {
+            // the synchronous engine (and failed submissions) complete here
             auto it = std::find(b->inflight.begin(), b->inflight.end(), bt);
             if (it != b->inflight.end()) b->inflight.erase(it);
             complete_locked(b, bt, clock_t_::now());
@@ -544,7 +547,7 @@ void completion_main(vodhip_batcher* b) {
         lk.unlock();
         // waits for THIS search's event only (younger batches keep the device busy); if a candidate list overflowed, the library
         // runs its per-query recovery passes here - under its own per-handle lock, so the scheduler may keep enqueuing
-        const int rc = vodhip_index_search_finish(b->index, b->stream);
+        const int rc = b->kind == ENGINE_NODE ? vodhip_node_index_search_finish(b->node) : vodhip_index_search_finish(b->index, b->stream);
         const std::string err = rc ? vodhip_last_error() : "";
         lk.lock();
         b->inflight.pop_front();
@@ -606,7 +609,7 @@ int vodhip_batcher_create(vodhip_index_t* index, vodhip_node_index_t* node, vodh
     b->slots.resize(4);  // depth (<= 3) batches on the device + one being assembled / copied out
     b->t_idle_since = clock_t_::now();
     b->th_sched = std::thread(scheduler_main, b);
-    if (b->kind == ENGINE_INDEX) b->th_compl = std::thread(completion_main, b);
+    if (b->kind != ENGINE_CALLBACK) b->th_compl = std::thread(completion_main, b);
     *out = b;
     return 0;
 }
