@@ -442,7 +442,7 @@ int64_t vodhip_b64url_decode(const char* src, int64_t n, uint8_t* out);
  *
  * vodhip_batcher   fuses concurrent searches into shared corpus scans (a brute-force scan reads the whole store whatever the batch
  *   size).  Exactly one engine: `index` (searches are pipelined on the batcher's own stream, up to "depth" batches on the device,
- *   result rows written straight into device-visible host memory), `node` (the node index; one batch at a time) or `fn` (a host
+ *   result rows written straight into device-visible host memory), `node` (the node index; two batches in flight since round 6: vodhip_node_index_search_async / _finish) or `fn` (a host
  *   callback `fn(user, float32 queries [nq, dim], nq, k, subset | NULL, n_subset, out_scores, out_ids) -> 0 | error`, e.g. a
  *   multi-process group; needs no GPU in this process).  The batcher OWNS the engine's search path while it exists: do not call
  *   vodhip_index_search* on the same handle from elsewhere.
