@@ -55,6 +55,31 @@ def test_kloop_microbenchmark_cross_compiles(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
 
 
+def test_query_resident_experiment_kernel_cross_compiles_without_spills(tmp_path):
+    """experiments/csrc/kernels_mips_qres.hip (round 6's negative result, profiles/r06_ab_query_resident.txt) stays buildable for gfx950, and its
+    dim-768 instantiation keeps what the experiment depended on: 512 registers per lane (256 + 256), no scratch - a spill in that loop puts a
+    vmcnt(0) in front of the counted LDS-DMA waits."""
+    import pathlib
+    import re
+    import shutil
+
+    import pytest
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not pathlib.Path(hipcc).exists():
+        pytest.skip("no hipcc")
+    out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-I", str(ROOT / "vod_amd" / "csrc"), "-I", str(ROOT / "include"),
+                          "-Rpass-analysis=kernel-resource-usage", "-c", "-o", str(tmp_path / "qres.o"), str(ROOT / "experiments" / "csrc" / "kernels_mips_qres.hip")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = re.split(r"Function Name: ", out.stderr)[1:]
+    k768 = [b for b in blocks if "ELi24E" in b.split()[0]]
+    assert len(k768) == 4, [b.split()[0] for b in blocks]   # f16 / bf16 x corpus `nt` policy on / off
+    for b in k768:
+        assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", b) and re.search(r"VGPRs Spill: 0\b", b), b[:600]
+        assert re.search(r"AGPRs: 256\b", b) and re.search(r"Occupancy \[waves/SIMD\]: 1\b", b), b[:600]
+
+
 # ---- round 4: the launcher's failure modes (the driver's 8-GPU run gets one try) ---------------------------------------------
 
 
