@@ -281,6 +281,26 @@ int main(void) {
                         (long long)(hi[e] - 1000));
                 return 1;
             }
+        /* round 6: two searches in flight (the same batch twice into two result buffers), finished in order; a third is refused */
+        {
+            float* ns2 = (float*)malloc(sizeof(float) * nq * k);
+            int64_t* ni2 = (int64_t*)malloc(sizeof(int64_t) * nq * k);
+            int64_t merge_ns = -1;
+            memset(ns, 0, sizeof(float) * nq * k);
+            memset(ni, 0, sizeof(int64_t) * nq * k);
+            CHECK(vodhip_node_index_set_param(nx, "profile", 1));
+            CHECK(vodhip_node_index_search_async(nx, q, VODHIP_F32, nq, k, VODHIP_HOST, ns, ni, NULL));
+            CHECK(vodhip_node_index_search_async(nx, q, VODHIP_F32, nq, k, VODHIP_HOST, ns2, ni2, NULL));
+            if (vodhip_node_index_search_async(nx, q, VODHIP_F32, nq, k, VODHIP_HOST, ns2, ni2, NULL) == 0) { fprintf(stderr, "third pending search accepted\n"); return 1; }
+            CHECK(vodhip_node_index_search_finish(nx));
+            CHECK(vodhip_node_index_search_finish(nx));
+            if (vodhip_node_index_search_finish(nx) == 0) { fprintf(stderr, "finish without a pending search\n"); return 1; }
+            for (int64_t e = 0; e < nq * k; ++e)
+                if (ni[e] != hi[e] - 1000 || ns[e] != hs[e] || ni2[e] != ni[e] || ns2[e] != ns[e]) { fprintf(stderr, "pipelined node search entry %lld differs\n", (long long)e); return 1; }
+            CHECK(vodhip_node_index_get_stat(nx, "last_merge_ns", &merge_ns));
+            if (merge_ns <= 0) { fprintf(stderr, "last_merge_ns = %lld\n", (long long)merge_ns); return 1; }
+            free(ns2); free(ni2);
+        }
         int64_t base1 = -1;
         CHECK(vodhip_node_index_shard(nx, 1, NULL, &base1, NULL));
         if (base1 != 10000) { fprintf(stderr, "shard 1 starts at %lld\n", (long long)base1); return 1; }
