@@ -19,6 +19,9 @@
 //   16384 (two-slot loop, round 6) NO query bytes on-chip: the B fragments are made up once, no query pieces are staged and none are read -
 //        what ANY query-resident design could save at full (two waves per SIMD) MFMA issue: 8 instead of 12 ds_read_b128 and 2 instead of 4
 //        LDS-DMA pieces per k-step
+//   32768 (with 16384) + the accumulator hand-off of a K-SPLIT wave pair (each wave of a SIMD keeps the fragments of HALF the contraction and the
+//        partial sums of a 16-row block pass from one to the other through LDS: 8 b128 accesses per 96 MFMAs): 3 ds_write_b128 + 3 ds_read_b128
+//        every 2 k-steps
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(512, 2) void kloop(const char* __restrict__ X, cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    constexpr bool ONEQ = (MODE & 256) != 0, NOQ = (MODE & 16384) != 0;
+    constexpr bool ONEQ = (MODE & 256) != 0, NOQ = (MODE & 16384) != 0, HAND = (MODE & 32768) != 0;
     const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3, qt = ONEQ ? 0 : (jj & 3);
     const int xt0 = ONEQ ? bid : (jj >> 2) * 8 + xcd, xt_step = ONEQ ? (int)gridDim.x : (int)gridDim.x / 4;
     // fill the LDS with finite fp16 values (0.125 .. 0.25, random sign)
@@ -201,6 +204,14 @@ __global__ __launch_bounds__(512, 2) void kloop(const char* __restrict__ X, cons
             mma(f1, 6, 7);
             dma(slot, 7);
             mma(f1, 7, 8);
+            if constexpr (HAND) {  // (the accumulators really travel: written, then read back into the accumulation chain)
+                char* hb = smem + 2 * STAGE_BYTES + (wave * 64 + lane) * 16 * 3;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) *(f32x4*)(hb + u * 16) = acc[u][0];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) acc[u + 3][1] += *(const f32x4*)(hb + u * 16);
+            }
             __builtin_amdgcn_sched_barrier(0);
         } else {
             sync();
@@ -609,7 +620,7 @@ static unsigned long long* g_clk = nullptr;
 template <int MODE>
 float run(const char* X, const char* Q, float* out, int ksteps, int n_xtiles, int reps) {
     constexpr bool DEEP = (MODE & 128) != 0, WIDE = (MODE & 2048) != 0, WIDE3 = (MODE & 4096) != 0;
-    const int lds = WIDE3 ? 3 * W3_SLOT : WIDE ? 2 * W_STAGE : DEEP ? 3 * C_SLOT + 3 * Q_SLOT : 2 * STAGE_BYTES;
+    const int lds = WIDE3 ? 3 * W3_SLOT : WIDE ? 2 * W_STAGE : DEEP ? 3 * C_SLOT + 3 * Q_SLOT : 2 * STAGE_BYTES + ((MODE & 32768) ? 8 * 64 * 48 : 0);
     auto launch = [&]() {
         if constexpr (WIDE3) kwide3<MODE><<<256, 512, lds>>>(X, Q, out, ksteps, n_xtiles, g_clk);
         else if constexpr (WIDE) kwide<MODE><<<256, 512, lds>>>(X, Q, out, ksteps, n_xtiles, g_clk);
@@ -686,7 +697,7 @@ int main(int argc, char** argv) {
                 CASE(1) CASE(2) CASE(3) CASE(7) CASE(6) CASE(8) CASE(24) CASE(9) CASE(25) CASE(11) CASE(15) CASE(27) CASE(31)
                 CASE(1083) CASE(699) CASE(703) CASE(2107) CASE(2075) CASE(4155) CASE(4123) CASE(9275) CASE(8383) CASE(12347)
                 CASE(135) CASE(143) CASE(159) CASE(175) CASE(191) CASE(190) CASE(134) CASE(187) CASE(315) CASE(319) CASE(447) CASE(443) CASE(287) CASE(415)
-                CASE(16415) CASE(16447) CASE(16671) CASE(16703) CASE(43) CASE(47) CASE(59) CASE(63) CASE(35) CASE(39) CASE(67) CASE(71) CASE(127) CASE(123) CASE(95) CASE(91) CASE(79) CASE(75)
+                CASE(16415) CASE(16447) CASE(16671) CASE(16703) CASE(49215) CASE(49471) CASE(43) CASE(47) CASE(59) CASE(63) CASE(35) CASE(39) CASE(67) CASE(71) CASE(127) CASE(123) CASE(95) CASE(91) CASE(79) CASE(75)
                 default: printf("mode %d not instantiated\n", m); continue;
             }
             double ghz = 0;

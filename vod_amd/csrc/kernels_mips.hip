@@ -1216,10 +1216,12 @@ hipError_t launch_filter(int store_dtype, int tile, int mode, const void* store,
     if (filter_tile_is_persistent(tile) && mode == MODE_DENSE) tile = 1;  // nq_pad is a multiple of 256, which the 128-wide tile divides
     if (tile == 14 && mode == MODE_FILTER)  // the 8-phase K loop (kernels_mips_8phase.hip): FILTER stages of batches with >= 2 query tiles
         return launch_filter_8phase(store_dtype, 14, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
-    if (tile == 17) {  // query tile resident in registers (experiment builds; shapes it does not take run the production 8-phase kernel)
+    if (tile == 17 || tile == 18) {  // query tile resident in registers (experiment builds; shapes they do not take run the production 8-phase kernel)
 #ifdef VODHIP_EXPERIMENTS
-        if (mode == MODE_FILTER && !subset && filter_qres_supports(dim_pad))
+        if (tile == 17 && mode == MODE_FILTER && !subset && filter_qres_supports(dim_pad))
             return launch_filter_qres(store_dtype, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
+        if (tile == 18 && mode == MODE_FILTER && !subset && filter_ksplit_supports(dim_pad))
+            return launch_filter_ksplit(store_dtype, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
 #endif
         if (mode == MODE_FILTER) return launch_filter_8phase(store_dtype, 14, store, q_pad, dim_pad, row_begin, row_end, nq, nq_pad, ws, stream);
         tile = 8;

@@ -1217,7 +1217,7 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
 #else
         const bool ring_ok = false;
 #endif
-        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 14 && value != 42 && value != 46 && !(ring_ok && ((value >= 10 && value <= 13) || (value >= 15 && value <= 17))))
+        if (value != 0 && value != 1 && value != 8 && value != 9 && value != 14 && value != 42 && value != 46 && !(ring_ok && ((value >= 10 && value <= 13) || (value >= 15 && value <= 18))))
             return fail("tile must be 0 (auto) or a filter-kernel variant id: 1, 8, 9, 14, 42, 46 (DESIGN.md 4)");
         ix->tile = value;
     } else {

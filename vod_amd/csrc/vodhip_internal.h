@@ -125,7 +125,11 @@ hipError_t launch_filter_8phase(int store_dtype, int variant /* 14 = production;
 bool filter_qres_supports(int64_t dim_pad);
 hipError_t launch_filter_qres(int store_dtype, const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin, int64_t row_end,
                               int64_t nq, int64_t nq_pad, const SearchWorkspace& ws, hipStream_t stream);
-inline bool filter_tile_is_persistent(int tile) { return tile >= 8 && tile <= 17; }  // one 256 x 256 workgroup per CU walking tiles
+// ... and with a K-split wave pair, two waves per SIMD (experiments/csrc/kernels_mips_ksplit.hip; tile 18; dim_pad 768 only)
+bool filter_ksplit_supports(int64_t dim_pad);
+hipError_t launch_filter_ksplit(int store_dtype, const void* store, const void* q_pad, int64_t dim_pad, int64_t row_begin, int64_t row_end,
+                                int64_t nq, int64_t nq_pad, const SearchWorkspace& ws, hipStream_t stream);
+inline bool filter_tile_is_persistent(int tile) { return tile >= 8 && tile <= 18; }  // one 256 x 256 workgroup per CU walking tiles
 int filter_tile_rows(int tile);  // BM of the tile config
 int filter_tile_cols(int tile);  // BN of the tile config
 int filter_group_rows(int tile); // rows per GMAX group (one lane's rows of one column block)
