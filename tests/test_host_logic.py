@@ -15,6 +15,25 @@ from vod_amd import types as vt
 from vod_amd.search import base, client as vclient, sharded
 
 
+def wall_clock_test(attempts: int = 3):
+    """Tests of the batcher's timing rules assert wall-clock bounds (a scan is a 40-150 ms sleep, a grace wait 24 ms).  The bounds have slack,
+    but a loaded box can stall a thread for longer than any slack: such a test passes if ONE of a few whole attempts meets its bounds
+    (a rule that is broken misses them every time)."""
+    import functools
+
+    def wrap(fn):
+        @functools.wraps(fn)
+        def run(*a, **kw):
+            for i in range(attempts):
+                try:
+                    return fn(*a, **kw)
+                except AssertionError:
+                    if i + 1 == attempts:
+                        raise
+        return run
+    return wrap
+
+
 def _load(name):
     return np.load(GOLDEN / f"{name}.npz")
 
@@ -758,6 +777,7 @@ def test_usable_cpus_honours_affinity_and_quota(monkeypatch):
         torch.set_num_threads(before)
 
 
+@wall_clock_test()
 def test_native_batcher_gathers_the_next_batch_while_the_engine_is_busy():
     """Batch-while-busy, no window: the first request runs at once; requests that arrive while it is on the (slow) engine end up in ONE
     following batch; the engine is never entered twice at a time; a failing batch fails its own callers only."""
@@ -827,6 +847,7 @@ def test_native_batcher_gathers_the_next_batch_while_the_engine_is_busy():
     mb.close()
 
 
+@wall_clock_test()
 def test_native_batcher_waits_for_expected_company_only():
     """The grace rule: with several recently active clients an idle engine waits (a bounded moment) for the ones still missing, so closed-loop
     clients stay in ONE batch instead of falling into two alternating groups; a lone client never waits."""
