@@ -127,8 +127,9 @@ int vodhip_index_set_query_labels(vodhip_index_t* index, const int32_t* q_labels
 
 /* Tunables / introspection (tests and bench).
  * params: "cand_cap" (candidate slots per query and stage, default 16384), "dense_rows" (indexes up to this many rows are
- *   scored densely, default 2048), "sample_div" (the threshold bootstrap scores ~ntotal / sample_div sampled rows, default 96),
- *   "growth" (x100: a filter stage covers growth x the rows its threshold was calibrated on, default 800),
+ *   scored densely, default 2048), "sample_div" (the threshold bootstrap scores ~ntotal / sample_div sampled rows; 0 = auto, the default: 96, and 192
+ *   for batches above 512 queries on stores of 4 M rows and more), "growth" (x100: a filter stage covers growth x the rows its threshold
+ *   was calibrated on; 0 = auto, the default: 800, and 300 where sample_div is 192),
  *   "force_safe" (1 = exhaustive schedule: dense chunks of <= cand_cap rows), "tile" (0 = auto; 1 = 128x128, 42 / 46 = small-batch
  *   rings, 8 / 9 = persistent 256x256 two-slot kernel without / with the wave stagger, 14 = persistent 256x256 on the 8-phase K loop: the
  *   auto choice above 128 queries), "small_chunk_tiles", "profile" (1 = HIP events around

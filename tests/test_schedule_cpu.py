@@ -98,7 +98,7 @@ def _check(n, k, nq, cap=16384, tile=0, **kw):
 def test_baseline_shapes(n, k, nq):
     st_ = _check(n, k, nq)
     if n >= 100_000:
-        assert st_[0, 0] == GMAX and 3 <= len(st_) <= 7  # bootstrap + 2..6 filter stages (round 1: 6 launches, 4 of them tiny)
+        assert st_[0, 0] == GMAX and 3 <= len(st_) <= 8  # bootstrap + 2..7 filter stages (round 6: growth 3 behind a N / 192 bootstrap from 4 M rows on)
 
 
 @settings(max_examples=300, deadline=None, derandomize=True)  # (a 30,000-draw random run of the same property is clean; fixed draws keep the CPU suite reproducible)

@@ -291,16 +291,38 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
     };
 
     // ---- epilogue of one tile (the persistent kernel's, FILTER mode) ------------------------------
+    // What it costs (round 6: compile-time part removal, experiments/tools/build_p8_parts.sh with -DP8_ABL_NO_EPILOGUE / -DP8_ABL_NO_EMIT;
+    // profiles/r06_ab_epilogue.txt): on C3 the block maxima + compares 0.24 ms of a 13.2 ms batch, the SURVIVOR path below 0.85-1.28 ms
+    // (11 % of C2, 12 % of a 1.25 M-row shard).  It is not a cold path: a stage lets ~k * growth rows per query pass, 1.4-2.4 per wave
+    // tile, so ~45 % of the (wave, 16-query block) pairs take it, and the 8 waves meet at the next barrier - every tile pays its slowest
+    // wave.  Hence the planner's small stage growth (vodhip_api.hip); moving the maxima into the K loop's phases and narrowing the hit mask
+    // by fragment were built and measured: slower / equal (same profile).
     auto epilogue = [&](int x0) {
 #pragma unroll
         for (int j = 0; j < NB16; ++j) {
+#ifdef P8_ABL_NO_EPILOGUE  // timing only: the accumulators stay live, nothing is filtered
+#pragma unroll
+            for (int i = 0; i < MB; ++i) asm volatile("" ::"v"(acc[i][j]));
+            continue;
+#endif
             const int q = q0 + wn * TN + j * 16 + fr;
-            float m = acc[0][j][0];
+            // the block maximum of this lane: v_max3 chain (fmaxf costs two more v_max per value: hipcc quiets each operand first; a quiet NaN
+            // operand of v_max3 is ignored, which is what the per-value compares below do with it too)
+            float m = vmax3(acc[0][j][0], acc[0][j][1], acc[0][j][2]);
+            m = fmaxf_raw(m, acc[0][j][3]);
 #pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[i][j][r]);
+            for (int i = 1; i < MB; ++i) {
+                m = vmax3(m, acc[i][j][0], acc[i][j][1]);
+                m = vmax3(m, acc[i][j][2], acc[i][j][3]);
+            }
             const bool hit = m >= thr[j];  // false for NaN and for padded queries (thr = +inf)
+#ifdef P8_ABL_NO_EMIT  // timing only: the test runs, its survivors are dropped
+            {
+                const unsigned long long any_hit = __ballot(hit);
+                asm volatile("" ::"s"(any_hit));
+                continue;
+            }
+#endif
             if (__any(hit)) {
                 int x0_o = x0, row_end_o = row_end;
                 asm volatile("" : "+s"(x0_o), "+s"(row_end_o));

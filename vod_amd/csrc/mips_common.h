@@ -79,6 +79,18 @@ __device__ __forceinline__ void glds16_aux(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const VOD_AS1 void*)gsrc, (VOD_AS3 void*)lds_dst, 16, 0, AUX);
 }
 
+// max of three / two floats in ONE instruction, no operand canonicalisation (a quiet NaN operand is ignored)
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float fmaxf_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     // counted wait: all but the N youngest vector-memory operations of this wave are complete

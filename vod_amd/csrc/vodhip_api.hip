@@ -134,8 +134,8 @@ struct vodhip_index {
     // tunables
     int64_t cand_cap = 16384;
     int64_t dense_rows = 2048;   // indexes up to this many rows are scored densely in one launch
-    int64_t growth_x100 = 0;     // FILTER stage = growth x the rows its threshold was calibrated on; 0 = 8
-    int64_t sample_div = 96;     // GMAX bootstrap scores ~ ntotal / sample_div sampled rows (measured: 96 beats 48 by 1-1.6 % on C3 and on a 1.25 M-row shard)
+    int64_t growth_x100 = 0;     // FILTER stage = growth x the rows its threshold was calibrated on; 0 = auto (8; 3 for batches above 512 queries on stores of 4 M rows and more)
+    int64_t sample_div = 0;      // GMAX bootstrap scores ~ ntotal / sample_div sampled rows; 0 = auto (96; 192 where growth is 3)
     int64_t force_safe = 0;
     int64_t tile = 0;
     int64_t kflags = 0;
@@ -300,7 +300,15 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad,
         return make_geometric_schedule(n, k, cap, st);
     }
     const int64_t s_min = std::min(s_max, round_up(std::max<int64_t>(4 * rg * (int64_t)k, 2048), bm));
-    int64_t s = std::min(s_max, std::max(s_min, round_up(n / std::max<int64_t>(ix->sample_div, 2), bm)));
+    // Round 6: the survivor path of the FILTER epilogue is 7-10 % of a C3 batch (kernels_mips_8phase.hip), and a stage lets ~ growth * k
+    // rows per query pass: on a large store searched with a large batch, more and smaller stages behind a smaller bootstrap pay (10 M x
+    // 768, nq 1024: growth 3 + N / 192 = 6 launches against growth 8 + N / 96 = 4: -2.0 %, exact-f32 -2.1 %, clustered rows -1.9 %).  At
+    // 512 queries and fewer (half the survivors per corpus tile) and on small stores a stage's own cost - a select launch, a partial round
+    // of the persistent grid - weighs as much: measured +-0.4 % (5 M / 40 M x 1024 at nq 512, 10 M at nq 256, 1.25 M), the round-3 rule
+    // stays there (profiles/r06_ab_epilogue.txt).
+    const bool many_small_stages = n >= 4000000 && nq_pad > 512;
+    const int64_t sdiv = ix->sample_div > 0 ? ix->sample_div : (many_small_stages ? 192 : 96);
+    int64_t s = std::min(s_max, std::max(s_min, round_up(n / std::max<int64_t>(sdiv, 2), bm)));
     int64_t round_rows = ROW_ALIGN;  // corpus rows ONE round of the persistent grid covers (one 256 x 256 tile per CU)
     if (filter_tile_is_persistent(gmax_tile)) {
         round_rows = std::max<int64_t>(1, std::max(1, ix->n_cu) / std::max<int64_t>(1, nq_pad / 256)) * bm;
@@ -323,6 +331,11 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad,
         int64_t b = 0, calibrated = s;
         while (b < n) {
             int64_t rows = std::min(rows_safe, round_up((int64_t)((double)calibrated * growth), ROW_ALIGN));
+            // stages held down by the capacity bound share what is left evenly (40 M x 1024 at growth 3: 3 x 10.06 M + a 0.38 M tail otherwise)
+            if (rows == rows_safe && n - b > rows) {
+                const int64_t m = (n - b + rows_safe - 1) / rows_safe;
+                rows = std::min(rows_safe, round_up((n - b + m - 1) / m, ROW_ALIGN));
+            }
             // whole rounds of the persistent grid: a stage of r.x rounds costs r + 1 (its last round runs on a fraction of the CUs), so
             // only the LAST stage of a search may end inside a round (round 4; the capacity bound rows_safe only ever rounds DOWN)
             if (rows > round_rows) rows = rows / round_rows * round_rows;
@@ -333,7 +346,7 @@ void make_schedule(const vodhip_index* ix, int k, int gmax_tile, int64_t nq_pad,
             calibrated = e;
         }
     };
-    plan(std::min(256.0, std::max(1.25, ix->growth_x100 > 0 ? ix->growth_x100 / 100.0 : 8.0)));
+    plan(std::min(256.0, std::max(1.25, ix->growth_x100 > 0 ? ix->growth_x100 / 100.0 : (many_small_stages ? 3.0 : 8.0))));
     // A store of ~10-20 sample sizes comes out as a short first stage followed by ONE stage with all the rest (the 1.25 M-row shard
     // of the headline: 131 k + 1,119 k rows).  Three stages at growth 4 (65 k + 327 k + 858 k) measure 1.3 % faster there, six out of
     // six interleaved runs (profiles/r03_ab_growth.txt); stores that already get three or more stages are unaffected (10 M rows: growth
@@ -1190,7 +1203,7 @@ int vodhip_index_set_param(vodhip_index_t* ix, const char* key, int64_t value) {
     } else if (!strcmp(key, "kflags")) {
         ix->kflags = value;
     } else if (!strcmp(key, "sample_div")) {
-        if (value < 2) return fail("sample_div must be >= 2");
+        if (value != 0 && value < 2) return fail("sample_div must be 0 (auto) or >= 2");
         ix->sample_div = value;
     } else if (!strcmp(key, "profile")) {
         ix->profile = value;
