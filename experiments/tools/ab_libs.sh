@@ -19,7 +19,7 @@ args_of() { case $1 in
   C3clustered) echo "--data clustered --steps 12 --warmup 3";; C4) echo "--config c4 --steps 6 --warmup 2";; esac; }
 for w in $W; do
   for rep in $(seq $R); do
-    for lib in old new; do
+    for lib in ${LIBS:-old new}; do
       VODHIP_LIB=$ROOTD/experiments/_build/libvodhip_$lib.so python3 $ROOTD/bench.py $(args_of $w) --no-side --no-cpu-baseline --verify-queries 16 2>/dev/null | tail -1 | python3 /tmp/ab_libs_line.py $w $lib
     done
   done

@@ -36,7 +36,14 @@ constexpr int P8_HALF = 128 * 128;         // one half-tile: 128 rows x 128 B
 constexpr int P8_OPERANDS = 8 * P8_HALF;   // 128 KB
 constexpr int P8_WL_CAP = 256;             // records per wave list
 constexpr int P8_WL_FLUSH = 176;
-constexpr int P8_LDS = P8_OPERANDS + 8 * P8_WL_CAP * 12;
+#ifndef P8_TRANSPOSE_EMIT
+#define P8_TRANSPOSE_EMIT 1  // 0: the survivor path of rounds 1-6a (per-lane hit mask + select tree), kept for A/B builds
+#endif
+#ifndef P8_TRANSPOSE_MAX_LANES
+#define P8_TRANSPOSE_MAX_LANES 2  // query blocks with at most this many lanes holding survivors take the transpose path
+#endif
+constexpr int P8_XPOSE = 8 * 2 * 32 * 4;   // survivor transpose: per wave 2 slots of a lane's 32 sums of one query (2 KB)
+constexpr int P8_LDS = P8_OPERANDS + 8 * P8_WL_CAP * 12 + P8_XPOSE;
 static_assert(P8_LDS <= 160 * 1024, "LDS budget");
 }  // namespace
 
@@ -163,6 +170,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
     key_t64* const wl_key = (key_t64*)(smem + P8_OPERANDS) + wave * P8_WL_CAP;
     int* const wl_q = (int*)(smem + P8_OPERANDS + NWAVES * P8_WL_CAP * 8) + wave * P8_WL_CAP;
     int wl_n = 0;  // wave-uniform
+    float* const xpose = (float*)(smem + P8_OPERANDS + NWAVES * P8_WL_CAP * 12) + wave * 64;
     auto wl_flush = [&]() {
         const int n = wl_n < P8_WL_CAP ? wl_n : P8_WL_CAP;
         constexpr int PER_LANE = P8_WL_CAP / 64;
@@ -305,7 +313,9 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
             for (int i = 0; i < MB; ++i) asm volatile("" ::"v"(acc[i][j]));
             continue;
 #endif
+#if !P8_TRANSPOSE_EMIT
             const int q = q0 + wn * TN + j * 16 + fr;
+#endif
             // the block maximum of this lane: v_max3 chain (fmaxf costs two more v_max per value: hipcc quiets each operand first; a quiet NaN
             // operand of v_max3 is ignored, which is what the per-value compares below do with it too)
             float m = vmax3(acc[0][j][0], acc[0][j][1], acc[0][j][2]);
@@ -323,6 +333,94 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
                 continue;
             }
 #endif
+#if P8_TRANSPOSE_EMIT
+            // The survivor path (7-10 % of a C3 batch, profiles/r06_ab_epilogue.txt), two forms:
+            //  * TRANSPOSE: a lane that holds a survivor writes its 32 sums of this query to LDS (8 ds_write_b128) and lane t of a 32-lane half
+            //    reads sum t back: one compare, one key and one append per half handle all 32 in parallel, with row offsets that depend on the
+            //    lane number alone - no mask, no select, no per-survivor loop.  Two source lanes per pass; the source lane's threshold and
+            //    coordinates travel as scalars (v_readlane, s_ff1).  Cheapest when few lanes hold survivors (the late, large stages of a
+            //    search: one survivor in one lane is the common case) and when a lane holds several (rows sorted by topic: -4.7 %).
+            //  * MASK (rounds 1-6a): every lane compares its 32 sums into a hit mask and appends its own survivors, all lanes at once; the
+            //    score of a single survivor is the lane's maximum.  Cheapest when many lanes hold one survivor each (the early, small stages;
+            //    a 1.25 M-row shard is mostly those: all-transpose was +5.8 % there).
+            // Same records either way, in a different order (the select kernel's result does not depend on it).
+            const unsigned long long hit_lanes = __ballot(hit);
+            if (hit_lanes != 0ull) {
+                // (opaque: or hipcc computes the lane-dependent offsets of all four query blocks once, outside the K loop, and holds them in
+                // vector registers the loop does not have - it spilled 18)
+                int x0_o = x0, row_end_o = row_end, lane_o = lane;
+                asm volatile("" : "+s"(x0_o), "+s"(row_end_o));
+                asm volatile("" : "+v"(lane_o));
+                auto transpose_emit = [&]() __attribute__((always_inline)) {
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit_lanes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit_lanes, 0u));
+                    const int half = lane_o >> 5, t = lane_o & 31;
+                    unsigned long long rest = hit_lanes;
+                    int done = 0;  // source lanes handled by earlier passes
+                    do {
+                        const int slot = rank - done;
+                        if (hit && (unsigned)slot < 2u) {
+                            float* dst = xpose + slot * 32;
+#pragma unroll
+                            for (int i = 0; i < MB; ++i) *(f32x4*)(dst + 4 * i) = acc[i][j];
+                        }
+                        const int l0 = __builtin_ctzll(rest);
+                        rest &= rest - 1ull;
+                        const bool two = rest != 0ull;
+                        const int l1 = two ? __builtin_ctzll(rest) : l0;
+                        rest &= rest - 1ull;  // (0 stays 0)
+                        const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thr[j]), l0));
+                        const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thr[j]), l1));
+                        const float sc = xpose[lane_o];  // (LDS operations of one wave execute in order: the stores above have landed)
+                        const int src = half ? l1 : l0;
+                        const float thr_src = half ? t1 : t0;
+                        const int q_src = q0 + wn * TN + j * 16 + (src & 15);
+                        const int rw = x0_o + wm * TM + 4 * (src >> 4) + (t >> 2) * 16 + (t & 3);
+                        wl_append((half == 0 || two) && sc >= thr_src && rw < row_end_o, make_key(sc, (unsigned)rw), q_src);
+                        done += 2;
+                    } while (rest != 0ull);
+                };
+                if (__builtin_popcountll(hit_lanes) <= P8_TRANSPOSE_MAX_LANES) {
+                    transpose_emit();
+                } else {
+                    auto val = [&](int v) { return acc[v >> 2][j][v & 3]; };
+                    unsigned mask = 0;
+                    if (hit) {
+#pragma unroll
+                        for (int v = 0; v < MB * 4; ++v) mask |= (val(v) >= thr[j]) ? (1u << v) : 0u;
+                    }
+                    const bool multi = __any((mask & (mask - 1u)) != 0u);
+                    const int q = q0 + wn * TN + j * 16 + (lane_o & 15);
+                    do {
+                        const bool p = mask != 0u;
+                        const int b = p ? __builtin_ctz(mask) : 0;
+                        mask &= mask - 1u;
+                        float sc = m;  // (one survivor in a lane: it is the lane's maximum)
+                        if (multi) {
+                            const unsigned long long s0 = __ballot(b & 1), s1 = __ballot(b & 2), s2 = __ballot(b & 4), s3 = __ballot(b & 8),
+                                                     s4 = __ballot(b & 16);
+                            auto sel = [](float lo, float hi, unsigned long long sm) {
+                                float r;
+                                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(lo), "v"(hi), "s"(sm));
+                                return r;
+                            };
+                            float t16[16], t8[8], t4[4], t2[2];
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) t16[u] = sel(val(2 * u), val(2 * u + 1), s0);
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) t8[u] = sel(t16[2 * u], t16[2 * u + 1], s1);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) t4[u] = sel(t8[2 * u], t8[2 * u + 1], s2);
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) t2[u] = sel(t4[2 * u], t4[2 * u + 1], s3);
+                            sc = sel(t2[0], t2[1], s4);
+                        }
+                        const int rw = x0_o + wm * TM + 4 * (lane_o >> 4) + (b >> 2) * 16 + (b & 3);
+                        wl_append(p && rw < row_end_o, make_key(sc, (unsigned)rw), q);
+                    } while (__any(mask != 0u));
+                }
+            }
+        }
+#else
             if (__any(hit)) {
                 int x0_o = x0, row_end_o = row_end;
                 asm volatile("" : "+s"(x0_o), "+s"(row_end_o));
@@ -362,6 +460,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
                 } while (__any(mask != 0u));
             }
         }
+#endif
         if (wl_n >= P8_WL_FLUSH) wl_flush();
     };
 
