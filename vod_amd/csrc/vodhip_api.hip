@@ -401,7 +401,9 @@ int enqueue_search_impl(vodhip_index* ix, const PendingSearch& ps, bool safe, in
     if (tile == 0) tile = ps.nq > 128 ? 8 : (ps.nq > 64 ? 46 : 42);
     // ... and the FILTER stages of those batches run the 8-phase K loop (tile 14: C3 -2.4 %, C4 shard -4.0 %; with ONE query tile and the
     // corpus stream on the `nt` policy C2 -3.5 %, nq 256 on 10 M rows -2.7 %: profiles/r05_ab_8phase.txt, r05_ab_one_query_tile.txt); its
-    // subset instantiation spills, so filtered searches stay on tile 8, as does the bootstrap
+    // subset instantiation spilled through round 6a and is 4-5 % slower than tile 8 on filtered searches since it no longer does (2.5 M x
+    // 768, a quarter of the rows eligible: 3.95-3.99 vs 3.78-3.80 ms, experiments/tools/probe_subset_tile.py): they stay on tile 8, as does
+    // the bootstrap
     const bool auto_8phase = ix->tile == 0 && ps.nq > 128 && !(ix->row_label && ps.q_label);
     const bool persistent = filter_tile_is_persistent(tile);
     const int64_t bn = filter_tile_cols(tile);
