@@ -351,14 +351,15 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
                 int x0_o = x0, row_end_o = row_end, lane_o = lane;
                 asm volatile("" : "+s"(x0_o), "+s"(row_end_o));
                 asm volatile("" : "+v"(lane_o));
-                auto transpose_emit = [&]() __attribute__((always_inline)) {
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hit_lanes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hit_lanes, 0u));
+                // (`src_lanes`: the lanes whose sums travel; `mine`: this lane is one of them)
+                auto transpose_emit = [&](unsigned long long src_lanes, bool mine) __attribute__((always_inline)) {
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(src_lanes >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)src_lanes, 0u));
                     const int half = lane_o >> 5, t = lane_o & 31;
-                    unsigned long long rest = hit_lanes;
+                    unsigned long long rest = src_lanes;
                     int done = 0;  // source lanes handled by earlier passes
                     do {
                         const int slot = rank - done;
-                        if (hit && (unsigned)slot < 2u) {
+                        if (mine && (unsigned)slot < 2u) {
                             float* dst = xpose + slot * 32;
 #pragma unroll
                             for (int i = 0; i < MB; ++i) *(f32x4*)(dst + 4 * i) = acc[i][j];
@@ -380,43 +381,22 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
                     } while (rest != 0ull);
                 };
                 if (__builtin_popcountll(hit_lanes) <= P8_TRANSPOSE_MAX_LANES) {
-                    transpose_emit();
+                    transpose_emit(hit_lanes, hit);
                 } else {
-                    auto val = [&](int v) { return acc[v >> 2][j][v & 3]; };
+                    // many lanes: every lane compares its 32 sums into a hit mask; a lane with ONE survivor appends it from its maximum, all
+                    // such lanes at once; the lanes with several (few) send theirs through the transpose
                     unsigned mask = 0;
                     if (hit) {
 #pragma unroll
-                        for (int v = 0; v < MB * 4; ++v) mask |= (val(v) >= thr[j]) ? (1u << v) : 0u;
+                        for (int v = 0; v < MB * 4; ++v) mask |= (acc[v >> 2][j][v & 3] >= thr[j]) ? (1u << v) : 0u;
                     }
-                    const bool multi = __any((mask & (mask - 1u)) != 0u);
+                    const bool several = (mask & (mask - 1u)) != 0u;
                     const int q = q0 + wn * TN + j * 16 + (lane_o & 15);
-                    do {
-                        const bool p = mask != 0u;
-                        const int b = p ? __builtin_ctz(mask) : 0;
-                        mask &= mask - 1u;
-                        float sc = m;  // (one survivor in a lane: it is the lane's maximum)
-                        if (multi) {
-                            const unsigned long long s0 = __ballot(b & 1), s1 = __ballot(b & 2), s2 = __ballot(b & 4), s3 = __ballot(b & 8),
-                                                     s4 = __ballot(b & 16);
-                            auto sel = [](float lo, float hi, unsigned long long sm) {
-                                float r;
-                                asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(lo), "v"(hi), "s"(sm));
-                                return r;
-                            };
-                            float t16[16], t8[8], t4[4], t2[2];
-#pragma unroll
-                            for (int u = 0; u < 16; ++u) t16[u] = sel(val(2 * u), val(2 * u + 1), s0);
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) t8[u] = sel(t16[2 * u], t16[2 * u + 1], s1);
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) t4[u] = sel(t8[2 * u], t8[2 * u + 1], s2);
-#pragma unroll
-                            for (int u = 0; u < 2; ++u) t2[u] = sel(t4[2 * u], t4[2 * u + 1], s3);
-                            sc = sel(t2[0], t2[1], s4);
-                        }
-                        const int rw = x0_o + wm * TM + 4 * (lane_o >> 4) + (b >> 2) * 16 + (b & 3);
-                        wl_append(p && rw < row_end_o, make_key(sc, (unsigned)rw), q);
-                    } while (__any(mask != 0u));
+                    const int b = hit ? __builtin_ctz(mask) : 0;
+                    const int rw = x0_o + wm * TM + 4 * (lane_o >> 4) + (b >> 2) * 16 + (b & 3);
+                    wl_append(hit && !several && rw < row_end_o, make_key(m, (unsigned)rw), q);
+                    const unsigned long long several_lanes = __ballot(several);
+                    if (several_lanes != 0ull) transpose_emit(several_lanes, several);
                 }
             }
         }
