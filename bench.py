@@ -316,7 +316,9 @@ def make_queries(torch, dev, tdt, data: str, nq: int, d: int, n_total: int):
 
 NAMEPLATE_MFMA = 2.5e15   # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md): what `roofline.peak` / `frac` / `bound` use
 NAMEPLATE_HBM = 8.0e12     # HBM3E peak
-PRACTICAL_MFMA = 1.24e15   # flop/s a streaming fp16 contraction holds on this part (power-limited; HISTORY.md 5, MI355X_MICROARCH "DVFS give-back")
+PRACTICAL_MFMA = 1.33e15   # flop/s of the best-known fp16 / bf16 contraction on this part: the guide's 8-phase GEMM template, K = 4 k, uniform random
+                           # operands (cdna_hip_programming.md:377: 1.32-1.34 PF; power-limited, MI355X_MICROARCH "DVFS give-back").  Through round 6a this
+                           # was 1.24e15, the rate of our own loop - which the round-6 epilogue work passed (1.28 PF on C3)
 PRACTICAL_HBM = 6.29e12    # B/s of a streaming copy (MI355X_MICROARCH.md:34-43)
 
 
@@ -678,7 +680,7 @@ def roofline_of(m: dict, world: int) -> dict:
 
     `bound` is the roof that binds at the NAMEPLATE peaks `peak` / `frac` are quoted against (2.5 PFLOP/s dense fp16 / bf16 MFMA, 8 TB/s
     HBM: SURVEY 8d's table - C2 is HBM-bound, C3 / C4 MFMA-bound); both fractions are always reported.  `practical` holds the ceilings a
-    streaming kernel actually reaches on this part (1.24 PFLOP/s power-limited fp16 contraction, 6.29 TB/s streaming read) and the roof
+    streaming kernel actually reaches on this part (1.33 PFLOP/s: the best-known power-limited fp16 / bf16 contraction, 6.29 TB/s streaming read) and the roof
     that binds at those - context, never the basis of `frac`.  Recovery launches, if any, are part of the kernel time."""
     rows, d, nq, k, steps = m["rows"], m["dim"], m["nq"], m["k"], m["steps"]
     n_local = m["n_local"]

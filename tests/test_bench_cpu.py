@@ -204,7 +204,7 @@ def test_roofline_bound_follows_the_nameplate_peaks_and_the_traffic_key_carries_
     c2 = dict(_fake_measurement(), rows=1_000_000, n_local=1_000_000, nq=256, elapsed=0.0045 * 20, filter_ns=int(0.4e6 * 20))
     r = bench.roofline_of(c2, 1)  # C2 is HBM-bound at 8 TB/s vs 2.5 PF (0.192 ms vs 0.157 ms)
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["hbm_frac_at_8TBps"]) < 1e-12
-    assert r["practical"]["bound"] == "mfma"  # (at 1.24 PF / 6.29 TB/s the same shape is MFMA-bound: context only)
+    assert r["practical"]["bound"] == "mfma"  # (at 1.33 PF / 6.29 TB/s the same shape is MFMA-bound: context only)
     r = bench.roofline_of(_fake_measurement(), 1)
     assert r["bound"] == "mfma" and r["peak"] == 2500.0 and abs(r["frac"] - r["mfma_frac_of_2.5PF"]) < 1e-12
     assert bench.traffic_key(10_000_000, 768, 1024, 1) == "10000000x768x1024@1"
