@@ -306,25 +306,37 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
     // wave.  Hence the planner's small stage growth (vodhip_api.hip); moving the maxima into the K loop's phases and narrowing the hit mask
     // by fragment were built and measured: slower / equal (same profile).
     auto epilogue = [&](int x0) {
+#ifndef P8_ABL_NO_EPILOGUE
+        // the block maxima of this lane, all four query blocks first: four independent v_max3 chains (16 deep each) the scheduler can
+        // interleave - behind the branches of the survivor path they would run one after the other.  (v_max3, not fmaxf: hipcc quiets
+        // every operand of fmaxf first, two more v_max per value; a quiet NaN operand of v_max3 is ignored, which is what the per-value
+        // compares below do with it too.)
+        float mj[NB16];
+#pragma unroll
+        for (int j = 0; j < NB16; ++j) {
+            mj[j] = vmax3(acc[0][j][0], acc[0][j][1], acc[0][j][2]);
+            mj[j] = fmaxf_raw(mj[j], acc[0][j][3]);
+        }
+#pragma unroll
+        for (int i = 1; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB16; ++j) {
+                mj[j] = vmax3(mj[j], acc[i][j][0], acc[i][j][1]);
+                mj[j] = vmax3(mj[j], acc[i][j][2], acc[i][j][3]);
+            }
+#endif
 #pragma unroll
         for (int j = 0; j < NB16; ++j) {
 #ifdef P8_ABL_NO_EPILOGUE  // timing only: the accumulators stay live, nothing is filtered
 #pragma unroll
             for (int i = 0; i < MB; ++i) asm volatile("" ::"v"(acc[i][j]));
             continue;
+#else
+            const float m = mj[j];
 #endif
 #if !P8_TRANSPOSE_EMIT
             const int q = q0 + wn * TN + j * 16 + fr;
 #endif
-            // the block maximum of this lane: v_max3 chain (fmaxf costs two more v_max per value: hipcc quiets each operand first; a quiet NaN
-            // operand of v_max3 is ignored, which is what the per-value compares below do with it too)
-            float m = vmax3(acc[0][j][0], acc[0][j][1], acc[0][j][2]);
-            m = fmaxf_raw(m, acc[0][j][3]);
-#pragma unroll
-            for (int i = 1; i < MB; ++i) {
-                m = vmax3(m, acc[i][j][0], acc[i][j][1]);
-                m = vmax3(m, acc[i][j][2], acc[i][j][3]);
-            }
             const bool hit = m >= thr[j];  // false for NaN and for padded queries (thr = +inf)
 #ifdef P8_ABL_NO_EMIT  // timing only: the test runs, its survivors are dropped
             {
