@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
     key_t64* const wl_key = (key_t64*)(smem + P8_OPERANDS) + wave * P8_WL_CAP;
     int* const wl_q = (int*)(smem + P8_OPERANDS + NWAVES * P8_WL_CAP * 8) + wave * P8_WL_CAP;
     int wl_n = 0;  // wave-uniform
-    float* const xpose = (float*)(smem + P8_OPERANDS + NWAVES * P8_WL_CAP * 12) + wave * 64;
+    [[maybe_unused]] float* const xpose = (float*)(smem + P8_OPERANDS + NWAVES * P8_WL_CAP * 12) + wave * 64;
     auto wl_flush = [&]() {
         const int n = wl_n < P8_WL_CAP ? wl_n : P8_WL_CAP;
         constexpr int PER_LANE = P8_WL_CAP / 64;
@@ -306,7 +306,14 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
     // wave.  Hence the planner's small stage growth (vodhip_api.hip); moving the maxima into the K loop's phases and narrowing the hit mask
     // by fragment were built and measured: slower / equal (same profile).
     auto epilogue = [&](int x0) {
-#ifndef P8_ABL_NO_EPILOGUE
+#ifdef P8_ABL_NO_EPILOGUE  // timing only (experiments/tools/build_p8_parts.sh): the accumulators stay live, nothing is filtered
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB16; ++j) asm volatile("" ::"v"(acc[i][j]));
+        (void)x0;
+        return;
+#else
         // the block maxima of this lane, all four query blocks first: four independent v_max3 chains (16 deep each) the scheduler can
         // interleave - behind the branches of the survivor path they would run one after the other.  (v_max3, not fmaxf: hipcc quiets
         // every operand of fmaxf first, two more v_max per value; a quiet NaN operand of v_max3 is ignored, which is what the per-value
@@ -324,27 +331,33 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
                 mj[j] = vmax3(mj[j], acc[i][j][0], acc[i][j][1]);
                 mj[j] = vmax3(mj[j], acc[i][j][2], acc[i][j][3]);
             }
+#ifdef P8_ABL_NO_EMIT  // timing only: the tests run, their survivors are dropped
+#pragma unroll
+        for (int j = 0; j < NB16; ++j) {
+            const unsigned long long any_hit = __ballot(mj[j] >= thr[j]);
+            asm volatile("" ::"s"(any_hit));
+        }
+        (void)x0;
+        return;
+#else
+#if P8_TRANSPOSE_EMIT
+        // ... and the four tests: most tiles of a search's late stages hold no survivor for any of the wave's 64 queries - one branch, not four
+        unsigned long long hl[NB16];
+#pragma unroll
+        for (int j = 0; j < NB16; ++j) hl[j] = __ballot(mj[j] >= thr[j]);  // (false for NaN and for padded queries: thr = +inf)
+        if ((hl[0] | hl[1] | hl[2] | hl[3]) == 0ull) {
+            if (wl_n >= P8_WL_FLUSH) wl_flush();
+            return;
+        }
+        static_assert(NB16 == 4, "the early-out above");
 #endif
 #pragma unroll
         for (int j = 0; j < NB16; ++j) {
-#ifdef P8_ABL_NO_EPILOGUE  // timing only: the accumulators stay live, nothing is filtered
-#pragma unroll
-            for (int i = 0; i < MB; ++i) asm volatile("" ::"v"(acc[i][j]));
-            continue;
-#else
             const float m = mj[j];
-#endif
 #if !P8_TRANSPOSE_EMIT
             const int q = q0 + wn * TN + j * 16 + fr;
 #endif
             const bool hit = m >= thr[j];  // false for NaN and for padded queries (thr = +inf)
-#ifdef P8_ABL_NO_EMIT  // timing only: the test runs, its survivors are dropped
-            {
-                const unsigned long long any_hit = __ballot(hit);
-                asm volatile("" ::"s"(any_hit));
-                continue;
-            }
-#endif
 #if P8_TRANSPOSE_EMIT
             // The survivor path (7-10 % of a C3 batch, profiles/r06_ab_epilogue.txt), two forms:
             //  * TRANSPOSE: a lane that holds a survivor writes its 32 sums of this query to LDS (8 ds_write_b128) and lane t of a 32-lane half
@@ -356,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
             //    score of a single survivor is the lane's maximum.  Cheapest when many lanes hold one survivor each (the early, small stages;
             //    a 1.25 M-row shard is mostly those: all-transpose was +5.8 % there).
             // Same records either way, in a different order (the select kernel's result does not depend on it).
-            const unsigned long long hit_lanes = __ballot(hit);
+            const unsigned long long hit_lanes = hl[j];
             if (hit_lanes != 0ull) {
                 // (opaque: or hipcc computes the lane-dependent offsets of all four query blocks once, outside the K loop, and holds them in
                 // vector registers the loop does not have - it spilled 18)
@@ -454,6 +467,8 @@ __global__ __launch_bounds__(512, 2) void mips_filter8ph_kernel(
         }
 #endif
         if (wl_n >= P8_WL_FLUSH) wl_flush();
+#endif  // P8_ABL_NO_EMIT
+#endif  // P8_ABL_NO_EPILOGUE
     };
 
     // ---- prologue: 7 half-tiles in flight, the first K-tile landed and visible -----------------------
