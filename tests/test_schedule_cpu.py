@@ -187,3 +187,23 @@ def test_stage_tile_order_is_a_low_discrepancy_bijection():
                 run = np.sort(tiles[start : start + L])
                 gaps = np.diff(np.concatenate([[-1], run, [T]]))
                 assert gaps.max() <= 4 * (T / L) + 2, (n, L, start, gaps.max())
+
+
+def test_large_batches_on_large_stores_get_more_and_smaller_stages():
+    """Round 6 (profiles/r06_ab_epilogue.txt): a stage lets ~ growth x k rows per query pass and the survivor path of the FILTER epilogue is 7-10 %
+    of a batch, so batches above 512 queries on stores of 4 M rows and more run growth 3 behind an N / 192 bootstrap; smaller batches and
+    smaller stores keep growth 8 / N / 96 (a stage's own cost weighs as much there); explicit parameters win."""
+    big = _check(10_000_000, 100, 1024)
+    assert big[0, 0] == GMAX and len(big) >= 6                         # bootstrap + >= 5 filter stages (4 launches at growth 8)
+    s_rows = int(big[0, 3]) * 256
+    assert 10_000_000 // 256 <= s_rows <= 10_000_000 // 128            # ~ N / 192 sampled rows
+    first = int(big[1, 2] - big[1, 1])
+    assert 2.5 * s_rows <= first <= 3.5 * s_rows                        # growth 3
+    for n, k, nq in ((10_000_000, 100, 256), (10_000_000, 100, 512), (40_000_000, 200, 512), (1_250_000, 100, 1024)):
+        st_ = _check(n, k, nq)
+        s_rows = int(st_[0, 3]) * 256
+        if n >= 4_000_000:
+            assert 7 * s_rows <= int(st_[1, 2] - st_[1, 1]) <= 8 * s_rows   # growth 8 (whole rounds of the persistent grid round down)
+        assert len(st_) <= 6
+    forced = _check(10_000_000, 100, 1024, growth=800, sdiv=96)
+    assert len(forced) < len(big)
